@@ -1,0 +1,166 @@
+/*
+ * mbx.h — C-ABI of the MI355X MetaBBO rollout engine (libmbx.so).
+ *
+ * The reference (GMC-DRL/MetaBox) has no FFI: its hot path sits behind a duck-typed Python plugin
+ * protocol.  This header is the drop-in boundary a maintainer binds with ctypes
+ * to replace that path; every entry point names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - plain C types only; `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
+ *   - pointers named d_* are DEVICE pointers owned by the caller; all others are host pointers.
+ *   - every function returns 0 on success or a negative MBX_E_* code; mbx_last_error() returns a
+ *     thread-local message for the last failure.  No exceptions cross the ABI.
+ *   - a handle is not thread-safe; distinct handles may be used from distinct threads.
+ *   - launches are asynchronous on `stream`; the caller synchronises before reading d_* outputs.
+ */
+#ifndef MBX_H
+#define MBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBX_OK            0
+#define MBX_E_ARG        -1   /* invalid argument (reference raises ValueError / AssertionError)   */
+#define MBX_E_HIP        -2   /* a HIP runtime call failed                                          */
+#define MBX_E_UNSUPPORTED -3  /* valid request that this build does not implement (NotImplementedError) */
+#define MBX_E_NOMEM      -4
+
+/* ------------------------------------------------------------------------------------------------
+ * Problem description — one entry per problem instance of a suite.
+ * Replaces the per-instance attributes of the reference's problem objects:
+ *   BBOB / noisy BBOB: src/problem/bbob.py:31-47 (dim, shift, rotate, bias, lb, ub, optimum) plus the
+ *   per-class extras created in the constructors (bbob.py:233,250,294,314,360,423,589,609,634,694,
+ *   744,768-794,847,873); noise mix-ins bbob.py:96-146.
+ *   Protein docking: src/problem/protein_docking.py:9-26 (coor_init, q, e, r, basis, eigval).
+ * `kind` selects the base objective: 1..24 = BBOB F1..F24 (noisy ids map onto their base kind),
+ * MBX_KIND_PROTEIN = protein-docking energy.  Unused pointers are NULL.
+ * ---------------------------------------------------------------------------------------------- */
+#define MBX_KIND_PROTEIN 100
+
+#define MBX_NOISE_NONE    0
+#define MBX_NOISE_GAUSS   1   /* f*exp(a*N)                                   bbob.py:108-119 */
+#define MBX_NOISE_UNIFORM 2   /* f*U^b*max(1,(1e9/(f+1e-99))^(a*(.49+1/D)*U'))  bbob.py:122-132 */
+#define MBX_NOISE_CAUCHY  3   /* f+a*max(0,1e3+[U<b]*N/(|N'|+1e-199))         bbob.py:135-146 */
+
+typedef struct mbx_problem_desc {
+    int32_t func_id;      /* 1..24, 101..130, or 0 for protein                                   */
+    int32_t kind;         /* base objective, see above                                           */
+    int32_t dim;
+    int32_t n_peaks;      /* Gallagher: 101 or 21; protein: number of atoms (100)                */
+    int32_t noise_kind;   /* MBX_NOISE_*                                                         */
+    int32_t reserved;
+    double  bias, lb, ub;
+    double  pen_coef;     /* coefficient of boundaryHandling(x) = pen_coef * sum(max(0,|x|-ub)^2) */
+    double  s[4];         /* kind-specific scalars (metabox_amd/problem/bbob.py: BBOB_Problem.desc) */
+    double  noise_a, noise_b;
+    const double* dshift; /* [dim]      subtracted from x before m1                              */
+    const double* m1;     /* [dim,dim]  first linear map, row-major (z_i = sum_k m1[i,k] y_k)    */
+    const double* m2;     /* [dim,dim]  second linear map or NULL                                */
+    const double* v0;     /* [dim]      per-dimension constants or NULL                          */
+    const double* v1;
+    const double* v2;
+    const double* py;     /* Gallagher peaks  [n_peaks,dim]; protein: basis/sqrt(eigval) [dim,3*n] */
+    const double* pc;     /* Gallagher C      [n_peaks,dim]; protein: coor_init [n,3]            */
+    const double* pw;     /* Gallagher w      [n_peaks];     protein: q|sqrt(e)|r  [3,n,n]       */
+} mbx_problem_desc;
+
+typedef struct mbx_suite mbx_suite;
+typedef struct mbx_batch mbx_batch;
+
+/* Upload a problem set (reference: construct_problem_set, src/utils.py:4-27 -> the list of problem
+ * objects every optimizer evaluates against).  Also evaluates optimum_i = f_i(opt_i) on the device
+ * like BBOB_Basic_Problem.__init__ (bbob.py:42); opt == NULL entries (protein) get optimum = NaN,
+ * the ABI's spelling of the reference's `optimum = None`.  `opt` is [n_problems][dim] or NULL. */
+int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, const double* opt, mbx_suite** out);
+int mbx_suite_destroy(mbx_suite* s);
+int mbx_suite_size(const mbx_suite* s);
+/* host copy of optimum_i (problem.optimum; NaN = None) */
+int mbx_suite_optimum(const mbx_suite* s, double* optimum_out /* [n_problems] */);
+
+/* Stand-alone objective evaluation: Basic_Problem.eval / F*.func (src/problem/basic_problem.py:12-34).
+ * d_x is [n, dim] row-major, d_f is [n]; the bias is included, the optimum is NOT subtracted.
+ * noisy != 0 applies the noise model like NoisyProblem.eval (bbob.py:100-102) with Philox draws keyed
+ * by (seed, row); with d_noise_draws != NULL ([3, n]: the model's draws in the reference's call order)
+ * those values are used instead of Philox (replay of recorded numpy draws). */
+int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f,
+             int noisy, uint64_t seed, const double* d_noise_draws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Lock-step batch of independent (problem x run) optimizer instances.
+ * ---------------------------------------------------------------------------------------------- */
+#define MBX_ALGO_RLEPSO 1   /* src/optimizer/rlepso_optimizer.py   one step = one generation       */
+#define MBX_ALGO_LDE    2   /* src/optimizer/lde_optimizer.py      one step = one generation       */
+#define MBX_ALGO_DEDDQN 3   /* src/optimizer/de_ddqn_optimizer.py  one step = one trial vector     */
+#define MBX_ALGO_RANDOM_SEARCH 4 /* src/optimizer/random_search.py  one step = NP uniform samples   */
+
+typedef struct mbx_algo_cfg {
+    int32_t algo;          /* MBX_ALGO_*                                                          */
+    int32_t np;            /* population size: reference hard-codes 100 (RLEPSO, rlepso_optimizer.py:11),
+                              50 (LDE, lde_optimizer.py:10), 100 (DE-DDQN, de_ddqn_optimizer.py:12) */
+    int32_t dim;
+    int32_t max_fes;       /* config.maxFEs       (src/config.py:74,88)                           */
+    int32_t log_interval;  /* config.log_interval (src/config.py:102)                             */
+    int32_t n_logpoint;    /* config.n_logpoint   (src/config.py:77,90)                           */
+    int32_t early_stop;    /* 1 = reference rule `done = fes>=maxFEs or gbest<=1e-8`; 0 = fixed horizon */
+    int32_t n_group;       /* RLEPSO: 5 (rlepso_optimizer.py:26)                                  */
+} mbx_algo_cfg;
+
+/* Dimensions of the per-step tensors for a configuration (so callers can size buffers):
+ *   RLEPSO : state [1]      (fes/maxFEs, rlepso_optimizer.py:170-171), action [35] float32
+ *   LDE    : state [np+10]  (lde_optimizer.py:145-157),               action [2*np] float32
+ *   DEDDQN : state [99]     (de_ddqn_optimizer.py:76-129),            action [1] int32      */
+int mbx_state_dim(const mbx_algo_cfg* cfg);
+int mbx_action_dim(const mbx_algo_cfg* cfg);
+/* number of doubles of external random numbers one instance consumes per step (see mbx_set_tape) */
+int64_t mbx_tape_stride(const mbx_algo_cfg* cfg);
+
+/* Create B instances.  problem_idx[i] indexes the suite, seeds[i] is the Philox key of instance i
+ * (results depend only on (problem, seed), never on batch position or GPU count).
+ * Replaces the (problem x run) enumeration of Tester.test / rollout (src/tester.py:190-202,317-328)
+ * and the `PBO_Env(problem, optimizer)` construction per pair. */
+int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int32_t* problem_idx,
+                     const uint64_t* seeds, int n_instances, mbx_batch** out);
+int mbx_batch_destroy(mbx_batch* b);
+
+/* Replace the Philox source by caller-supplied random numbers for the NEXT mbx_reset / mbx_step:
+ * d_tape is [n_instances, mbx_tape_stride()] doubles laid out as documented in
+ * include/mbx_layout.h (one slot per draw site of the reference's update()).  NULL restores
+ * Philox.  This is the replay hook that lets recorded numpy draws drive the kernel. */
+int mbx_set_tape(mbx_batch* b, const double* d_tape);
+
+/* PBO_Env.reset() for every instance: problem.reset(); optimizer.init_population(problem)
+ * (src/environment/basic_environment.py:17-19, rlepso_optimizer.py:39-65).  Writes the initial state
+ * [n_instances, state_dim] (float64). */
+int mbx_reset(mbx_batch* b, double* d_state_out, void* stream);
+
+/* PBO_Env.step(action) for every instance that is not done: optimizer.update(action, problem)
+ * (basic_environment.py:21-22, rlepso_optimizer.py:173-263).  d_actions is
+ * [n_instances, action_dim] (float32; int32 for DEDDQN).  Outputs: next state (float64),
+ * reward (float64), done (uint8).  Done instances are left untouched and report reward 0. */
+int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out,
+             uint8_t* d_done_out, void* stream);
+
+/* Per-instance results, the fields rollout_episode returns (src/agent/rlepso_agent.py:294-303):
+ * cost curve `optimizer.cost` padded to n_logpoint+1 entries with its last value
+ * (src/tester.py:204-205), fes, return (sum of rewards), executed env-steps, and the live length of the
+ * cost list.  Any pointer may be NULL. */
+int mbx_results(mbx_batch* b, double* d_cost_curves /* [B, n_logpoint+1] */, double* d_fes /* [B] */,
+                double* d_return /* [B] */, int32_t* d_steps /* [B] */, int32_t* d_cost_len /* [B] */,
+                void* stream);
+
+/* Test / diagnostics: copy the internal per-instance optimizer state to the host.
+ * RLEPSO layout: see MBX_RLEPSO_* offsets in include/mbx_layout.h. */
+int64_t mbx_instance_state_doubles(const mbx_batch* b);
+int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out);
+
+const char* mbx_last_error(void);
+const char* mbx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBX_H */

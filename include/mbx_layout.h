@@ -1,0 +1,103 @@
+/*
+ * mbx_layout.h — data layouts that are part of the C-ABI contract (shared by libmbx.so, its host
+ * mirror and the test oracle; it defines formats only, no algorithm).
+ *
+ *  1. the per-step "tape" of external random numbers (mbx_set_tape),
+ *  2. the per-instance optimizer state exposed by mbx_debug_read_state,
+ *  3. the Philox4x32-10 draw-site map (which counter produces which random number).
+ *
+ * All sizes are in doubles; NP = population size, D = dimension.
+ */
+#ifndef MBX_LAYOUT_H
+#define MBX_LAYOUT_H
+
+#include <stdint.h>
+
+/* ---------------------------------------------------------------- 1. RLEPSO tape (per instance, per step)
+ * Slots follow the draw order of RLEPSO_Optimizer.update (reference: rlepso_optimizer.py:179-180,
+ * 77,88,108, eval noise, 238, 137-138, eval noise):
+ *   rand1[NP] rand2[NP] clpso_u[NP*D] tourn_idx[NP*D*2] fdr_u[NP*D] noise_main[3*NP]
+ *   reinit_u[NP] reinit_pos_u[NP*D] reinit_vel_u[NP*D] noise_reinit[3*NP]
+ * Every value is the raw draw (U[0,1), integer index, or N(0,1)); the kernel applies low+(high-low)*u.
+ * mbx_reset (init_population, rlepso_optimizer.py:40-42) uses the reinit_pos_u / reinit_vel_u /
+ * noise_reinit slots.  The three noise rows hold the noise model's draws in the reference's call
+ * order (gauss: N; uniform: U,U'; cauchy: U,N,N').                                                    */
+#define MBX_RLEPSO_TAPE_RAND1(NP, D)      ((int64_t)0)
+#define MBX_RLEPSO_TAPE_RAND2(NP, D)      ((int64_t)(NP))
+#define MBX_RLEPSO_TAPE_CLPSO(NP, D)      ((int64_t)2 * (NP))
+#define MBX_RLEPSO_TAPE_TOURN(NP, D)      ((int64_t)2 * (NP) + (int64_t)(NP) * (D))
+#define MBX_RLEPSO_TAPE_FDR(NP, D)        ((int64_t)2 * (NP) + (int64_t)3 * (NP) * (D))
+#define MBX_RLEPSO_TAPE_NOISE0(NP, D)     ((int64_t)2 * (NP) + (int64_t)4 * (NP) * (D))
+#define MBX_RLEPSO_TAPE_REINIT(NP, D)     ((int64_t)5 * (NP) + (int64_t)4 * (NP) * (D))
+#define MBX_RLEPSO_TAPE_REPOS(NP, D)      ((int64_t)6 * (NP) + (int64_t)4 * (NP) * (D))
+#define MBX_RLEPSO_TAPE_REVEL(NP, D)      ((int64_t)6 * (NP) + (int64_t)5 * (NP) * (D))
+#define MBX_RLEPSO_TAPE_NOISE1(NP, D)     ((int64_t)6 * (NP) + (int64_t)6 * (NP) * (D))
+#define MBX_RLEPSO_TAPE_STRIDE(NP, D)     ((int64_t)9 * (NP) + (int64_t)6 * (NP) * (D))
+
+/* ---------------------------------------------------------------- 2. RLEPSO instance state (HBM, doubles)
+ * One contiguous block per instance (one workgroup streams it in and out per generation):
+ *   cur_pos[NP*D] vel[NP*D] pbest_pos[NP*D] c_cost[NP] pbest[NP] per_no_improve[NP] gbest_pos[D]
+ *   scalars[MBX_NSCALAR] cost_curve[n_logpoint+1]
+ * (the fields of RLEPSO_Optimizer.__particles, rlepso_optimizer.py:53-61, plus fes/cost/log_index).   */
+#define MBX_RLEPSO_ST_POS(NP, D)      ((int64_t)0)
+#define MBX_RLEPSO_ST_VEL(NP, D)      ((int64_t)(NP) * (D))
+#define MBX_RLEPSO_ST_PBPOS(NP, D)    ((int64_t)2 * (NP) * (D))
+#define MBX_RLEPSO_ST_CCOST(NP, D)    ((int64_t)3 * (NP) * (D))
+#define MBX_RLEPSO_ST_PBEST(NP, D)    ((int64_t)3 * (NP) * (D) + (NP))
+#define MBX_RLEPSO_ST_PNI(NP, D)      ((int64_t)3 * (NP) * (D) + 2 * (NP))
+#define MBX_RLEPSO_ST_GBPOS(NP, D)    ((int64_t)3 * (NP) * (D) + 3 * (NP))
+#define MBX_RLEPSO_ST_SCALARS(NP, D)  ((int64_t)3 * (NP) * (D) + 3 * (NP) + (D))
+
+/* scalar slots (shared by every algorithm's state block) */
+#define MBX_SC_GBEST      0   /* gbest_val                                         */
+#define MBX_SC_FES        1   /* optimizer.fes                                     */
+#define MBX_SC_LOG_INDEX  2   /* optimizer.log_index                               */
+#define MBX_SC_COST_LEN   3   /* len(optimizer.cost)                               */
+#define MBX_SC_DONE       4   /* 1.0 once update() has returned is_done            */
+#define MBX_SC_RETURN     5   /* sum of rewards (rollout_episode's R)              */
+#define MBX_SC_GEN        6   /* number of update() calls executed this episode    */
+#define MBX_SC_EPISODE    7   /* number of resets so far (Philox counter word 3)   */
+#define MBX_SC_GBEST_IDX  8   /* gbest_index                                       */
+#define MBX_SC_REINIT     9   /* 1.0 if __reinit fired in the last step (diagnostic) */
+#define MBX_NSCALAR       16
+
+#define MBX_RLEPSO_STATE_DOUBLES(NP, D, NLOG) \
+    (MBX_RLEPSO_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+
+/* ---------------------------------------------------------------- 3. Philox4x32-10 draw sites
+ * key     = (seed_lo, seed_hi)             the instance's 64-bit seed
+ * counter = (index, site, generation, episode)
+ * A call yields four 32-bit words w0..w3.  u53(a,b) = ((a>>5)*2^26 + (b>>6)) / 2^53  in [0,1).
+ * Integer draws in [0,n): mulhi32(w, n).  Normal pairs: Box-Muller on (1-u53(w0,w1), u53(w2,w3)):
+ * r = sqrt(-2 ln(1-ua)), n0 = r cos(2 pi ub), n1 = r sin(2 pi ub).
+ *
+ *   site                 index        words
+ *   MBX_SITE_ELEM_A      e = i*D+d    u53(w0,w1) = clpso_u[e];  mulhi(w2,NP), mulhi(w3,NP) = tournament pair
+ *   MBX_SITE_ELEM_B      e            u53(w0,w1) = fdr_u[e]
+ *   MBX_SITE_PART        i            u53(w0,w1) = rand1[i];    u53(w2,w3) = rand2[i]
+ *   MBX_SITE_REINIT      i            u53(w0,w1) = reinit_u[i]
+ *   MBX_SITE_ELEM_R      e            u53(w0,w1) = pos_u[e];    u53(w2,w3) = vel_u[e]   (init + reinit)
+ *   MBX_SITE_NOISE0_A/B  i            main evaluation:   A -> (ua,ub), B -> (uc,ud)
+ *   MBX_SITE_NOISE1_A/B  i            init / reinit evaluation
+ *       gauss  : N = n0(ua,ub)            uniform: U = ua, U' = ub
+ *       cauchy : U = ua, (N, N') = (n0, n1)(uc,ud)
+ */
+#define MBX_SITE_ELEM_A    0u
+#define MBX_SITE_ELEM_B    1u
+#define MBX_SITE_PART      2u
+#define MBX_SITE_REINIT    3u
+#define MBX_SITE_ELEM_R    4u
+#define MBX_SITE_NOISE0_A  5u
+#define MBX_SITE_NOISE0_B  6u
+#define MBX_SITE_NOISE1_A  7u
+#define MBX_SITE_NOISE1_B  8u
+/* stand-alone mbx_eval noise: counter = (row, MBX_SITE_EVAL_A/B, 0, 0) */
+#define MBX_SITE_EVAL_A    9u
+#define MBX_SITE_EVAL_B    10u
+
+#define MBX_PHILOX_M0 0xD2511F53u
+#define MBX_PHILOX_M1 0xCD9E8D57u
+#define MBX_PHILOX_W0 0x9E3779B9u
+#define MBX_PHILOX_W1 0xBB67AE85u
+
+#endif /* MBX_LAYOUT_H */

@@ -1,0 +1,384 @@
+// mbx.hip — libmbx.so: kernels' launch code and the C-ABI of include/mbx.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared mbx.hip -o libmbx.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mbx_device.hpp"
+#include "mbx_rlepso.hpp"
+
+using namespace mbx;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(MBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ handles
+struct mbx_suite {
+    int n = 0, dim = 0;
+    double* d_pool = nullptr;
+    DevProblem* d_problems = nullptr;
+    std::vector<DevProblem> h_problems;       // device pointers inside
+    std::vector<double> optimum;
+};
+
+struct mbx_batch {
+    mbx_suite* suite = nullptr;
+    mbx_algo_cfg cfg{};
+    int B = 0;
+    int32_t* d_problem_idx = nullptr;
+    uint64_t* d_seeds = nullptr;
+    double* d_state = nullptr;
+    int64_t state_stride = 0;
+    const double* d_tape = nullptr;
+    size_t lds_bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ kernels
+// Stand-alone evaluation: each block stages the problem's linear maps and evaluates up to `rows` rows.
+__global__ __launch_bounds__(kThreads) void k_eval(const DevProblem* problems, int problem, const double* __restrict__ x, int n,
+                                                   int rows, double* __restrict__ f, int noisy, uint64_t seed,
+                                                   const double* __restrict__ draws)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem P = problems[problem];
+    const int D = P.dim, tid = threadIdx.x;
+    const int row0 = blockIdx.x * rows;
+    const int m = min(rows, n - row0);
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D);
+    double* X = smem;
+    double* T = X + NE;
+    double* Z = T + NE;
+    double* M1T = Z + SC;
+    double* M2T = M1T + DD;
+    double* F = M2T + DD;
+    stage_transposed(P.m1, D, M1T);
+    stage_transposed(P.m2, D, M2T);
+    for (int e = tid; e < m * D; e += kThreads) X[e] = x[(int64_t)row0 * D + e];
+    __syncthreads();
+    eval_rows(P, X, m, Z, T, M1T, M2T, F);
+    for (int i = tid; i < m; i += kThreads) {
+        double v = F[i];
+        if (noisy && P.noise_kind != MBX_NOISE_NONE) {
+            double a, b, c;
+            const int r = row0 + i;
+            if (draws) { a = draws[r]; b = draws[n + r]; c = draws[2 * (int64_t)n + r]; }
+            else {
+                const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u};
+                philox_noise(rng, (uint32_t)r, MBX_SITE_EVAL_A, MBX_SITE_EVAL_B, P.noise_kind, a, b, c);
+            }
+            v = apply_noise(P, v, a, b, c);
+        }
+        f[row0 + i] = v;
+    }
+}
+
+static size_t eval_lds_bytes(int rows, int D)
+{
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D);
+    return (size_t)(2 * NE + SC + 2 * DD + align2(rows)) * sizeof(double);
+}
+
+__global__ void k_init_state(double* state, int64_t stride, int64_t sc_off, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) state[(int64_t)b * stride + sc_off + MBX_SC_EPISODE] = -1.;
+}
+
+__global__ void k_set_optimum(DevProblem* problems, const double* opt, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) problems[i].optimum = opt[i];
+}
+
+// rollout_episode's return fields for every instance (rlepso_agent.py:303), cost padded with its last value
+__global__ void k_results(const double* state, int64_t stride, int64_t sc_off, int B, int nlog, double* cost, double* fes,
+                          double* ret, int32_t* steps, int32_t* cost_len)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* sc = state + (int64_t)b * stride + sc_off;
+    const int len = (int)sc[MBX_SC_COST_LEN];
+    if (cost)
+        for (int k = 0; k <= nlog; ++k) cost[(int64_t)b * (nlog + 1) + k] = sc[MBX_NSCALAR + (k < len ? k : len - 1)];
+    if (fes) fes[b] = sc[MBX_SC_FES];
+    if (ret) ret[b] = sc[MBX_SC_RETURN];
+    if (steps) steps[b] = (int32_t)sc[MBX_SC_GEN];
+    if (cost_len) cost_len[b] = len;
+}
+
+// ------------------------------------------------------------------------------------------------ suite
+static int max_lds_bytes()
+{
+    int v = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+    return v;
+}
+
+static int launch_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f, int noisy, uint64_t seed,
+                       const double* d_draws, hipStream_t st)
+{
+    if (n <= 0) return MBX_OK;
+    const int D = s->dim;
+    int rows = n < 128 ? n : 128;
+    const int cap = max_lds_bytes();
+    while (rows > 1 && eval_lds_bytes(rows, D) > (size_t)cap) rows /= 2;
+    const size_t lds = eval_lds_bytes(rows, D);
+    if (lds > (size_t)cap) return fail(MBX_E_UNSUPPORTED, "dim %d needs %zu B of LDS (> %d)", D, lds, cap);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (n + rows - 1) / rows;
+    hipLaunchKernelGGL(k_eval, dim3(grid), dim3(kThreads), lds, st, s->d_problems, problem, d_x, n, rows, d_f, noisy, seed,
+                       d_draws);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, const double* opt, mbx_suite** out)
+{
+    if (!descs || n_problems <= 0 || !out) return fail(MBX_E_ARG, "mbx_suite_create: bad arguments");
+    const int D = descs[0].dim;
+    if (D < 2 || D > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", D);
+    std::vector<double> pool;
+    std::vector<DevProblem> hp(n_problems);
+    struct Off { int64_t o[9]; };
+    std::vector<Off> offs(n_problems);
+    auto push = [&](const double* p, size_t n) -> int64_t {
+        if (!p) return -1;
+        while (pool.size() % 2) pool.push_back(0.);
+        const int64_t o = (int64_t)pool.size();
+        pool.insert(pool.end(), p, p + n);
+        return o;
+    };
+    for (int i = 0; i < n_problems; ++i) {
+        const mbx_problem_desc& d = descs[i];
+        if (d.dim != D) return fail(MBX_E_ARG, "problem %d has dim %d, suite dim is %d", i, d.dim, D);
+        const bool bbob = d.kind >= 1 && d.kind <= 24;
+        if (!bbob) return fail(MBX_E_UNSUPPORTED, "problem %d: objective kind %d is not implemented", i, d.kind);
+        if (!d.dshift || !d.m1) return fail(MBX_E_ARG, "problem %d: dshift/m1 missing", i);
+        if ((d.kind == 21 || d.kind == 22) && (!d.py || !d.pc || !d.pw || d.n_peaks <= 0))
+            return fail(MBX_E_ARG, "problem %d: Gallagher tables missing", i);
+        DevProblem& p = hp[i];
+        memset(&p, 0, sizeof(p));
+        p.func_id = d.func_id; p.kind = d.kind; p.dim = d.dim; p.n_peaks = d.n_peaks; p.noise_kind = d.noise_kind;
+        p.bias = d.bias; p.lb = d.lb; p.ub = d.ub; p.pen_coef = d.pen_coef;
+        for (int k = 0; k < 4; ++k) p.s[k] = d.s[k];
+        p.noise_a = d.noise_a; p.noise_b = d.noise_b; p.optimum = NAN;
+        const size_t DD = (size_t)D * D, PK = (size_t)d.n_peaks * D;
+        Off& o = offs[i];
+        o.o[0] = push(d.dshift, D); o.o[1] = push(d.m1, DD); o.o[2] = push(d.m2, DD);
+        o.o[3] = push(d.v0, D); o.o[4] = push(d.v1, D); o.o[5] = push(d.v2, D);
+        o.o[6] = push(d.py, PK); o.o[7] = push(d.pc, PK); o.o[8] = push(d.pw, d.n_peaks);
+    }
+    mbx_suite* s = new mbx_suite();
+    s->n = n_problems; s->dim = D;
+    HIP_TRY(hipMalloc(&s->d_pool, pool.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(s->d_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int i = 0; i < n_problems; ++i) {
+        const double** ptrs[9] = {&hp[i].dshift, &hp[i].m1, &hp[i].m2, &hp[i].v0, &hp[i].v1,
+                                  &hp[i].v2, &hp[i].py, &hp[i].pc, &hp[i].pw};
+        for (int k = 0; k < 9; ++k) *ptrs[k] = offs[i].o[k] < 0 ? nullptr : s->d_pool + offs[i].o[k];
+    }
+    HIP_TRY(hipMalloc(&s->d_problems, n_problems * sizeof(DevProblem)));
+    HIP_TRY(hipMemcpy(s->d_problems, hp.data(), n_problems * sizeof(DevProblem), hipMemcpyHostToDevice));
+    s->h_problems = hp;
+    s->optimum.assign(n_problems, NAN);
+    if (opt) {          // optimum_i = func_i(opt_i), noise-free, like BBOB_Basic_Problem.__init__ (bbob.py:42)
+        double *d_x = nullptr, *d_f = nullptr;
+        HIP_TRY(hipMalloc(&d_x, (size_t)n_problems * D * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_f, (size_t)n_problems * sizeof(double)));
+        HIP_TRY(hipMemcpy(d_x, opt, (size_t)n_problems * D * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < n_problems; ++i) {
+            int rc = launch_eval(s, i, d_x + (size_t)i * D, 1, d_f + i, 0, 0, nullptr, nullptr);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_set_optimum, dim3((n_problems + 63) / 64), dim3(64), 0, nullptr, s->d_problems, d_f, n_problems);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(s->optimum.data(), d_f, n_problems * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_problems; ++i) s->h_problems[i].optimum = s->optimum[i];
+        (void)hipFree(d_x); (void)hipFree(d_f);
+    }
+    *out = s;
+    return MBX_OK;
+}
+
+extern "C" int mbx_suite_destroy(mbx_suite* s)
+{
+    if (!s) return MBX_OK;
+    (void)hipFree(s->d_pool); (void)hipFree(s->d_problems);
+    delete s;
+    return MBX_OK;
+}
+
+extern "C" int mbx_suite_size(const mbx_suite* s) { return s ? s->n : fail(MBX_E_ARG, "null suite"); }
+
+extern "C" int mbx_suite_optimum(const mbx_suite* s, double* optimum_out)
+{
+    if (!s || !optimum_out) return fail(MBX_E_ARG, "mbx_suite_optimum: bad arguments");
+    memcpy(optimum_out, s->optimum.data(), s->n * sizeof(double));
+    return MBX_OK;
+}
+
+extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f, int noisy, uint64_t seed,
+                        const double* d_noise_draws, void* stream)
+{
+    if (!s || problem < 0 || problem >= s->n || n < 0 || (n > 0 && (!d_x || !d_f)))
+        return fail(MBX_E_ARG, "mbx_eval: bad arguments");
+    return launch_eval(s, problem, d_x, n, d_f, noisy, seed, d_noise_draws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+static int check_cfg(const mbx_algo_cfg* c)
+{
+    if (!c) return fail(MBX_E_ARG, "null cfg");
+    if (c->algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
+    if (c->np < 2 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [2, %d]", c->np, kThreads);
+    if (c->n_group < 1 || c->n_group > 16 || c->np / c->n_group < 1) return fail(MBX_E_ARG, "bad n_group %d", c->n_group);
+    if (c->max_fes <= 0 || c->log_interval <= 0 || c->n_logpoint <= 0) return fail(MBX_E_ARG, "bad budget/log settings");
+    return MBX_OK;
+}
+
+extern "C" int mbx_state_dim(const mbx_algo_cfg* c)
+{
+    if (check_cfg(c)) return MBX_E_ARG;
+    return 1;
+}
+
+extern "C" int mbx_action_dim(const mbx_algo_cfg* c)
+{
+    if (check_cfg(c)) return MBX_E_ARG;
+    return 7 * c->n_group;
+}
+
+extern "C" int64_t mbx_tape_stride(const mbx_algo_cfg* c)
+{
+    if (check_cfg(c)) return MBX_E_ARG;
+    return MBX_RLEPSO_TAPE_STRIDE(c->np, c->dim);
+}
+
+extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int32_t* problem_idx, const uint64_t* seeds,
+                                int n_instances, mbx_batch** out)
+{
+    if (!s || !problem_idx || !seeds || n_instances <= 0 || !out) return fail(MBX_E_ARG, "mbx_batch_create: bad arguments");
+    if (int rc = check_cfg(cfg)) return rc;
+    if (cfg->dim != s->dim) return fail(MBX_E_ARG, "cfg.dim %d != suite dim %d", cfg->dim, s->dim);
+    for (int i = 0; i < n_instances; ++i)
+        if (problem_idx[i] < 0 || problem_idx[i] >= s->n) return fail(MBX_E_ARG, "problem_idx[%d]=%d out of range", i, problem_idx[i]);
+    const size_t lds = (size_t)rl_lds_doubles(cfg->np, cfg->dim) * sizeof(double);
+    if (lds > (size_t)max_lds_bytes())
+        return fail(MBX_E_UNSUPPORTED, "np=%d dim=%d needs %zu B of LDS per workgroup (> %d)", cfg->np, cfg->dim, lds, max_lds_bytes());
+    mbx_batch* b = new mbx_batch();
+    b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
+    b->state_stride = (MBX_RLEPSO_STATE_DOUBLES(cfg->np, cfg->dim, cfg->n_logpoint) + 1) & ~(int64_t)1;
+    HIP_TRY(hipMalloc(&b->d_problem_idx, n_instances * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&b->d_seeds, n_instances * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&b->d_state, (size_t)n_instances * b->state_stride * sizeof(double)));
+    HIP_TRY(hipMemcpy(b->d_problem_idx, problem_idx, n_instances * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b->d_state, 0, (size_t)n_instances * b->state_stride * sizeof(double)));
+    hipLaunchKernelGGL(k_init_state, dim3((n_instances + 255) / 256), dim3(256), 0, nullptr, b->d_state, b->state_stride,
+                       MBX_RLEPSO_ST_SCALARS(cfg->np, cfg->dim), n_instances);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    *out = b;
+    return MBX_OK;
+}
+
+extern "C" int mbx_batch_destroy(mbx_batch* b)
+{
+    if (!b) return MBX_OK;
+    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state);
+    delete b;
+    return MBX_OK;
+}
+
+extern "C" int mbx_set_tape(mbx_batch* b, const double* d_tape)
+{
+    if (!b) return fail(MBX_E_ARG, "null batch");
+    b->d_tape = d_tape;
+    return MBX_OK;
+}
+
+static BatchParams make_params(const mbx_batch* b)
+{
+    BatchParams p;
+    p.problems = b->suite->d_problems; p.problem_idx = b->d_problem_idx; p.seeds = b->d_seeds;
+    p.state = b->d_state; p.state_stride = b->state_stride;
+    p.tape = b->d_tape; p.tape_stride = MBX_RLEPSO_TAPE_STRIDE(b->cfg.np, b->cfg.dim);
+    p.NP = b->cfg.np; p.D = b->cfg.dim; p.max_fes = b->cfg.max_fes; p.log_interval = b->cfg.log_interval;
+    p.n_logpoint = b->cfg.n_logpoint; p.early_stop = b->cfg.early_stop; p.n_group = b->cfg.n_group; p.B = b->B;
+    return p;
+}
+
+extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
+{
+    if (!b) return fail(MBX_E_ARG, "null batch");
+    hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out, uint8_t* d_done_out,
+                        void* stream)
+{
+    if (!b || !d_actions) return fail(MBX_E_ARG, "mbx_step: bad arguments");
+    hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                       (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_results(mbx_batch* b, double* d_cost_curves, double* d_fes, double* d_return, int32_t* d_steps,
+                           int32_t* d_cost_len, void* stream)
+{
+    if (!b) return fail(MBX_E_ARG, "null batch");
+    hipLaunchKernelGGL(k_results, dim3((b->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->d_state, b->state_stride,
+                       MBX_RLEPSO_ST_SCALARS(b->cfg.np, b->cfg.dim), b->B, b->cfg.n_logpoint, d_cost_curves, d_fes, d_return,
+                       d_steps, d_cost_len);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int64_t mbx_instance_state_doubles(const mbx_batch* b)
+{
+    if (!b) return fail(MBX_E_ARG, "null batch");
+    return MBX_RLEPSO_STATE_DOUBLES(b->cfg.np, b->cfg.dim, b->cfg.n_logpoint);
+}
+
+extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out)
+{
+    if (!b || instance < 0 || instance >= b->B || !host_out) return fail(MBX_E_ARG, "mbx_debug_read_state: bad arguments");
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t n = mbx_instance_state_doubles(b);
+    HIP_TRY(hipMemcpy(host_out, b->d_state + (int64_t)instance * b->state_stride, n * sizeof(double), hipMemcpyDeviceToHost));
+    // cost curve is reported padded with its last value, like mbx_results
+    double* sc = host_out + MBX_RLEPSO_ST_SCALARS(b->cfg.np, b->cfg.dim);
+    const int len = (int)sc[MBX_SC_COST_LEN];
+    for (int k = len; k <= b->cfg.n_logpoint && len > 0; ++k) sc[MBX_NSCALAR + k] = sc[MBX_NSCALAR + len - 1];
+    return MBX_OK;
+}
+
+extern "C" const char* mbx_last_error(void) { return g_err.c_str(); }
+extern "C" const char* mbx_version(void) { return "metabox_amd libmbx 0.1 (gfx950)"; }

@@ -1,0 +1,350 @@
+// mbx_rlepso.hpp — fused RLEPSO generation kernels for gfx950.
+//
+// One workgroup (256 threads = 4 waves) owns one (problem x run) instance.  Per launch it streams the
+// instance's state block in from HBM, keeps pbest positions / candidate positions / evaluation scratch
+// in LDS, performs one whole RLEPSO_Optimizer.update() (reference: src/optimizer/rlepso_optimizer.py:
+// 173-263) including the objective evaluation, and streams the state back out.
+//
+// Mapping: element e = i*D + d (particle i, dimension d) is owned by thread e % 256; particle-level work
+// (pbest/stagnation bookkeeping) is done by thread i; argmin uses wave shuffles.
+#pragma once
+#include "mbx_device.hpp"
+
+namespace mbx {
+
+struct BatchParams {
+    const DevProblem* problems;
+    const int32_t* problem_idx;
+    const uint64_t* seeds;
+    double* state;               // [B][state_stride]
+    int64_t state_stride;
+    const double* tape;          // nullptr -> Philox
+    int64_t tape_stride;
+    int32_t NP, D, max_fes, log_interval, n_logpoint, early_stop, n_group, B;
+};
+
+// LDS carve-up (all offsets in doubles; base is 16-byte aligned, every array starts 16-byte aligned)
+struct RlLds {
+    double *PB, *X, *Z, *T, *M1T, *M2T, *PBC, *CC, *NC, *PNI, *CMUT, *GB, *COEF, *RED;
+    int *IMPR, *MASK, *DIRTY;
+};
+
+__host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_t)1; }
+
+__host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
+{
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+                  P = align2(NP);
+    // PB, X, T: NE each; Z: SC; M1T, M2T; PBC, CC, NC, PNI, CMUT: P each; GB: D; COEF: 6*16; RED: 16; 3 int arrays
+    return 3 * NE + SC + 2 * DD + 5 * P + align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
+}
+
+__device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
+{
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+                  P = align2(NP);
+    RlLds L;
+    double* p = base;
+    L.PB = p; p += NE;
+    L.X = p; p += NE;
+    L.T = p; p += NE;
+    L.Z = p; p += SC;
+    L.M1T = p; p += DD;
+    L.M2T = p; p += DD;
+    L.PBC = p; p += P;
+    L.CC = p; p += P;
+    L.NC = p; p += P;
+    L.PNI = p; p += P;
+    L.CMUT = p; p += P;
+    L.GB = p; p += align2(D);
+    L.COEF = p; p += 96;
+    L.RED = p; p += 16;
+    L.IMPR = (int*)p; p += align2((P + 1) / 2);
+    L.MASK = (int*)p; p += align2((P + 1) / 2);
+    L.DIRTY = (int*)p;
+    return L;
+}
+
+// cost_i = problem.eval(x_i) [- optimum]   (__get_costs, rlepso_optimizer.py:68-74), noise from tape or Philox
+__device__ __forceinline__ void rl_costs(const DevProblem& P, const RlLds& L, int NP, const Rng& rng, const double* tape_noise,
+                                         uint32_t siteA, uint32_t siteB)
+{
+    eval_rows(P, L.X, NP, L.Z, L.T, L.M1T, L.M2T, L.NC);
+    for (int i = threadIdx.x; i < NP; i += kThreads) {
+        double f = L.NC[i];
+        if (P.noise_kind != MBX_NOISE_NONE) {
+            double a, b, c;
+            if (tape_noise) { a = tape_noise[i]; b = tape_noise[NP + i]; c = tape_noise[2 * NP + i]; }
+            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, b, c);
+            f = apply_noise(P, f, a, b, c);
+        }
+        L.NC[i] = isnan(P.optimum) ? f : f - P.optimum;
+    }
+    __syncthreads();
+}
+
+// pbest / gbest bookkeeping shared by update() and __reinit() (rlepso_optimizer.py:200-222, 145-168).
+// Candidate positions are in L.X, their costs in L.NC.  `stagnation` additionally updates per_no_improve
+// against the previous c_cost (:225-233), which only update() does.
+__device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool stagnation, double& gbest, int& gbest_idx)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NP; i += kThreads) {
+        const double nc = L.NC[i];
+        if (stagnation) L.PNI[i] = nc < L.CC[i] ? 0. : L.PNI[i] + 1;
+        const int impr = nc < L.PBC[i];
+        if (impr) { L.PBC[i] = nc; L.DIRTY[i] = 1; }
+        L.IMPR[i] = impr;
+        L.CC[i] = nc;
+    }
+    double cbv; int cb;
+    block_argmin(L.NC, NP, L.RED, cbv, cb);         // contains the barriers that publish IMPR / CC
+    const bool better = cbv < gbest;
+    if (better) { gbest = cbv; gbest_idx = cb; }
+    const int NE = NP * D;
+    for (int e = tid; e < NE; e += kThreads) {
+        const int i = e / D;
+        if (L.IMPR[i]) L.PB[e] = L.X[e];
+    }
+    if (better && tid < D) L.GB[tid] = L.X[cb * D + tid];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// PBO_Env.reset(): init_population (rlepso_optimizer.py:39-65)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, double* __restrict__ state_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    const RlLds L = rl_carve(smem, NP, D);
+    double* S = bp.state + (int64_t)b * bp.state_stride;
+    double* sc = S + MBX_RLEPSO_ST_SCALARS(NP, D);
+    const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
+
+    const int episode = (int)sc[MBX_SC_EPISODE] + 1;
+    const uint64_t seed = bp.seeds[b];
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, (uint32_t)episode};
+    const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
+
+    stage_transposed(P.m1, D, L.M1T);
+    stage_transposed(P.m2, D, L.M2T);
+    for (int e = tid; e < NE; e += kThreads) {
+        double up, uv;
+        if (tape) { up = tape[MBX_RLEPSO_TAPE_REPOS(NP, D) + e]; uv = tape[MBX_RLEPSO_TAPE_REVEL(NP, D) + e]; }
+        else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_ELEM_R); up = u53(w.x, w.y); uv = u53(w.z, w.w); }
+        const double x = lb + (ub - lb) * up;
+        L.X[e] = x;
+        S[MBX_RLEPSO_ST_POS(NP, D) + e] = x;
+        S[MBX_RLEPSO_ST_PBPOS(NP, D) + e] = x;
+        S[MBX_RLEPSO_ST_VEL(NP, D) + e] = -vmax + (vmax - (-vmax)) * uv;
+    }
+    __syncthreads();
+    rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    double gb; int gi;
+    block_argmin(L.NC, NP, L.RED, gb, gi);
+    for (int i = tid; i < NP; i += kThreads) {
+        const double c = L.NC[i];
+        S[MBX_RLEPSO_ST_CCOST(NP, D) + i] = c;
+        S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = c;
+        S[MBX_RLEPSO_ST_PNI(NP, D) + i] = 0.;
+    }
+    if (tid < D) S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid] = L.X[gi * D + tid];
+    if (tid == 0) {
+        sc[MBX_SC_GBEST] = gb; sc[MBX_SC_FES] = NP; sc[MBX_SC_LOG_INDEX] = 1; sc[MBX_SC_COST_LEN] = 1;
+        sc[MBX_SC_DONE] = 0; sc[MBX_SC_RETURN] = 0; sc[MBX_SC_GEN] = 0; sc[MBX_SC_EPISODE] = episode;
+        sc[MBX_SC_GBEST_IDX] = gi; sc[MBX_SC_REINIT] = 0;
+        sc[MBX_NSCALAR] = gb;                                    // cost = [gbest]
+        if (state_out) state_out[b] = (double)NP / bp.max_fes;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PBO_Env.step(action): RLEPSO_Optimizer.update (rlepso_optimizer.py:173-263)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
+                                                          double* __restrict__ state_out, double* __restrict__ reward_out,
+                                                          uint8_t* __restrict__ done_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NP = bp.NP, D = bp.D, NE = NP * D, G = bp.n_group;
+    double* S = bp.state + (int64_t)b * bp.state_stride;
+    double* sc = S + MBX_RLEPSO_ST_SCALARS(NP, D);
+
+    if (sc[MBX_SC_DONE] != 0.) {                                  // finished instances idle (block-uniform exit)
+        if (tid == 0) {
+            if (state_out) state_out[b] = sc[MBX_SC_FES] / bp.max_fes;
+            if (reward_out) reward_out[b] = 0.;
+            if (done_out) done_out[b] = 1;
+        }
+        return;
+    }
+    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    const RlLds L = rl_carve(smem, NP, D);
+    const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
+    const float* act = actions + (int64_t)b * (7 * G);
+
+    const int gen = (int)sc[MBX_SC_GEN] + 1;
+    const uint64_t seed = bp.seeds[b];
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE]};
+    const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
+    double gbest = sc[MBX_SC_GBEST];
+    int gbest_idx = (int)sc[MBX_SC_GBEST_IDX];
+    const double pre_gbest = gbest;
+    double fes = sc[MBX_SC_FES];
+
+    // ---- stage: pbest positions/costs, c_cost, stagnation counters, gbest position, linear maps
+    const double* gPB = S + MBX_RLEPSO_ST_PBPOS(NP, D);
+    for (int e = tid; e < NE; e += kThreads) L.PB[e] = gPB[e];
+    for (int i = tid; i < NP; i += kThreads) {
+        L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
+        L.CC[i] = S[MBX_RLEPSO_ST_CCOST(NP, D) + i];
+        L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
+        L.DIRTY[i] = 0;
+    }
+    if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
+    stage_transposed(P.m1, D, L.M1T);
+    stage_transposed(P.m2, D, L.M2T);
+    // __get_coe (:112-132): float32 arithmetic (numpy >= 2 keeps float32 for scalar*python-float), group g
+    // reads actions[g*n_group : g*n_group+7]
+    if (tid < G) {
+        const float* a = act + tid * G;
+        const float cm = a[0] * 0.01f;
+        const float wv = a[1] * 0.8f + 0.1f;
+        float den = a[3] + a[4];
+        den = den + a[5]; den = den + a[6]; den = den + 1e-5f;
+        float scale = 1.f / den;
+        scale = scale * a[2]; scale = scale * 8.f;
+        double* c = L.COEF + tid * 6;
+        c[0] = (double)cm; c[1] = (double)wv;
+        c[2] = (double)(scale * a[3]); c[3] = (double)(scale * a[4]);
+        c[4] = (double)(scale * a[5]); c[5] = (double)(scale * a[6]);
+    }
+    __syncthreads();
+    const int per_group = NP / G;
+    for (int i = tid; i < NP; i += kThreads) {
+        const int g = i / per_group;
+        L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
+    }
+
+    // ---- velocity / position update, one element per thread-iteration (:179-195)
+    double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
+    double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
+    const double pci_den = exp(10.) - 1;
+    for (int e = tid; e < NE; e += kThreads) {
+        const int i = e / D, d = e - i * D;
+        double r1, r2, uc, uf; int t1, t2;
+        if (tape) {
+            r1 = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; r2 = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i];
+            uc = tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
+            t1 = (int)tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2 = (int)tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1];
+            uf = tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e];
+        } else {
+            U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); r1 = u53(w.x, w.y); r2 = u53(w.z, w.w);
+            w = rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc = u53(w.x, w.y);
+            t1 = (int)__umulhi(w.z, (uint32_t)NP); t2 = (int)__umulhi(w.w, (uint32_t)NP);
+            w = rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf = u53(w.x, w.y);
+        }
+        const double cur = gPos[e], pp = L.PB[e], fi = L.PBC[i];
+        // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
+        const double pci = 0.05 + 0.45 * exp(10. * i / (NP - 1)) / pci_den;
+        const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
+        const double exemplar = uc > pci ? pp : L.PB[tw * D + d];
+        const double v_clpso = uc * (exemplar - cur);
+        // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109)
+        int jb = 0;
+        double fb = (L.PBC[0] - fi) / (fabs(L.PB[d] - pp) + 1e-5);
+        for (int j = 1; j < NP; ++j) {
+            const double fdr = (L.PBC[j] - fi) / (fabs(L.PB[j * D + d] - pp) + 1e-5);
+            if (fdr < fb) { fb = fdr; jb = j; }
+        }
+        const double v_fdr = uf * (L.PB[jb * D + d] - pp);
+        const double v_pbest = r1 * (pp - cur);
+        const double v_gbest = r2 * (L.GB[d] - cur);
+        const int g = i / per_group;
+        double cw = 0., c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
+        if (g < G) { const double* c = L.COEF + g * 6; cw = c[1]; c1 = c[2]; c2 = c[3]; c3 = c[4]; c4 = c[5]; }
+        double nv = cw * gVel[e] + c1 * v_clpso + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
+        nv = fmin(fmax(nv, -vmax), vmax);
+        double np_ = cur + nv;
+        np_ = fmin(fmax(np_, lb), ub);
+        L.X[e] = np_;
+        gPos[e] = np_;
+        gVel[e] = nv;
+    }
+    __syncthreads();
+
+    // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
+    rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    fes += NP;
+    rl_commit(L, NP, D, true, gbest, gbest_idx);
+
+    // ---- re-initialisation (:238-239, 134-168): P(i) = u < c_mutation_i * 0.01 * per_no_improve_i
+    int mine = 0;
+    for (int i = tid; i < NP; i += kThreads) {
+        double u;
+        if (tape) u = tape[MBX_RLEPSO_TAPE_REINIT(NP, D) + i];
+        else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_REINIT); u = u53(w.x, w.y); }
+        const int m = u < L.CMUT[i] * 0.01 * L.PNI[i];
+        L.MASK[i] = m;
+        mine += m;
+    }
+    const int n_reinit = __syncthreads_count(mine);               // NP <= 256: at most one particle per thread
+    if (n_reinit > 0) {
+        for (int e = tid; e < NE; e += kThreads) {
+            const int i = e / D;
+            if (L.MASK[i]) {
+                double up, uv;
+                if (tape) { up = tape[MBX_RLEPSO_TAPE_REPOS(NP, D) + e]; uv = tape[MBX_RLEPSO_TAPE_REVEL(NP, D) + e]; }
+                else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_ELEM_R); up = u53(w.x, w.y); uv = u53(w.z, w.w); }
+                const double x = lb + (ub - lb) * up;
+                L.X[e] = x;
+                gPos[e] = x;
+                gVel[e] = -vmax + (vmax - (-vmax)) * uv;
+            }
+        }
+        __syncthreads();
+        // the whole population is re-evaluated but only the re-initialised particles are billed (:141-143)
+        rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+        fes += n_reinit;
+        rl_commit(L, NP, D, false, gbest, gbest_idx);
+    }
+
+    // ---- write back what changed
+    double* gPBw = S + MBX_RLEPSO_ST_PBPOS(NP, D);
+    for (int e = tid; e < NE; e += kThreads) {
+        const int i = e / D;
+        if (L.DIRTY[i]) gPBw[e] = L.PB[e];
+    }
+    for (int i = tid; i < NP; i += kThreads) {
+        S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = L.PBC[i];
+        S[MBX_RLEPSO_ST_CCOST(NP, D) + i] = L.CC[i];
+        S[MBX_RLEPSO_ST_PNI(NP, D) + i] = L.PNI[i];
+    }
+    if (gbest < pre_gbest && tid < D) S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid] = L.GB[tid];
+
+    // ---- logging, termination, reward, next state (:241-261)
+    if (tid == 0) {
+        int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
+        double* cost = sc + MBX_NSCALAR;
+        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
+        bool done = fes >= bp.max_fes;
+        if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
+        const double reward = gbest < pre_gbest ? 1. : -1.;
+        if (done) {
+            if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
+            else cost[cost_len++] = gbest;
+        }
+        sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
+        sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += reward; sc[MBX_SC_GEN] = gen;
+        sc[MBX_SC_GBEST_IDX] = gbest_idx; sc[MBX_SC_REINIT] = n_reinit > 0 ? 1. : 0.;
+        if (state_out) state_out[b] = fes / bp.max_fes;
+        if (reward_out) reward_out[b] = reward;
+        if (done_out) done_out[b] = done ? 1 : 0;
+    }
+}
+
+}  // namespace mbx

@@ -1,0 +1,171 @@
+"""Device-resident problem suites and lock-step instance batches (thin host wrappers over the C-ABI).
+
+``Suite``  ~ the list of problem objects returned by the reference's ``construct_problem_set``
+            (src/utils.py:4-27), uploaded once to HBM.
+``Batch``  ~ B independent ``PBO_Env(problem, optimizer)`` pairs (src/environment/basic_environment.py:6-22)
+            stepped together by one kernel launch per ``step``.
+
+PyTorch is used only for device memory and streams; the arithmetic lives in libmbx.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _abi.MbxError('metabox_amd needs a ROCm GPU (MI355X); there is no CPU fallback for the hot path.')
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Suite:
+    """A set of problem instances of one dimension, resident on the current GPU."""
+
+    def __init__(self, problems):
+        _require_gpu()
+        self.lib = _abi.load_lib()
+        self.problems = list(problems)
+        self.dim = int(self.problems[0].dim)
+        descs = [p.desc() for p in self.problems]
+        arr, self._keep = _abi.pack_descs(descs)
+        opts = [getattr(p, 'opt', None) for p in self.problems]
+        opt_arr = None
+        if all(o is not None for o in opts):
+            opt_arr = np.ascontiguousarray(np.stack([np.asarray(o, dtype=np.float64) for o in opts]))
+        h = C.c_void_p()
+        _abi.check(self.lib.mbx_suite_create(arr, len(descs), opt_arr.ctypes.data_as(_abi.c_double_p) if opt_arr is not None
+                                             else _abi.c_double_p(), C.byref(h)))
+        self._h = h
+        out = np.empty(len(descs))
+        _abi.check(self.lib.mbx_suite_optimum(self._h, out.ctypes.data_as(_abi.c_double_p)))
+        self._optimum = out
+        for i, p in enumerate(self.problems):
+            p._suite = self
+            p._suite_index = i
+            p._optimum = None if np.isnan(out[i]) else float(out[i])
+
+    def __len__(self):
+        return len(self.problems)
+
+    def optimum(self, i):
+        v = self._optimum[i]
+        return None if np.isnan(v) else float(v)
+
+    def eval_device(self, i, x_dev, noisy=False, seed=0, noise_draws=None):
+        """x_dev: float64 CUDA tensor [n, dim] -> float64 CUDA tensor [n] (asynchronous on the current stream)."""
+        assert x_dev.is_cuda and x_dev.dtype == torch.float64 and x_dev.is_contiguous() and x_dev.shape[1] == self.dim
+        n = x_dev.shape[0]
+        f = torch.empty(n, dtype=torch.float64, device=x_dev.device)
+        _abi.check(self.lib.mbx_eval(self._h, int(i), _ptr(x_dev), n, _ptr(f), int(bool(noisy)), int(seed),
+                                     _ptr(noise_draws), _stream()))
+        return f
+
+    _eval_calls = 0
+
+    def eval(self, i, x, noisy=False, seed=None, noise_draws=None):
+        """Host convenience used by ``problem.eval``: numpy in, numpy out."""
+        xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+        if seed is None:                       # fresh Philox stream per call, like consuming a global RNG
+            Suite._eval_calls += 1
+            seed = (int(np.random.randint(0, 2 ** 31 - 1)) << 20) + Suite._eval_calls
+        nd = None
+        if noise_draws is not None:
+            nd = torch.from_numpy(np.ascontiguousarray(noise_draws, dtype=np.float64)).cuda()
+        return self.eval_device(i, xd, noisy, seed, nd).cpu().numpy()
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.mbx_suite_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """B lock-step optimizer instances on one GPU (``mbx_batch``)."""
+
+    def __init__(self, suite, algo, problem_idx, seeds, np_, max_fes, log_interval, n_logpoint, early_stop=True, n_group=5):
+        _require_gpu()
+        self.lib = suite.lib
+        self.suite = suite
+        self.cfg = _abi.AlgoCfg(int(algo), int(np_), suite.dim, int(max_fes), int(log_interval), int(n_logpoint),
+                                int(bool(early_stop)), int(n_group))
+        pidx = np.ascontiguousarray(problem_idx, dtype=np.int32)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert pidx.shape == sd.shape and pidx.ndim == 1
+        self.B = int(pidx.shape[0])
+        h = C.c_void_p()
+        _abi.check(self.lib.mbx_batch_create(suite._h, C.byref(self.cfg), pidx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             sd.ctypes.data_as(C.POINTER(C.c_uint64)), self.B, C.byref(h)))
+        self._h = h
+        self.state_dim = self.lib.mbx_state_dim(C.byref(self.cfg))
+        self.action_dim = self.lib.mbx_action_dim(C.byref(self.cfg))
+        self.tape_stride = int(self.lib.mbx_tape_stride(C.byref(self.cfg)))
+        dev = torch.device('cuda', torch.cuda.current_device())
+        self.device = dev
+        self.state = torch.zeros(self.B, self.state_dim, dtype=torch.float64, device=dev)
+        self.reward = torch.zeros(self.B, dtype=torch.float64, device=dev)
+        self.done = torch.zeros(self.B, dtype=torch.uint8, device=dev)
+        self._tape = None
+
+    def set_tape(self, tape):
+        """tape: float64 CUDA tensor [B, tape_stride] or None (back to Philox)."""
+        if tape is not None:
+            assert tape.is_cuda and tape.dtype == torch.float64 and tape.is_contiguous()
+            assert tuple(tape.shape) == (self.B, self.tape_stride)
+        self._tape = tape
+        _abi.check(self.lib.mbx_set_tape(self._h, _ptr(tape)))
+
+    def reset(self):
+        _abi.check(self.lib.mbx_reset(self._h, _ptr(self.state), _stream()))
+        return self.state
+
+    def step(self, actions):
+        """actions: CUDA tensor [B, action_dim] (float32).  Returns (state, reward, done) device tensors that are
+        overwritten by the next call."""
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == torch.float32
+        assert tuple(actions.shape) == (self.B, self.action_dim)
+        _abi.check(self.lib.mbx_step(self._h, _ptr(actions), _ptr(self.state), _ptr(self.reward), _ptr(self.done), _stream()))
+        return self.state, self.reward, self.done
+
+    def results(self):
+        """-> dict of device tensors: cost [B, n_logpoint+1], fes [B], return [B], steps [B], cost_len [B]."""
+        n = self.cfg.n_logpoint + 1
+        cost = torch.empty(self.B, n, dtype=torch.float64, device=self.device)
+        fes = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        ret = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        steps = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        clen = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.mbx_results(self._h, _ptr(cost), _ptr(fes), _ptr(ret), _ptr(steps), _ptr(clen), _stream()))
+        return {'cost': cost, 'fes': fes, 'return': ret, 'steps': steps, 'cost_len': clen}
+
+    def read_state(self, instance):
+        n = int(self.lib.mbx_instance_state_doubles(self._h))
+        out = np.empty(n)
+        _abi.check(self.lib.mbx_debug_read_state(self._h, int(instance), out.ctypes.data_as(_abi.c_double_p)))
+        return out
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.mbx_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,201 @@
+"""ctypes front-end of oracle/liboracle.so — TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from metabox_amd._abi import AlgoCfg, ProblemDesc, pack_desc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, 'liboracle.so')
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'mbx_oracle.c')
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B' if force else '-s'])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_eval.argtypes = [C.POINTER(ProblemDesc), _dp, C.c_int, _dp]
+        L.orc_apply_noise.argtypes = [C.POINTER(ProblemDesc), C.c_double, _dp, C.c_int, _dp, _dp]
+        L.orc_eval_noisy_philox.argtypes = [C.POINTER(ProblemDesc), C.c_double, _dp, C.c_int, C.c_uint64, _dp]
+        L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.POINTER(C.c_uint32)]
+        L.orc_rlepso_new.restype = C.c_void_p
+        L.orc_rlepso_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_rlepso_free.argtypes = [C.c_void_p]
+        L.orc_rlepso_reset.restype = C.c_double
+        L.orc_rlepso_reset.argtypes = [C.c_void_p, _dp]
+        L.orc_rlepso_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), _dp, _dp]
+        L.orc_rlepso_state.argtypes = [C.c_void_p, _dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def evaluate(desc, x):
+    """F*.func: [n, dim] -> [n] (bias included)."""
+    st, keep = pack_desc(desc)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    f = np.empty(x.shape[0])
+    lib().orc_eval(C.byref(st), _p(x), x.shape[0], _p(f))
+    return f
+
+
+def apply_noise(desc, optimum, ftrue, draws):
+    st, keep = pack_desc(desc)
+    ftrue = np.ascontiguousarray(ftrue, dtype=np.float64)
+    draws = np.ascontiguousarray(draws, dtype=np.float64)
+    out = np.empty_like(ftrue)
+    lib().orc_apply_noise(C.byref(st), float(optimum), _p(ftrue), len(ftrue), _p(draws), _p(out))
+    return out
+
+
+def evaluate_noisy_philox(desc, optimum, x, seed):
+    st, keep = pack_desc(desc)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    f = np.empty(x.shape[0])
+    lib().orc_eval_noisy_philox(C.byref(st), float(optimum), _p(x), x.shape[0], int(seed), _p(f))
+    return f
+
+
+def philox(seed, idx, site, gen, episode):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox(int(seed), idx, site, gen, episode, out)
+    return list(out)
+
+
+def make_cfg(algo, np_, dim, max_fes, log_interval, n_logpoint, early_stop=1, n_group=5):
+    return AlgoCfg(algo, np_, dim, max_fes, log_interval, n_logpoint, early_stop, n_group)
+
+
+def rlepso_state_doubles(NP, D, nlog):
+    return 3 * NP * D + 3 * NP + D + 16 + nlog + 1
+
+
+class RlepsoOracle:
+    """One RLEPSO instance on the CPU (init_population / update restated in C)."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = lib().orc_rlepso_new(C.byref(self._st), float('nan') if optimum is None else float(optimum),
+                                       C.byref(cfg), int(seed))
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            lib().orc_rlepso_free(self._h)
+            self._h = None
+
+    def reset(self, tape=None):
+        return lib().orc_rlepso_reset(self._h, _p(tape) if tape is not None else None)
+
+    def step(self, action, tape=None):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        out = np.empty(3)
+        lib().orc_rlepso_step(self._h, a.ctypes.data_as(C.POINTER(C.c_float)),
+                              _p(tape) if tape is not None else None, _p(out))
+        return out[0], out[1], bool(out[2])
+
+    def state(self):
+        out = np.empty(rlepso_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
+        lib().orc_rlepso_state(self._h, _p(out))
+        return out
+
+
+# scalar slots (include/mbx_layout.h)
+SC_GBEST, SC_FES, SC_LOG_INDEX, SC_COST_LEN, SC_DONE, SC_RETURN, SC_GEN, SC_EPISODE, SC_GBEST_IDX, SC_REINIT = range(10)
+NSCALAR = 16
+
+
+def split_rlepso_state(st, NP, D, nlog):
+    o = 0
+    out = {}
+    for name, n in (('pos', NP * D), ('vel', NP * D), ('pbpos', NP * D), ('ccost', NP), ('pbest', NP),
+                    ('pni', NP), ('gbpos', D), ('scalars', NSCALAR), ('cost', nlog + 1)):
+        out[name] = st[o:o + n]
+        o += n
+    return out
+
+
+class NumpyTapeFeeder:
+    """Regenerates, from a seed, the numpy legacy-stream draws that RLEPSO_Optimizer consumes, in the
+    reference's call order, and lays them out as the per-step tape of include/mbx_layout.h.
+
+    Draw order per update() (rlepso_optimizer.py:179-180,77,88,108,[eval noise],238 and,
+    only when the re-init mask is non-empty, 137-138,[eval noise]).  The conditional draws are produced
+    speculatively; ``commit(reinit_fired)`` rewinds the stream when the step did not re-initialise.
+    """
+
+    def __init__(self, seed, NP, D, noise_kind):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise = NP, D, noise_kind
+        self.stride = 9 * NP + 6 * NP * D
+        self._rewind = None
+
+    def _noise_rows(self):
+        NP = self.NP
+        rows = np.zeros((3, NP))
+        if self.noise == 1:
+            rows[0] = self.rs.randn(NP)
+        elif self.noise == 2:
+            rows[0] = self.rs.rand(NP)
+            rows[1] = self.rs.rand(NP)
+        elif self.noise == 3:
+            rows[0] = self.rs.rand(NP)
+            rows[1] = self.rs.randn(NP)
+            rows[2] = self.rs.randn(NP)
+        return rows.ravel()
+
+    def _fill_reinit(self, tape):
+        NP, D = self.NP, self.D
+        o = 6 * NP + 4 * NP * D
+        tape[o:o + NP * D] = self.rs.random_sample((NP, D)).ravel()
+        tape[o + NP * D:o + 2 * NP * D] = self.rs.random_sample((NP, D)).ravel()
+        tape[o + 2 * NP * D:o + 2 * NP * D + 3 * NP] = self._noise_rows()
+
+    def reset_tape(self):
+        tape = np.zeros(self.stride)
+        self._fill_reinit(tape)
+        return tape
+
+    def step_tape(self):
+        NP, D = self.NP, self.D
+        tape = np.zeros(self.stride)
+        tape[0:NP] = self.rs.rand(NP, 1).ravel()
+        tape[NP:2 * NP] = self.rs.rand(NP, 1).ravel()
+        o = 2 * NP
+        tape[o:o + NP * D] = self.rs.rand(NP, D).ravel()
+        o += NP * D
+        tape[o:o + 2 * NP * D] = self.rs.randint(low=0, high=NP, size=(NP, D, 2)).ravel()
+        o += 2 * NP * D
+        tape[o:o + NP * D] = self.rs.rand(NP, D).ravel()
+        o += NP * D
+        tape[o:o + 3 * NP] = self._noise_rows()
+        o += 3 * NP
+        tape[o:o + NP] = self.rs.rand(NP)
+        self._rewind = self.rs.get_state()
+        self._fill_reinit(tape)
+        return tape
+
+    def commit(self, reinit_fired):
+        if not reinit_fired:
+            self.rs.set_state(self._rewind)
+        self._rewind = None

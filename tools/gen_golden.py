@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the UPSTREAM REFERENCE.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are data
+(inputs + expected outputs), never reference source.  Re-run: `python tools/gen_golden.py [section ...]`
+with sections in {instances, kat, noise, policy, rlepso}.
+
+What is recorded
+  instances : per (suite, dim) the problem names, biases, optima, a sha256 over every constructor-made
+              array, and the value of the next np.random.rand() after the dataset build (stream position).
+  kat       : f(x) for 14 points per function (0, linspace, 8 in-bounds, 4 out-of-bounds), D = 10, 30, 40.
+  noise     : problem.eval(x) of the 30 noisy functions under np.random.seed(s): expected noisy values.
+  policy    : weights of the shipped RLEPSO actor/critic + (state -> mu, sigma, value) pairs.
+  rlepso    : whole RLEPSO episodes (shipped actor, np.random.seed(s); torch.manual_seed(s)): the
+              float32 action of every generation and gbest / fes / reward / done after every update(),
+              final optimizer.cost, fes.  The numpy draws are NOT stored: the test regenerates them from
+              the seed with numpy's legacy MT19937 stream in the reference's draw order.
+"""
+import hashlib
+import json
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+ref_import.install()
+import torch  # noqa: E402
+
+torch.set_num_threads(1)
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+ARRAY_ATTRS = ('shift', 'rotate', 'scales', 'linearTF', 'Q_rotate', 'y', 'C', 'w', 'aK', 'bK', 'f0', 'mu0')
+
+
+def digest(problem):
+    h = hashlib.sha256()
+    for a in ARRAY_ATTRS:
+        if hasattr(problem, a):
+            h.update(a.encode())
+            h.update(np.ascontiguousarray(np.asarray(getattr(problem, a), dtype=np.float64)).tobytes())
+    return h.hexdigest()
+
+
+def kat_points(dim):
+    rs = np.random.RandomState(20250202 + dim)
+    pts = [np.zeros(dim), np.linspace(-4, 4, dim)]
+    pts += list(rs.uniform(-5, 5, size=(8, dim)))
+    pts += list(rs.uniform(-8, 8, size=(4, dim)))
+    return np.stack(pts)
+
+
+def all_problems(suite, dim, difficulty='easy'):
+    from problem.bbob import BBOB_Dataset
+    tr, te = BBOB_Dataset.get_datasets(suite, dim, 5.0, difficulty=difficulty)
+    nxt = float(np.random.rand())
+    return tr.data, te.data, nxt
+
+
+def fid_of(problem):
+    return int(type(problem).__name__[1:])
+
+
+def gen_instances():
+    out = {}
+    for suite in ('bbob', 'bbob-noisy'):
+        for dim in (10, 30, 40):
+            tr, te, nxt = all_problems(suite, dim)
+            rec = {'next_rand': nxt, 'train': [fid_of(p) for p in tr], 'test': [fid_of(p) for p in te], 'problems': {}}
+            for p in tr + te:
+                rec['problems'][str(fid_of(p))] = {
+                    'name': str(p), 'bias': float(p.bias), 'optimum': float(p.optimum), 'sha256': digest(p),
+                    'shift0': float(p.shift[0]), 'rotate00': float(p.rotate[0, 0])}
+            out[f'{suite}/{dim}'] = rec
+    with open(os.path.join(OUT, 'bbob_instances.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('instances:', len(out), 'suite/dim entries')
+
+
+def gen_kat():
+    data = {}
+    for suite in ('bbob', 'bbob-noisy'):
+        for dim in (10, 30, 40):
+            tr, te, _ = all_problems(suite, dim)
+            X = kat_points(dim)
+            data[f'x/{dim}'] = X
+            for p in tr + te:
+                # F*.func is the noise-free objective (bias included) for every id
+                data[f'f/{suite}/{dim}/{fid_of(p)}'] = np.asarray(p.func(X.copy()), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'bbob_kat.npz'), **data)
+    print('kat:', len(data), 'arrays')
+
+
+def gen_noise():
+    data = {}
+    for dim in (10, 30):
+        tr, te, _ = all_problems('bbob-noisy', dim)
+        rs = np.random.RandomState(777 + dim)
+        X = rs.uniform(-5, 5, size=(64, dim))
+        data[f'x/{dim}'] = X
+        for p in tr + te:
+            p.reset()
+            for seed in (0, 1):
+                np.random.seed(seed)
+                data[f'f/{dim}/{fid_of(p)}/{seed}'] = np.asarray(p.eval(X.copy()), dtype=np.float64)
+            # a near-optimum row exercises the `ftrue_unbiased >= 1e-8` switch
+            xo = np.stack([p.shift, p.shift + 1e-7])
+            np.random.seed(5)
+            data[f'fopt/{dim}/{fid_of(p)}'] = np.asarray(p.eval(xo.copy()), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'bbob_noise.npz'), **data)
+    print('noise:', len(data), 'arrays')
+
+
+def load_shipped(path):
+    with open(path, 'rb') as f:
+        return pickle.load(f)
+
+
+def gen_policy():
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/RLEPSO_Agent.pkl'))
+    actor = agent._RLEPSO_Agent__actor
+    critic = agent._RLEPSO_Agent__critic
+    data = {}
+    for k, v in actor.state_dict().items():
+        data['actor/' + k] = v.detach().cpu().numpy()
+    for k, v in critic.state_dict().items():
+        data['critic/' + k] = v.detach().cpu().numpy()
+    s = torch.linspace(0, 1.05, 64, dtype=torch.float32).reshape(-1, 1)
+    with torch.no_grad():
+        mu = (torch.tanh(actor._Actor__mu_net(s)) + 1.) / 2.
+        sg = (torch.tanh(actor._Actor__sigma_net(s)) + 1.) / 2. * (0.7 - 0.01) + 0.01
+        val = critic._Critic__value_head(s)
+    data['io/state'] = s.numpy()
+    data['io/mu'] = mu.numpy()
+    data['io/sigma'] = sg.numpy()
+    data['io/value'] = val.numpy()
+    data['meta/max_sigma'] = np.float64(actor._Actor__max_sigma)
+    data['meta/min_sigma'] = np.float64(actor._Actor__min_sigma)
+    np.savez_compressed(os.path.join(OUT, 'rlepso_policy.npz'), **data)
+    print('policy:', {k: v.shape for k, v in data.items() if k.startswith('actor')})
+
+
+def run_rlepso_episode(problem, seed, agent, config, action_mode):
+    """One reference rollout, recording per-generation actions and outcomes."""
+    from optimizer import RLEPSO_Optimizer
+    from environment import PBO_Env
+    import copy
+    opt = RLEPSO_Optimizer(copy.deepcopy(config))
+    env = PBO_Env(problem, opt)
+    actor = agent._RLEPSO_Agent__actor
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ars = np.random.RandomState(10_000 + seed)      # only for action_mode == 'uniform'
+    state = env.reset()
+    gb0 = float(opt._RLEPSO_Optimizer__particles['gbest_val'])
+    actions, gbest, fes, reward, done_l = [], [], [], [], []
+    done = False
+    while not done:
+        if action_mode == 'actor':
+            with torch.no_grad():
+                action = actor(torch.FloatTensor(state))[0].cpu().numpy()
+        else:
+            action = ars.uniform(0, 1, size=35).astype(np.float32)
+        state, r, done = env.step(action)
+        actions.append(action.astype(np.float32))
+        gbest.append(float(opt._RLEPSO_Optimizer__particles['gbest_val']))
+        fes.append(float(opt.fes))
+        reward.append(float(r))
+        done_l.append(bool(done))
+    part = opt._RLEPSO_Optimizer__particles
+    return dict(actions=np.stack(actions), gbest=np.array(gbest), fes=np.array(fes), reward=np.array(reward),
+                done=np.array(done_l), cost=np.array(opt.cost, dtype=np.float64), gbest0=np.float64(gb0),
+                final_pos=np.array(part['current_position']), final_pbest=np.array(part['pbest']),
+                final_pni=np.array(opt._RLEPSO_Optimizer__per_no_improve))
+
+
+def gen_rlepso():
+    scratch = tempfile.mkdtemp()
+    data = {}
+    cases = []
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/RLEPSO_Agent.pkl'))
+    for suite, fids, seeds, mode in (
+            ('bbob', (1, 5, 6, 3, 7, 16, 21, 23, 24), (0, 1), 'actor'),
+            ('bbob', (2, 4, 8, 9, 10, 11, 12, 13, 14, 15, 17, 18, 19, 20, 22), (2,), 'actor'),
+            ('bbob', (1, 9, 20), (3,), 'uniform'),              # random actions: __reinit fires constantly
+            ('bbob-noisy', (101, 102, 103, 113, 117, 121, 124, 126, 130), (0,), 'actor'),
+            ('bbob-noisy', (108, 115), (4,), 'uniform')):
+        config = ref_import.ref_config(['--problem', suite, '--dim', '10'], scratch)
+        tr, te, _ = all_problems(suite, 10)
+        byid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            for seed in seeds:
+                p = byid[fid]
+                p.reset()
+                rec = run_rlepso_episode(p, seed, agent, config, mode)
+                key = f'{suite}/{fid}/{seed}/{mode}'
+                cases.append(key)
+                for k, v in rec.items():
+                    data[f'{key}/{k}'] = v
+                n_re = int(np.sum(np.diff(np.concatenate([[100.], rec['fes']])) != 100))
+                print(f'{key}: gens={len(rec["gbest"])} fes={rec["fes"][-1]:.0f} final={rec["gbest"][-1]:.6g} reinit_steps={n_re}')
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'rlepso_traces.npz'), **data)
+    print('rlepso:', len(cases), 'episodes')
+
+
+SECTIONS = {'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+            'rlepso': gen_rlepso}
+
+if __name__ == '__main__':
+    todo = sys.argv[1:] or list(SECTIONS)
+    for name in todo:
+        SECTIONS[name]()
