@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: RLEPSO rollout throughput on bbob d=10 pop=100, 4096 lock-step instances per MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A *step* is one lock-step generation of the whole instance batch: one batched policy forward (PyTorch-ROCm) and
+one fused RLEPSO generation kernel (mbx_step).  An episode is 199 generations (maxFEs = 20 000, pop 100); when it
+ends the batch is re-initialised (mbx_reset, a new Philox episode) and stepping continues, so K steps may span
+several episodes.  value = env-steps/s = sum over the K timed steps of the number of instances that were not yet
+done (reference stop rule gbest <= 1e-8 kept) / wall time, aggregated over all ranks (weak scaling: 4096
+instances per GPU).  Inputs (problem constants, policy weights, instance state) are resident in HBM before the
+timed region.
+
+Also reported on the same JSON line:
+  roofline     — fused generation kernel: algorithmic bytes (54.0 KB per env-step) x live instances
+                 per launch / average kernel duration measured with HIP events on the launch stream, vs 8 TB/s.
+  cpu_baseline — the C oracle (a float64 port of the reference path, oracle/mbx_oracle.c) on one host core,
+                 on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NP_, DIM, MAXFES, NLOG = 100, 10, 20000, 50
+LOGI = MAXFES // NLOG
+EPISODE_GENS = -(-(MAXFES - NP_) // NP_)            # 199
+INSTANCES_PER_GPU = 4096
+WORD = 8
+# per env-step  2*S + 4*35 + (D^2+D+2)*w + 13,  S = (3*NP*D + 3*NP + D + 1)*w + 16
+_S = (3 * NP_ * DIM + 3 * NP_ + DIM + 1) * WORD + 16
+ALGO_BYTES_PER_STEP = 2 * _S + 4 * 35 + (DIM * DIM + DIM + 2) * WORD + 13
+HBM_PEAK_GBS = 8000.0
+
+
+def make_config():
+    from metabox_amd.config import get_config
+    return get_config(['--problem', 'bbob', '--difficulty', 'easy', '--dim', str(DIM), '--device', 'cuda'])
+
+
+def load_agent(config, device):
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    config.agent_save_dir = None
+    agent = RLEPSO_Agent(config)
+    w = os.path.join(ROOT, 'metabox_amd', 'agent_model', 'rlepso_bbob_easy.npz')
+    agent.load_exported_weights(np.load(w))
+    return agent.to(device)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (port of the reference path) timed on one host core over whole episodes of the same workload."""
+    from metabox_amd.problem.bbob import BBOB_Dataset
+    from oracle import oracle
+    torch.set_num_threads(1)
+    config = make_config()
+    config.device = 'cpu'
+    agent = load_agent(config, 'cpu')
+    tr, te = BBOB_Dataset.get_datasets('bbob', DIM, 5.0)
+    ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+    cfg = oracle.make_cfg(1, NP_, DIM, MAXFES, LOGI, NLOG)
+    steps, t0, episodes = 0, time.perf_counter(), 0
+    run = 0
+    while time.perf_counter() - t0 < seconds_budget:
+        for p in ps:
+            o = oracle.RlepsoOracle(p.desc(), p.bias, cfg, seed=1000 + run)
+            s = o.reset()
+            done = False
+            while not done:
+                a = agent.actor.act_batch(torch.tensor([[s]], dtype=torch.float32))[0].numpy()
+                s, r, done = o.step(a)
+                steps += 1
+            episodes += 1
+            if time.perf_counter() - t0 >= seconds_budget:
+                break
+        run += 1
+    dt = time.perf_counter() - t0
+    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{episodes} whole RLEPSO episodes (bbob d=10 pop=100, functions round-robin, same policy), '
+                      f'{steps} env-steps in {dt:.1f} s, C float64 oracle + torch-CPU actor, 1 thread'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2 * EPISODE_GENS)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import RLEPSO_Optimizer
+    from metabox_amd.problem.bbob import BBOB_Dataset
+    config = make_config()
+    agent = load_agent(config, dev)
+    optimizer = RLEPSO_Optimizer(config)
+    tr, te = BBOB_Dataset.get_datasets('bbob', DIM, 5.0)
+    ps = sorted(tr.data + te.data, key=lambda p: p.func_id)          # all 24 functions, every branch exercised
+    B = args.instances
+    gid = np.arange(B, dtype=np.int64) + rank * B                       # global instance ids: weak scaling
+    pidx = (gid % len(ps)).astype(np.int32)
+    seeds = (gid // len(ps)).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
+    env = BatchedPBO_Env(ps, optimizer, pidx, seeds, early_stop=True)
+    actor = agent.actor
+
+    def steps_sum():
+        return int(env.results()['steps'].sum().item())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    K, W = args.steps, args.warmup
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    state = env.reset()
+    gen_in_ep, live, base = 0, 0, 0
+    t0 = None
+    with torch.no_grad():
+        for it in range(W + K):
+            if it == W:
+                barrier()
+                base = steps_sum()
+                t0 = time.perf_counter()
+            if gen_in_ep == EPISODE_GENS:
+                if it > W:
+                    live += steps_sum() - base
+                    base = 0
+                state = env.reset()
+                gen_in_ep = 0
+                if it <= W:
+                    base = 0
+            actions = actor.act_batch(state.to(torch.float32))
+            if it >= W:
+                ev0[it - W].record()
+            state, _, _ = env.step(actions)
+            if it >= W:
+                ev1[it - W].record()
+            gen_in_ep += 1
+        barrier()
+        elapsed = time.perf_counter() - t0
+        live += steps_sum() - base
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1))
+
+    tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    live_all, kern_ms_all, elapsed_max = float(tot[0]), float(tot[1]), float(tmax[0])
+
+    if rank == 0:
+        value = live_all / elapsed_max
+        avg_kernel_s = (kern_ms_all / world) / K / 1e3
+        bytes_per_launch = ALGO_BYTES_PER_STEP * (live_all / world / K)
+        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        out = {
+            'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed_max / K * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'RLEPSO_Agent + RLEPSO_Optimizer, bbob dim=10 pop=100, {B} lock-step instances per GPU '
+                                   f'(24 bbob functions round-robin x seeds), maxFEs=20000 (199 generations/episode), '
+                                   f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
+                       'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_rlepso_step',
+                         'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
+                         'live_instances_per_launch': live_all / world / K},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,2 @@
+from .basic_agent import Basic_Agent
+from .rlepso_agent import RLEPSO_Agent

@@ -1,0 +1,244 @@
+"""RLEPSO agent: PPO actor-critic over the scalar state fes/maxFEs (reference: src/agent/rlepso_agent.py).
+
+Actor : two MLPs 1 -> 64 -> 32 -> 35 (ReLU); mu = (tanh+1)/2, sigma = (tanh+1)/2*(max_sigma-min_sigma)+min_sigma,
+        action = clamp(Normal(mu, sigma).sample(), 0, 1)                      (rlepso_agent.py:9-47)
+Critic: MLP 1 -> 16 -> 8 -> 1                                                  (rlepso_agent.py:50-61)
+
+``rollout_episode`` / ``train_episode`` keep the reference's single-environment semantics.  ``rollout_batch``
+is the MI355X path: one policy forward over the whole instance batch per generation (PyTorch-ROCm GEMMs), one
+fused generation kernel, no host synchronisation inside the episode.
+"""
+import numpy as np
+import torch
+from torch import nn
+from torch.distributions import Normal
+
+from .basic_agent import Basic_Agent
+from .networks import MLP
+from .utils import Memory, save_class
+
+
+class Actor(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        net = [{'in': config.feature_dim, 'out': 64, 'drop_out': 0, 'activation': 'ReLU'},
+               {'in': 64, 'out': 32, 'drop_out': 0, 'activation': 'ReLU'},
+               {'in': 32, 'out': config.action_dim, 'drop_out': 0, 'activation': 'None'}]
+        self.mu_net = MLP(net)
+        self.sigma_net = MLP(net)
+        self.max_sigma = config.max_sigma
+        self.min_sigma = config.min_sigma
+
+    def distribution(self, x):
+        mu = (torch.tanh(self.mu_net(x)) + 1.) / 2.
+        sigma = (torch.tanh(self.sigma_net(x)) + 1.) / 2. * (self.max_sigma - self.min_sigma) + self.min_sigma
+        return mu, sigma
+
+    def forward(self, x, fixed_action=None, require_entropy=False):
+        mu, sigma = self.distribution(x)
+        policy = Normal(mu, sigma)
+        action = fixed_action if fixed_action is not None else torch.clamp(policy.sample(), min=0, max=1)
+        log_prob = torch.sum(policy.log_prob(action))
+        if require_entropy:
+            return action, log_prob, policy.entropy()
+        return action, log_prob
+
+    @torch.no_grad()
+    def act_batch(self, states):
+        """[B, 1] float32 -> [B, 35] float32 actions for B independent environments."""
+        mu, sigma = self.distribution(states)
+        return torch.clamp(torch.normal(mu, sigma), min=0, max=1)
+
+
+class Critic(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.value_head = MLP([{'in': config.feature_dim, 'out': 16, 'drop_out': 0, 'activation': 'ReLU'},
+                               {'in': 16, 'out': 8, 'drop_out': 0, 'activation': 'ReLU'},
+                               {'in': 8, 'out': 1, 'drop_out': 0, 'activation': 'None'}])
+
+    def forward(self, h):
+        v = self.value_head(h)
+        return v.detach().squeeze(), v.squeeze()
+
+
+_REF_PREFIX = {'actor/_Actor__mu_net.': 'mu_net.', 'actor/_Actor__sigma_net.': 'sigma_net.',
+               'critic/_Critic__value_head.': 'value_head.'}
+
+
+class RLEPSO_Agent(Basic_Agent):
+    def __init__(self, config):
+        super().__init__(config)
+        # the agent writes its hyper-parameters into the shared config like the reference (rlepso_agent.py:69-78)
+        config.feature_dim = 1
+        config.action_dim = 35
+        config.action_shape = (35,)
+        config.n_step = 10
+        config.K_epochs = 3
+        config.eps_clip = 0.1
+        config.gamma = 0.999
+        config.max_sigma = 0.7
+        config.min_sigma = 0.01
+        config.lr = 1e-5
+        self.__config = config
+        self.__device = config.device
+        self.__actor = Actor(config).to(self.__device)
+        self.__critic = Critic(config).to(self.__device)
+        self.__optimizer_actor = torch.optim.Adam([{'params': self.__actor.parameters(), 'lr': config.lr}])
+        self.__optimizer_critic = torch.optim.Adam([{'params': self.__critic.parameters(), 'lr': config.lr}])
+        self.__learning_time = 0
+        self.__cur_checkpoint = 0
+        if getattr(config, 'agent_save_dir', None):
+            save_class(config.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
+        self.__cur_checkpoint += 1
+
+    # ---- weights -----------------------------------------------------------------------------------
+    @property
+    def actor(self):
+        return self.__actor
+
+    @property
+    def critic(self):
+        return self.__critic
+
+    def load_exported_weights(self, npz):
+        """Load the arrays exported from a reference checkpoint by tools/gen_golden.py (`policy` section)."""
+        sd_a, sd_c = {}, {}
+        for k in npz.files if hasattr(npz, 'files') else npz:
+            for pre, new in _REF_PREFIX.items():
+                if k.startswith(pre):
+                    (sd_c if pre.startswith('critic') else sd_a)[new + k[len(pre):]] = torch.as_tensor(np.asarray(npz[k]))
+        self.__actor.load_state_dict(sd_a)
+        self.__critic.load_state_dict(sd_c)
+        return self
+
+    def to(self, device):
+        self.__device = device
+        self.__config.device = device
+        self.__actor.to(device)
+        self.__critic.to(device)
+        return self
+
+    def update_setting(self, config):
+        self.__config.max_learning_step = config.max_learning_step
+        self.__config.agent_save_dir = config.agent_save_dir
+        self.__learning_time = 0
+        save_class(self.__config.agent_save_dir, 'checkpoint0', self)
+        self.__config.save_interval = config.save_interval
+        self.__cur_checkpoint = 1
+
+    # ---- rollout -----------------------------------------------------------------------------------
+    def rollout_episode(self, env):
+        """Single environment, reference loop (rlepso_agent.py:294-303)."""
+        is_done = False
+        state = env.reset()
+        R = 0
+        while not is_done:
+            state = torch.FloatTensor(state).to(self.__device)
+            with torch.no_grad():
+                action = self.__actor(state)[0].cpu().numpy()
+            state, reward, is_done = env.step(action)
+            R += reward
+        return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
+
+    @torch.no_grad()
+    def rollout_batch(self, env, max_steps=None):
+        """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.
+
+        Every update() bills at least NP evaluations, so after ceil((maxFEs-NP)/NP) generations every instance has
+        reached ``fes >= maxFEs``; instances that finish earlier idle inside the kernel.
+        """
+        c = self.__config
+        if max_steps is None:
+            max_steps = -(-(c.maxFEs - c.NP) // c.NP)
+        state = env.reset()
+        for _ in range(max_steps):
+            actions = self.__actor.act_batch(state.to(torch.float32))
+            state, _, _ = env.step(actions)
+        res = env.results()
+        return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
+                'cost_len': res['cost_len']}
+
+    # ---- training (PPO, single environment; reference rlepso_agent.py:113-292) ------------------------
+    def train_episode(self, env):
+        config = self.__config
+        memory = Memory()
+        state = torch.FloatTensor(env.reset()).to(self.__device)
+        gamma, n_step, K_epochs, eps_clip = config.gamma, config.n_step, config.K_epochs, config.eps_clip
+        t, _R, is_done = 0, 0, False
+
+        def info():
+            return {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1], 'return': _R,
+                    'learn_steps': self.__learning_time}
+        while not is_done:
+            t_s = t
+            entropy, bl_val_detached, bl_val = [], [], []
+            while t - t_s < n_step:
+                memory.states.append(state.clone())
+                action, log_lh, entro_p = self.__actor(state, require_entropy=True)
+                action = action.reshape(config.action_shape)
+                memory.actions.append(action.clone().detach())
+                memory.logprobs.append(log_lh)
+                entropy.append(entro_p.detach().cpu())
+                v_det, v = self.__critic(state)
+                bl_val_detached.append(v_det)
+                bl_val.append(v)
+                next_state, reward, is_done = env.step(action.cpu().numpy())
+                _R += reward
+                memory.rewards.append(torch.FloatTensor([reward]).to(self.__device))
+                t += 1
+                state = torch.FloatTensor(next_state).to(self.__device)
+                if is_done:
+                    break
+            t_time = t - t_s
+            old_actions = torch.stack(memory.actions)
+            old_states = torch.stack(memory.states).detach()
+            old_logprobs = torch.stack(memory.logprobs).detach().view(-1)
+            old_value = None
+            for _k in range(K_epochs):
+                if _k == 0:
+                    logprobs = memory.logprobs
+                else:
+                    logprobs, entropy, bl_val_detached, bl_val = [], [], [], []
+                    for tt in range(t_time):
+                        _, log_p, entro_p = self.__actor(old_states[tt], fixed_action=old_actions[tt], require_entropy=True)
+                        logprobs.append(log_p)
+                        entropy.append(entro_p.detach().cpu())
+                        v_det, v = self.__critic(old_states[tt])
+                        bl_val_detached.append(v_det)
+                        bl_val.append(v)
+                logprobs = torch.stack(logprobs).view(-1)
+                bl_val_detached = torch.stack(bl_val_detached).view(-1)
+                bl_val = torch.stack(bl_val).view(-1)
+                # n-step bootstrapped returns
+                R = self.__critic(state)[0]
+                Reward = []
+                for r in memory.rewards[::-1]:
+                    R = R * gamma + r
+                    Reward.append(R)
+                Reward = torch.stack(Reward[::-1], 0).view(-1)
+                ratios = torch.exp(logprobs - old_logprobs.detach())
+                advantages = Reward - bl_val_detached
+                surr1 = ratios * advantages
+                surr2 = torch.clamp(ratios, 1 - eps_clip, 1 + eps_clip) * advantages
+                reinforce_loss = -torch.min(surr1, surr2).mean()
+                if old_value is None:
+                    baseline_loss = ((bl_val - Reward) ** 2).mean()
+                    old_value = bl_val.detach()
+                else:
+                    vpredclipped = old_value + torch.clamp(bl_val - old_value, -eps_clip, eps_clip)
+                    baseline_loss = torch.max((bl_val - Reward) ** 2, (vpredclipped - Reward) ** 2).mean()
+                self.__optimizer_actor.zero_grad()
+                self.__optimizer_critic.zero_grad()
+                baseline_loss.backward()
+                reinforce_loss.backward()
+                self.__optimizer_actor.step()
+                self.__optimizer_critic.step()
+                self.__learning_time += 1
+                if self.__learning_time >= (config.save_interval * self.__cur_checkpoint):
+                    save_class(config.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
+                    self.__cur_checkpoint += 1
+                if self.__learning_time >= config.max_learning_step:
+                    return True, info()
+            memory.clear_memory()
+        return self.__learning_time >= config.max_learning_step, info()

@@ -143,6 +143,11 @@ def gen_policy():
     data['meta/max_sigma'] = np.float64(actor._Actor__max_sigma)
     data['meta/min_sigma'] = np.float64(actor._Actor__min_sigma)
     np.savez_compressed(os.path.join(OUT, 'rlepso_policy.npz'), **data)
+    # weights only, shipped with the package (exported arrays of the reference's trained bbob_easy checkpoint)
+    pkg = os.path.join(os.path.dirname(HERE), 'metabox_amd', 'agent_model')
+    os.makedirs(pkg, exist_ok=True)
+    np.savez_compressed(os.path.join(pkg, 'rlepso_bbob_easy.npz'),
+                        **{k: v for k, v in data.items() if k.startswith(('actor/', 'critic/'))})
     print('policy:', {k: v.shape for k, v in data.items() if k.startswith('actor')})
 
 
