@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmbx.so')
+LIB_PATH = os.environ.get('MBX_LIB') or os.path.join(_HERE, 'csrc', 'libmbx.so')   # MBX_LIB: kernel-ablation builds (tools/kbench.py)
 
 c_double_p = C.POINTER(C.c_double)
 

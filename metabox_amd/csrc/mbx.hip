@@ -67,17 +67,19 @@ __global__ __launch_bounds__(kThreads) void k_eval(const DevProblem* problems, i
     const int row0 = blockIdx.x * rows;
     const int m = min(rows, n - row0);
     const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D);
+    const int64_t DV = align2(D);
     double* X = smem;
     double* T = X + NE;
     double* Z = T + NE;
     double* M1T = Z + SC;
     double* M2T = M1T + DD;
-    double* F = M2T + DD;
-    stage_transposed(P.m1, D, M1T);
-    stage_transposed(P.m2, D, M2T);
+    double* VEC = M2T + DD;
+    double* F = VEC + 4 * DV;
+    const EvalLds L{X, Z, T, M1T, M2T, VEC, VEC + DV, VEC + 2 * DV, VEC + 3 * DV, F};
+    stage_problem(P, L);
     for (int e = tid; e < m * D; e += kThreads) X[e] = x[(int64_t)row0 * D + e];
     __syncthreads();
-    eval_rows(P, X, m, Z, T, M1T, M2T, F);
+    eval_rows(P, L, m);
     for (int i = tid; i < m; i += kThreads) {
         double v = F[i];
         if (noisy && P.noise_kind != MBX_NOISE_NONE) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void k_eval(const DevProblem* problems, i
 static size_t eval_lds_bytes(int rows, int D)
 {
     const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D);
-    return (size_t)(2 * NE + SC + 2 * DD + align2(rows)) * sizeof(double);
+    return (size_t)(2 * NE + SC + 2 * DD + 4 * align2(D) + align2(rows)) * sizeof(double);
 }
 
 __global__ void k_init_state(double* state, int64_t stride, int64_t sc_off, int B)
@@ -162,7 +164,7 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
     if (D < 2 || D > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", D);
     std::vector<double> pool;
     std::vector<DevProblem> hp(n_problems);
-    struct Off { int64_t o[9]; };
+    struct Off { int64_t o[10]; };
     std::vector<Off> offs(n_problems);
     auto push = [&](const double* p, size_t n) -> int64_t {
         if (!p) return -1;
@@ -190,15 +192,28 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
         o.o[0] = push(d.dshift, D); o.o[1] = push(d.m1, DD); o.o[2] = push(d.m2, DD);
         o.o[3] = push(d.v0, D); o.o[4] = push(d.v1, D); o.o[5] = push(d.v2, D);
         o.o[6] = push(d.py, PK); o.o[7] = push(d.pc, PK); o.o[8] = push(d.pw, d.n_peaks);
+        o.o[9] = -1;
+        if (d.kind == 21 || d.kind == 22) {
+            // R y_k for every peak: z_k = R (x - y_k) = R x - R y_k lets the kernel rotate x once per row
+            // instead of once per (row, peak) pair (10x fewer flops at D = 10); rounding differs by O(ulp |R x|).
+            std::vector<double> ry(PK);
+            for (int k = 0; k < d.n_peaks; ++k)
+                for (int r = 0; r < D; ++r) {
+                    double acc = 0.;
+                    for (int j = 0; j < D; ++j) acc += d.m1[(size_t)r * D + j] * d.py[(size_t)k * D + j];
+                    ry[(size_t)k * D + r] = acc;
+                }
+            o.o[9] = push(ry.data(), PK);
+        }
     }
     mbx_suite* s = new mbx_suite();
     s->n = n_problems; s->dim = D;
     HIP_TRY(hipMalloc(&s->d_pool, pool.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(s->d_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice));
     for (int i = 0; i < n_problems; ++i) {
-        const double** ptrs[9] = {&hp[i].dshift, &hp[i].m1, &hp[i].m2, &hp[i].v0, &hp[i].v1,
-                                  &hp[i].v2, &hp[i].py, &hp[i].pc, &hp[i].pw};
-        for (int k = 0; k < 9; ++k) *ptrs[k] = offs[i].o[k] < 0 ? nullptr : s->d_pool + offs[i].o[k];
+        const double** ptrs[10] = {&hp[i].dshift, &hp[i].m1, &hp[i].m2, &hp[i].v0, &hp[i].v1,
+                                   &hp[i].v2, &hp[i].py, &hp[i].pc, &hp[i].pw, &hp[i].pyr};
+        for (int k = 0; k < 10; ++k) *ptrs[k] = offs[i].o[k] < 0 ? nullptr : s->d_pool + offs[i].o[k];
     }
     HIP_TRY(hipMalloc(&s->d_problems, n_problems * sizeof(DevProblem)));
     HIP_TRY(hipMemcpy(s->d_problems, hp.data(), n_problems * sizeof(DevProblem), hipMemcpyHostToDevice));

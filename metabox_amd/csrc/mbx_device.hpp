@@ -14,6 +14,18 @@
 
 namespace mbx {
 
+#ifdef MBX_NOINLINE_MATH
+#define MBX_MATH __device__ __noinline__
+#else
+#define MBX_MATH __device__ __forceinline__
+#endif
+MBX_MATH double m_pow(double a, double b) { return pow(a, b); }
+MBX_MATH double m_sin(double a) { return sin(a); }
+MBX_MATH double m_cos(double a) { return cos(a); }
+MBX_MATH double m_exp(double a) { return exp(a); }
+MBX_MATH double m_log(double a) { return log(a); }
+
+
 constexpr int kThreads = 256;          // 4 waves of 64
 constexpr double kTwoPi = 6.283185307179586;
 
@@ -24,6 +36,7 @@ struct DevProblem {
     int32_t func_id, kind, dim, n_peaks, noise_kind, pad;
     double bias, lb, ub, pen_coef, s[4], noise_a, noise_b, optimum;
     const double *dshift, *m1, *m2, *v0, *v1, *v2, *py, *pc, *pw;
+    const double* pyr;   // Gallagher: R y_k, precomputed at upload (mbx_suite_create)
 };
 
 // ------------------------------------------------------------------------------------------------ Philox
@@ -57,10 +70,10 @@ struct Rng {                      // per-instance stream: key = seed, counter = 
 
 __device__ __forceinline__ void box_muller(double ua, double ub, double& n0, double& n1)
 {
-    const double r = sqrt(-2.0 * log(1.0 - ua));
+    const double r = sqrt(-2.0 * m_log(1.0 - ua));
     const double t = kTwoPi * ub;
-    n0 = r * cos(t);
-    n1 = r * sin(t);
+    n0 = r * m_cos(t);
+    n1 = r * m_sin(t);
 }
 
 // noise draws (a,b,c) of evaluation row `row` (include/mbx_layout.h §3)
@@ -90,9 +103,9 @@ __device__ __forceinline__ double apply_noise(const DevProblem& P, double ftrue,
     const double fu = ftrue - P.optimum;
     double fn;
     if (P.noise_kind == MBX_NOISE_GAUSS) {
-        fn = fu * exp(P.noise_a * a);
+        fn = fu * m_exp(P.noise_a * a);
     } else if (P.noise_kind == MBX_NOISE_UNIFORM) {
-        fn = fu * pow(a, P.noise_b) * fmax(1., pow(1e9 / (fu + 1e-99), P.noise_a * (0.49 + 1. / P.dim) * b));
+        fn = fu * m_pow(a, P.noise_b) * fmax(1., m_pow(1e9 / (fu + 1e-99), P.noise_a * (0.49 + 1. / P.dim) * b));
     } else {
         fn = fu + P.noise_a * fmax(0., 1e3 + (a < P.noise_b ? 1. : 0.) * b / (fabs(c) + 1e-199));
     }
@@ -130,22 +143,23 @@ __device__ __forceinline__ void block_argmin(const double* a, int n, double* red
 }
 
 // ------------------------------------------------------------------------------------------------ BBOB pieces
+
 __device__ __forceinline__ double osc1(double x)                 // osc_transform, bbob.py:51-67
 {
     if (x > 0.) {
-        const double y = log(x) / 0.1;
-        return pow(exp(y + 0.49 * (sin(y) + sin(0.79 * y))), 0.1);
+        const double y = m_log(x) / 0.1;
+        return m_pow(m_exp(y + 0.49 * (m_sin(y) + m_sin(0.79 * y))), 0.1);
     }
     if (x < 0.) {
-        const double y = log(-x) / 0.1;
-        return -pow(exp(y + 0.49 * (sin(0.55 * y) + sin(0.31 * y))), 0.1);
+        const double y = m_log(-x) / 0.1;
+        return -m_pow(m_exp(y + 0.49 * (m_sin(0.55 * y) + m_sin(0.31 * y))), 0.1);
     }
     return x;
 }
 
 __device__ __forceinline__ double asy1(double x, double beta_lin)  // asy_transform, bbob.py:70-82
 {
-    return x > 0. ? pow(x, 1. + beta_lin * sqrt(x)) : x;
+    return x > 0. ? m_pow(x, 1. + beta_lin * sqrt(x)) : x;
 }
 
 __device__ __forceinline__ double pen_row(const double* x, int D, double ub)   // pen_func, bbob.py:85-93
@@ -158,98 +172,122 @@ __device__ __forceinline__ double pen_row(const double* x, int D, double ub)   /
     return s;
 }
 
-// Stage a D x D row-major matrix from global memory into LDS, transposed (MT[k*D+d] = M[d*D+k]) so that
-// lanes that differ in d read consecutive LDS words.
-__device__ __forceinline__ void stage_transposed(const double* __restrict__ M, int D, double* MT)
+// LDS working set of the block-cooperative evaluator.
+struct EvalLds {
+    const double* X;       // [n*D]  candidate positions (input)
+    double *Z, *T;         // [max(n*D, 256)], [n*D]  scratch
+    double *M1T, *M2T;     // [D*D]  linear maps, transposed: MT[k*D+d] = M[d][k]
+    double *DSH, *V0, *V1, *V2;   // [D] per-problem vectors
+    double* F;             // [n]    objective values (output)
+};
+
+// Stage the per-problem constants (two D x D maps, transposed so that lanes differing in d read consecutive
+// LDS words, and the four D-vectors) from global memory into LDS.  Caller synchronises afterwards.
+__device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds& L)
 {
-    if (M == nullptr) return;
+    const int D = P.dim;
     for (int t = threadIdx.x; t < D * D; t += kThreads) {
         const int d = t / D, k = t - d * D;
-        MT[k * D + d] = M[t];
+        if (P.m1) L.M1T[k * D + d] = P.m1[t];
+        if (P.m2) L.M2T[k * D + d] = P.m2[t];
+    }
+    for (int d = threadIdx.x; d < D; d += kThreads) {
+        L.DSH[d] = P.dshift[d];
+        L.V0[d] = P.v0 ? P.v0[d] : 0.;
+        L.V1[d] = P.v1 ? P.v1[d] : 0.;
+        L.V2[d] = P.v2 ? P.v2[d] : 0.;
     }
 }
 
-// Out[i][d] = sum_k M[d][k] * (In[i][k] - sub[k])   (sr_func, bbob.py:6-8; sub == nullptr -> plain product)
-__device__ __forceinline__ void matvec_rows(const double* MT, const double* In, const double* __restrict__ sub, int n, int D,
-                                            double* Out)
+// Out[i][d] = sum_k M[d][k] * In[i][k]   (the matmul of sr_func, bbob.py:6-8), k ascending, no FMA contraction
+__device__ __forceinline__ void matvec_rows(const double* MT, const double* In, int n, int D, double* Out)
 {
     const int NE = n * D;
     for (int e = threadIdx.x; e < NE; e += kThreads) {
         const int i = e / D, d = e - i * D;
         const double* row = In + i * D;
+        const double* col = MT + d;
         double s = 0.;
-        if (sub) {
-            for (int k = 0; k < D; ++k) s += MT[k * D + d] * (row[k] - sub[k]);
-        } else {
-            for (int k = 0; k < D; ++k) s += MT[k * D + d] * row[k];
-        }
+#pragma unroll 5
+        for (int k = 0; k < D; ++k) s += col[k * D] * row[k];
         Out[e] = s;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Block-cooperative objective: F[i] = func(X[i,:]) for i < n, bias and boundary penalty included
-// (the value F*.func returns).  X, Z, T are LDS arrays of n*D doubles, M1T/M2T the transposed linear
-// maps in LDS, F an LDS array of n doubles.  Must be called by every thread of the block.
+// (the value F*.func returns).  All arrays of `L` live in LDS; stage_problem() must have been called.
+// Must be called by every thread of the block.
 // ------------------------------------------------------------------------------------------------
-__device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z, double* T, const double* M1T,
-                          const double* M2T, double* F)
+__device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
 {
     const int D = P.dim, NE = n * D, kind = P.kind, tid = threadIdx.x;
     const double ub = P.ub, bias = P.bias;
-    const double* __restrict__ v0 = P.v0;
-    const double* __restrict__ v1 = P.v1;
-    const double* __restrict__ v2 = P.v2;
+    const double* X = L.X;
+    double* Z = L.Z;
+    double* T = L.T;
+    double* F = L.F;
+    const double* M1T = L.M1T;
+    const double* M2T = L.M2T;
+    const double* v0 = L.V0;
+    const double* v1 = L.V1;
+    const double* v2 = L.V2;
+    const double* dsh = L.DSH;
 
-    // ---- phase A: first linear map
-    const bool first_map = !(kind == 5 || kind == 20 || kind == 21 || kind == 22 || kind == 24);
-    if (first_map) matvec_rows(M1T, X, P.dshift, n, D, Z);
+    // ---- phase A: first linear map  z = M1 (x - dshift)   (Gallagher: M1 x, the peaks are pre-rotated)
+    const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
+    if (first_map) {
+        const bool gall = kind == 21 || kind == 22;
+        if (!gall) {
+            for (int e = tid; e < NE; e += kThreads) { const int d = e % D; T[e] = X[e] - dsh[d]; }
+            __syncthreads();
+        }
+        matvec_rows(M1T, gall ? X : T, n, D, Z);
+    }
     __syncthreads();
 
     // ---- phase E1: element-wise transforms
     if (kind == 21 || kind == 22) {
-        // Gallagher (bbob.py:796-800): S threads share a row and split the peaks; partial maxima go to Z.
-        const int S = kThreads / n > 0 ? kThreads / n : 1;
+        // Gallagher (bbob.py:796-800): max_k w_k exp(-1/(2D) sum_d C_kd z_kd^2), z_k = R (x - y_k) = R x - R y_k.
+        // Every (row, peak) pair is one work item; the row maximum is taken with an LDS atomic max on the bit
+        // pattern (all candidates are >= 0, so integer order == numeric order).
+        unsigned long long* rowmax = reinterpret_cast<unsigned long long*>(T);
+        for (int i = tid; i < n; i += kThreads) rowmax[i] = 0ull;
+        __syncthreads();
         const int npk = P.n_peaks;
-        for (int w = tid; w < n * S; w += kThreads) {
-            const int i = w / S, sl = w - i * S;
-            const double* x = X + i * D;
-            double best = -INFINITY;
-            for (int k = sl; k < npk; k += S) {
-                const double* __restrict__ yk = P.py + k * D;
-                const double* __restrict__ ck = P.pc + k * D;
-                double acc = 0.;
-                for (int d = 0; d < D; ++d) {
-                    double zd = 0.;
-                    for (int j = 0; j < D; ++j) zd += M1T[j * D + d] * (x[j] - yk[j]);
-                    acc += ck[d] * (zd * zd);
-                }
-                const double e = P.pw[k] * exp((-0.5 / D) * acc);
-                if (e > best) best = e;
-            }
-            Z[w] = best;
+        const double cexp = -0.5 / D;
+        for (int w = tid; w < n * npk; w += kThreads) {
+            const int k = w / n, i = w - k * n;                    // lanes of a wave share the peak
+            const double* __restrict__ ry = P.pyr + k * D;
+            const double* __restrict__ ck = P.pc + k * D;
+            const double* rx = Z + i * D;
+            double acc = 0.;
+            for (int d = 0; d < D; ++d) { const double zd = rx[d] - ry[d]; acc += ck[d] * (zd * zd); }
+            const double ev = P.pw[k] * m_exp(cexp * acc);
+            atomicMax(&rowmax[i], (unsigned long long)__double_as_longlong(ev));
         }
     } else {
+        const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
         for (int e = tid; e < NE; e += kThreads) {
-            const int i = e / D, d = e - i * D;
+            const int d = e % D;
             switch (kind) {
             case 2: case 10: { const double o = osc1(Z[e]); T[e] = v0[d] * (o * o); break; }
-            case 3: { const double z = v0[d] * asy1(osc1(Z[e]), v1[d]); Z[e] = z; T[e] = cos(kTwoPi * z); break; }
+            case 3: { const double z = v0[d] * asy1(osc1(Z[e]), v1[d]); Z[e] = z; T[e] = m_cos(kTwoPi * z); break; }
             case 4: {
                 double o = osc1(Z[e]);
                 if ((d & 1) == 0 && o > 0.) o *= 10.;
                 const double z = o * v0[d];
-                Z[e] = z; T[e] = cos(kTwoPi * z);
+                Z[e] = z; T[e] = m_cos(kTwoPi * z);
                 break;
             }
             case 5: {
                 const double x = X[e];
                 double zi = x;
-                if (x * P.dshift[d] > ub * ub) zi = (zi > 0. ? 1. : (zi < 0. ? -1. : 0.)) * ub;
+                if (x * dsh[d] > ub * ub) zi = (zi > 0. ? 1. : (zi < 0. ? -1. : 0.)) * ub;
                 T[e] = v1[d] - zi * v0[d];
                 break;
             }
-            case 6: { double zi = Z[e]; if (zi * P.dshift[d] > 0.) zi *= 100.; T[e] = zi * zi; break; }
+            case 6: { double zi = Z[e]; if (zi * dsh[d] > 0.) zi *= 100.; T[e] = zi * zi; break; }
             case 7: {
                 const double zh = Z[e];
                 T[e] = fabs(zh) > 0.5 ? floor(0.5 + zh) : floor(0.5 + 10. * zh) / 10.;
@@ -259,7 +297,7 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
             case 9: case 19: Z[e] = Z[e] + 0.5; break;
             case 11: { const double o = osc1(Z[e]); T[e] = o * o; break; }
             case 12: case 17: case 18: T[e] = asy1(Z[e], v1[d]); break;
-            case 14: T[e] = pow(fabs(Z[e]), v0[d]); break;
+            case 14: T[e] = m_pow(fabs(Z[e]), v0[d]); break;
             case 15: T[e] = asy1(osc1(Z[e]), v1[d]); break;
             case 16: T[e] = osc1(Z[e]); break;
             case 20: T[e] = v2[d] * X[e]; break;
@@ -271,7 +309,7 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
                     const double a = p2 * z;
                     temp += fabs(a - floor(a + 0.5)) / p2;
                 }
-                T[e] = pow(1 + (d + 1) * temp, 10 / pow((double)D, 1.2));
+                T[e] = m_pow(1 + (d + 1) * temp, kats_exp);
                 break;
             }
             case 24: T[e] = v0[d] * X[e] - P.s[0]; break;         // x_hat - mu0
@@ -285,45 +323,46 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
     if (kind == 7) {
         for (int i = tid; i < n; i += kThreads) F[i] = fabs(Z[i * D]);
         __syncthreads();
-        matvec_rows(M2T, T, nullptr, n, D, Z);
+        matvec_rows(M2T, T, n, D, Z);
     } else if (kind == 12 || kind == 24) {
-        matvec_rows(M1T, T, nullptr, n, D, Z);
+        matvec_rows(M1T, T, n, D, Z);
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
-        matvec_rows(M2T, T, nullptr, n, D, Z);
+        matvec_rows(M2T, T, n, D, Z);
     }
     __syncthreads();
 
     // ---- phase E2: element-wise terms after the second map
     if (kind == 15 || kind == 24) {
-        for (int e = tid; e < NE; e += kThreads) T[e] = cos(kTwoPi * Z[e]);
+        for (int e = tid; e < NE; e += kThreads) T[e] = m_cos(kTwoPi * Z[e]);
     } else if (kind == 16) {                                        // Weierstrass series, bbob.py:623
         for (int e = tid; e < NE; e += kThreads) {
             const double base = kTwoPi * (Z[e] + 0.5);
             double s = 0., ak = 1., bk = 1.;
-            for (int k = 0; k < 12; ++k) { s += ak * cos(base * bk); ak *= 0.5; bk *= 3.; }
+#pragma unroll 1
+            for (int k = 0; k < 12; ++k) { s += ak * m_cos(base * bk); ak *= 0.5; bk *= 3.; }
             T[e] = s;
         }
     } else if (kind == 17 || kind == 18) {                          // Schaffers, bbob.py:642-643
         for (int e = tid; e < NE; e += kThreads) {
-            const int i = e / D, d = e - i * D;
+            const int d = e % D;
             if (d < D - 1) {
                 const double s = sqrt(Z[e] * Z[e] + Z[e + 1] * Z[e + 1]);
-                T[e] = sqrt(s) * (pow(sin(50 * pow(s, 0.2)), 2) + 1);
+                T[e] = sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1);
             }
         }
     } else if (kind == 19) {                                        // Griewank-Rosenbrock, bbob.py:702-703
         for (int e = tid; e < NE; e += kThreads) {
-            const int i = e / D, d = e - i * D;
+            const int d = e % D;
             if (d < D - 1) {
                 const double a = Z[e] * Z[e] - Z[e + 1];
                 const double b = 1. - Z[e];
                 const double s = 100. * (a * a) + b * b;
-                T[e] = s / 4000. - cos(s);
+                T[e] = s / 4000. - m_cos(s);
             }
         }
     } else if (kind == 20) {                                        // Schwefel, bbob.py:754-756
         for (int e = tid; e < NE; e += kThreads) {
-            const int i = e / D, d = e - i * D;
+            const int d = e % D;
             double zi = T[e];
             if (d > 0) zi += 0.25 * (T[e - 1] - v1[d - 1]);
             Z[e] = 100. * (v0[d] * (zi - v1[d]) + v1[d]);
@@ -333,7 +372,7 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
             const double z = Z[e];
             const double q = fmax(0., fabs(z / 100) - ub);
             T[e] = q * q;
-            Z[e] = z * sin(sqrt(fabs(z)));
+            Z[e] = z * m_sin(sqrt(fabs(z)));
         }
     }
     __syncthreads();
@@ -361,7 +400,7 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
             break;
         }
         case 5: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = s + bias; break; }
-        case 6: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = pow(osc1(s), 0.9) + bias; break; }
+        case 6: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = m_pow(osc1(s), 0.9) + bias; break; }
         case 7: {
             double s = 0.;
             for (int d = 0; d < D; ++d) s += v0[d] * (z[d] * z[d]);
@@ -381,15 +420,15 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
         case 11: { double s = 0.; for (int d = 1; d < D; ++d) s += t[d]; f = 1000000 * t[0] + s + bias; break; }
         case 12: { double s = 0.; for (int d = 1; d < D; ++d) s += 1000000 * (z[d] * z[d]); f = z[0] * z[0] + s + bias; break; }
         case 13: { double s = 0.; for (int d = 1; d < D; ++d) s += z[d] * z[d]; f = z[0] * z[0] + 100. * sqrt(s) + bias; break; }
-        case 14: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = pow(s, 0.5) + bias + bh; break; }
+        case 14: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = m_pow(s, 0.5) + bias + bh; break; }
         case 16: {
             double acc = 0.; for (int d = 0; d < D; ++d) acc += t[d];
-            f = 10 * pow(acc / D - P.s[0], 3) + 10. / D * pen_row(x, D, ub) + bias;
+            f = 10 * m_pow(acc / D - P.s[0], 3) + 10. / D * pen_row(x, D, ub) + bias;
             break;
         }
         case 17: case 18: {
             double acc = 0.; for (int d = 0; d < D - 1; ++d) acc += t[d];
-            f = pow(1. / (D - 1) * acc, 2) + bh + bias;
+            f = m_pow(1. / (D - 1) * acc, 2) + bh + bias;
             break;
         }
         case 19: {
@@ -404,9 +443,7 @@ __device__ void eval_rows(const DevProblem& P, const double* X, int n, double* Z
             break;
         }
         case 21: case 22: {
-            const int S = kThreads / n > 0 ? kThreads / n : 1;
-            double best = -INFINITY;
-            for (int sl = 0; sl < S; ++sl) { const double v = Z[i * S + sl]; if (v > best) best = v; }
+            const double best = __longlong_as_double((long long)reinterpret_cast<const unsigned long long*>(T)[i]);
             const double o = osc1(10 - best);
             f = o * o + bias + bh;
             break;

@@ -25,8 +25,9 @@ struct BatchParams {
 
 // LDS carve-up (all offsets in doubles; base is 16-byte aligned, every array starts 16-byte aligned)
 struct RlLds {
-    double *PB, *X, *Z, *T, *M1T, *M2T, *PBC, *CC, *NC, *PNI, *CMUT, *GB, *COEF, *RED;
+    double *PB, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *PBC, *CC, *NC, *PNI, *CMUT, *PCI, *R1, *R2, *GB, *COEF, *RED;
     int *IMPR, *MASK, *DIRTY;
+    __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
 
 __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_t)1; }
@@ -35,8 +36,9 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP);
-    // PB, X, T: NE each; Z: SC; M1T, M2T; PBC, CC, NC, PNI, CMUT: P each; GB: D; COEF: 6*16; RED: 16; 3 int arrays
-    return 3 * NE + SC + 2 * DD + 5 * P + align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
+    // PB, X, T: NE each; Z: SC; M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each;
+    // COEF: 6*16; RED: 16; 3 int arrays
+    return 3 * NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
 }
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
@@ -51,6 +53,13 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
     L.Z = p; p += SC;
     L.M1T = p; p += DD;
     L.M2T = p; p += DD;
+    L.DSH = p; p += align2(D);
+    L.V0 = p; p += align2(D);
+    L.V1 = p; p += align2(D);
+    L.V2 = p; p += align2(D);
+    L.PCI = p; p += P;
+    L.R1 = p; p += P;
+    L.R2 = p; p += P;
     L.PBC = p; p += P;
     L.CC = p; p += P;
     L.NC = p; p += P;
@@ -69,7 +78,12 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
 __device__ __forceinline__ void rl_costs(const DevProblem& P, const RlLds& L, int NP, const Rng& rng, const double* tape_noise,
                                          uint32_t siteA, uint32_t siteB)
 {
-    eval_rows(P, L.X, NP, L.Z, L.T, L.M1T, L.M2T, L.NC);
+#ifdef MBX_ABLATE_EVAL
+    for (int i = threadIdx.x; i < NP; i += kThreads) L.NC[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
+    __syncthreads();
+#else
+    eval_rows(P, L.eval(), NP);
+#endif
     for (int i = threadIdx.x; i < NP; i += kThreads) {
         double f = L.NC[i];
         if (P.noise_kind != MBX_NOISE_NONE) {
@@ -129,8 +143,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
     const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, (uint32_t)episode};
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
 
-    stage_transposed(P.m1, D, L.M1T);
-    stage_transposed(P.m2, D, L.M2T);
+    stage_problem(P, L.eval());
     for (int e = tid; e < NE; e += kThreads) {
         double up, uv;
         if (tape) { up = tape[MBX_RLEPSO_TAPE_REPOS(NP, D) + e]; uv = tape[MBX_RLEPSO_TAPE_REVEL(NP, D) + e]; }
@@ -206,8 +219,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         L.DIRTY[i] = 0;
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
-    stage_transposed(P.m1, D, L.M1T);
-    stage_transposed(P.m2, D, L.M2T);
+    stage_problem(P, L.eval());
     // __get_coe (:112-132): float32 arithmetic (numpy >= 2 keeps float32 for scalar*python-float), group g
     // reads actions[g*n_group : g*n_group+7]
     if (tid < G) {
@@ -225,39 +237,47 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     }
     __syncthreads();
     const int per_group = NP / G;
-    for (int i = tid; i < NP; i += kThreads) {
+    const double pci_den = m_exp(10.) - 1;
+    for (int i = tid; i < NP; i += kThreads) {                    // per-particle quantities
         const int g = i / per_group;
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
+        L.PCI[i] = 0.05 + 0.45 * m_exp(10. * i / (NP - 1)) / pci_den;   // learning probability curve (:23-24)
+        if (tape) { L.R1[i] = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; L.R2[i] = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i]; }
+        else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w); }
     }
+    __syncthreads();
 
     // ---- velocity / position update, one element per thread-iteration (:179-195)
     double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
     double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
-    const double pci_den = exp(10.) - 1;
     for (int e = tid; e < NE; e += kThreads) {
         const int i = e / D, d = e - i * D;
-        double r1, r2, uc, uf; int t1, t2;
+        const double r1 = L.R1[i], r2 = L.R2[i];
+        double uc, uf; int t1, t2;
         if (tape) {
-            r1 = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; r2 = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i];
             uc = tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
             t1 = (int)tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2 = (int)tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1];
             uf = tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e];
         } else {
-            U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); r1 = u53(w.x, w.y); r2 = u53(w.z, w.w);
-            w = rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc = u53(w.x, w.y);
+            U4 w = rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc = u53(w.x, w.y);
             t1 = (int)__umulhi(w.z, (uint32_t)NP); t2 = (int)__umulhi(w.w, (uint32_t)NP);
             w = rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf = u53(w.x, w.y);
         }
         const double cur = gPos[e], pp = L.PB[e], fi = L.PBC[i];
         // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
-        const double pci = 0.05 + 0.45 * exp(10. * i / (NP - 1)) / pci_den;
+        const double pci = L.PCI[i];
         const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
         const double exemplar = uc > pci ? pp : L.PB[tw * D + d];
         const double v_clpso = uc * (exemplar - cur);
         // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109)
         int jb = 0;
         double fb = (L.PBC[0] - fi) / (fabs(L.PB[d] - pp) + 1e-5);
+#ifdef MBX_ABLATE_FDR
+        for (int j = 1; j < 2; ++j) {
+#else
+#pragma unroll 4
         for (int j = 1; j < NP; ++j) {
+#endif
             const double fdr = (L.PBC[j] - fi) / (fabs(L.PB[j * D + d] - pp) + 1e-5);
             if (fdr < fb) { fb = fdr; jb = j; }
         }
