@@ -87,6 +87,18 @@ def cpu_baseline(seconds_budget=20.0):
                       f'{steps} env-steps in {dt:.1f} s, C float64 oracle + torch-CPU actor, 1 thread'}
 
 
+def pmc_traffic_per_launch(live_per_launch):
+    """HBM bytes per launch of the generation kernel from the committed rocprofv3 PMC passes
+    (2 x FETCH_SIZE + WRITE_SIZE, calibration in profiles/*_pmc_hbm_traffic.json; collected with every instance
+    live), scaled to this run's average number of live instances per launch.  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
+    if not files:
+        return None
+    prof = json.load(open(files[-1]))
+    return prof['calibration']['hbm_bytes_per_launch'] / INSTANCES_PER_GPU * live_per_launch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -176,8 +188,10 @@ def main():
     if rank == 0:
         value = live_all / elapsed_max
         avg_kernel_s = (kern_ms_all / world) / K / 1e3
-        bytes_per_launch = ALGO_BYTES_PER_STEP * (live_all / world / K)
+        live_per_launch = live_all / world / K
+        bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
+        traffic = pmc_traffic_per_launch(live_per_launch)
         out = {
             'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed_max / K * 1e3, 'higher_is_better': True,
@@ -187,7 +201,8 @@ def main():
                                    f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
                        'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_rlepso_step',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_rlepso_step',
+                         'algorithmic_bytes_per_launch': bytes_per_launch,
                          'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
                          'live_instances_per_launch': live_all / world / K},
         }

@@ -269,17 +269,21 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
         const double exemplar = uc > pci ? pp : L.PB[tw * D + d];
         const double v_clpso = uc * (exemplar - cur);
-        // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109)
+        // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109).
+        // Ratios are compared by cross-multiplication (denominators are >= 1e-5 > 0): a_j/b_j < a*/b*  <=>
+        // a_j b* < a* b_j.  Exactly equal ratios give exactly equal products, so np.argmin's first-index rule is
+        // preserved; only ratios that differ by ~1 ulp could order differently from the rounded quotients.
         int jb = 0;
-        double fb = (L.PBC[0] - fi) / (fabs(L.PB[d] - pp) + 1e-5);
+        double ab = L.PBC[0] - fi, bb = fabs(L.PB[d] - pp) + 1e-5;
 #ifdef MBX_ABLATE_FDR
         for (int j = 1; j < 2; ++j) {
 #else
 #pragma unroll 4
         for (int j = 1; j < NP; ++j) {
 #endif
-            const double fdr = (L.PBC[j] - fi) / (fabs(L.PB[j * D + d] - pp) + 1e-5);
-            if (fdr < fb) { fb = fdr; jb = j; }
+            const double a = L.PBC[j] - fi;
+            const double b = fabs(L.PB[j * D + d] - pp) + 1e-5;
+            if (a * bb < ab * b) { ab = a; bb = b; jb = j; }
         }
         const double v_fdr = uf * (L.PB[jb * D + d] - pp);
         const double v_pbest = r1 * (pp - cur);
