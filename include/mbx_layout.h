@@ -95,6 +95,33 @@
 #define MBX_SITE_EVAL_A    9u
 #define MBX_SITE_EVAL_B    10u
 
+/* ---------------------------------------------------------------- 4. LDE (lde_optimizer.py) layouts
+ * tape per step, draw order of LDE_Optimizer.update (:88-90 pbest index, :109-121 r1/r2 after rejection,
+ * :44-47 crossover uniforms + jrand, eval noise):
+ *   pbest_idx[NP] r0[NP] r1[NP] jrand[NP] noise[3*NP] cross_u[NP*D]
+ * mbx_reset (init_population :133-134) uses cross_u as the position uniforms and noise[] for the evaluation.
+ * state block: pop[NP*D] (kept sorted by fitness, :74-79) fit[NP] hist_sum[8] scalars[16] cost_curve[nlog+1];
+ * hist_sum accumulates past_histo (:139,186), scalars[MBX_SC_HCOUNT] its length.
+ * Philox: MBX_SITE_LDE_PART(i): mulhi(w0,bound)=pbest_idx, w1 -> r0 over the NP-1 indices != i, w2 -> r1 over the
+ * NP-2 indices not in {i,r0} (same distribution as the reference's rejection loop), mulhi(w3,D)=jrand;
+ * MBX_SITE_LDE_ELEM(e): u53(w0,w1) = crossover / initial-position uniform.                                   */
+#define MBX_LDE_TAPE_PIDX(NP, D)   ((int64_t)0)
+#define MBX_LDE_TAPE_R0(NP, D)     ((int64_t)(NP))
+#define MBX_LDE_TAPE_R1(NP, D)     ((int64_t)2 * (NP))
+#define MBX_LDE_TAPE_JRAND(NP, D)  ((int64_t)3 * (NP))
+#define MBX_LDE_TAPE_NOISE(NP, D)  ((int64_t)4 * (NP))
+#define MBX_LDE_TAPE_CROSS(NP, D)  ((int64_t)7 * (NP))
+#define MBX_LDE_TAPE_STRIDE(NP, D) ((int64_t)7 * (NP) + (int64_t)(NP) * (D))
+#define MBX_LDE_BINS 5
+#define MBX_LDE_ST_POP(NP, D)      ((int64_t)0)
+#define MBX_LDE_ST_FIT(NP, D)      ((int64_t)(NP) * (D))
+#define MBX_LDE_ST_HSUM(NP, D)     ((int64_t)(NP) * (D) + (NP))
+#define MBX_LDE_ST_SCALARS(NP, D)  ((int64_t)(NP) * (D) + (NP) + 8)
+#define MBX_LDE_STATE_DOUBLES(NP, D, NLOG) (MBX_LDE_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_SC_HCOUNT 10
+#define MBX_SITE_LDE_PART  11u
+#define MBX_SITE_LDE_ELEM  12u
+
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u
 #define MBX_PHILOX_W0 0x9E3779B9u

@@ -1,2 +1,3 @@
 from .basic_agent import Basic_Agent
 from .rlepso_agent import RLEPSO_Agent
+from .lde_agent import LDE_Agent

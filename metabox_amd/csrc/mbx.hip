@@ -11,6 +11,7 @@
 
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"
+#include "mbx_lde.hpp"
 
 using namespace mbx;
 
@@ -53,7 +54,32 @@ struct mbx_batch {
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
     size_t lds_bytes = 0;
+    int64_t sc_off = 0;          // offset of the scalar block inside an instance's state
+    int64_t tape_stride = 0;
+    int state_dim = 0, action_dim = 0;
 };
+
+// per-algorithm geometry
+struct AlgoGeom { int64_t state_doubles, sc_off, tape_stride, lds_doubles; int state_dim, action_dim; };
+
+static AlgoGeom geom_of(const mbx_algo_cfg& c)
+{
+    AlgoGeom g{};
+    if (c.algo == MBX_ALGO_RLEPSO) {
+        g.state_doubles = MBX_RLEPSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_RLEPSO_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_RLEPSO_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = rl_lds_doubles(c.np, c.dim);
+        g.state_dim = 1; g.action_dim = 7 * c.n_group;
+    } else if (c.algo == MBX_ALGO_LDE) {
+        g.state_doubles = MBX_LDE_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_LDE_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_LDE_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = lde_lds_doubles(c.np, c.dim);
+        g.state_dim = c.np + 2 * MBX_LDE_BINS; g.action_dim = 2 * c.np;
+    }
+    return g;
+}
 
 // ------------------------------------------------------------------------------------------------ kernels
 // Stand-alone evaluation: each block stages the problem's linear maps and evaluates up to `rows` rows.
@@ -267,29 +293,32 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
-    if (c->np < 2 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [2, %d]", c->np, kThreads);
-    if (c->n_group < 1 || c->n_group > 16 || c->np / c->n_group < 1) return fail(MBX_E_ARG, "bad n_group %d", c->n_group);
+    if (c->algo != MBX_ALGO_RLEPSO && c->algo != MBX_ALGO_LDE)
+        return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
+    if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
+    if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
+    if (c->algo == MBX_ALGO_RLEPSO && (c->n_group < 1 || c->n_group > 16 || c->np / c->n_group < 1))
+        return fail(MBX_E_ARG, "bad n_group %d", c->n_group);
     if (c->max_fes <= 0 || c->log_interval <= 0 || c->n_logpoint <= 0) return fail(MBX_E_ARG, "bad budget/log settings");
     return MBX_OK;
 }
 
 extern "C" int mbx_state_dim(const mbx_algo_cfg* c)
 {
-    if (check_cfg(c)) return MBX_E_ARG;
-    return 1;
+    if (int rc = check_cfg(c)) return rc;
+    return geom_of(*c).state_dim;
 }
 
 extern "C" int mbx_action_dim(const mbx_algo_cfg* c)
 {
-    if (check_cfg(c)) return MBX_E_ARG;
-    return 7 * c->n_group;
+    if (int rc = check_cfg(c)) return rc;
+    return geom_of(*c).action_dim;
 }
 
 extern "C" int64_t mbx_tape_stride(const mbx_algo_cfg* c)
 {
-    if (check_cfg(c)) return MBX_E_ARG;
-    return MBX_RLEPSO_TAPE_STRIDE(c->np, c->dim);
+    if (int rc = check_cfg(c)) return rc;
+    return geom_of(*c).tape_stride;
 }
 
 extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int32_t* problem_idx, const uint64_t* seeds,
@@ -300,12 +329,14 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     if (cfg->dim != s->dim) return fail(MBX_E_ARG, "cfg.dim %d != suite dim %d", cfg->dim, s->dim);
     for (int i = 0; i < n_instances; ++i)
         if (problem_idx[i] < 0 || problem_idx[i] >= s->n) return fail(MBX_E_ARG, "problem_idx[%d]=%d out of range", i, problem_idx[i]);
-    const size_t lds = (size_t)rl_lds_doubles(cfg->np, cfg->dim) * sizeof(double);
+    const AlgoGeom g = geom_of(*cfg);
+    const size_t lds = (size_t)g.lds_doubles * sizeof(double);
     if (lds > (size_t)max_lds_bytes())
         return fail(MBX_E_UNSUPPORTED, "np=%d dim=%d needs %zu B of LDS per workgroup (> %d)", cfg->np, cfg->dim, lds, max_lds_bytes());
     mbx_batch* b = new mbx_batch();
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
-    b->state_stride = (MBX_RLEPSO_STATE_DOUBLES(cfg->np, cfg->dim, cfg->n_logpoint) + 1) & ~(int64_t)1;
+    b->state_stride = (g.state_doubles + 1) & ~(int64_t)1;
+    b->sc_off = g.sc_off; b->tape_stride = g.tape_stride; b->state_dim = g.state_dim; b->action_dim = g.action_dim;
     HIP_TRY(hipMalloc(&b->d_problem_idx, n_instances * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&b->d_seeds, n_instances * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&b->d_state, (size_t)n_instances * b->state_stride * sizeof(double)));
@@ -313,10 +344,15 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     HIP_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d_state, 0, (size_t)n_instances * b->state_stride * sizeof(double)));
     hipLaunchKernelGGL(k_init_state, dim3((n_instances + 255) / 256), dim3(256), 0, nullptr, b->d_state, b->state_stride,
-                       MBX_RLEPSO_ST_SCALARS(cfg->np, cfg->dim), n_instances);
+                       g.sc_off, n_instances);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (cfg->algo == MBX_ALGO_RLEPSO) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     *out = b;
     return MBX_OK;
 }
@@ -341,7 +377,7 @@ static BatchParams make_params(const mbx_batch* b)
     BatchParams p;
     p.problems = b->suite->d_problems; p.problem_idx = b->d_problem_idx; p.seeds = b->d_seeds;
     p.state = b->d_state; p.state_stride = b->state_stride;
-    p.tape = b->d_tape; p.tape_stride = MBX_RLEPSO_TAPE_STRIDE(b->cfg.np, b->cfg.dim);
+    p.tape = b->d_tape; p.tape_stride = b->tape_stride;
     p.NP = b->cfg.np; p.D = b->cfg.dim; p.max_fes = b->cfg.max_fes; p.log_interval = b->cfg.log_interval;
     p.n_logpoint = b->cfg.n_logpoint; p.early_stop = b->cfg.early_stop; p.n_group = b->cfg.n_group; p.B = b->B;
     return p;
@@ -350,7 +386,12 @@ static BatchParams make_params(const mbx_batch* b)
 extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
 {
     if (!b) return fail(MBX_E_ARG, "null batch");
-    hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    if (b->cfg.algo == MBX_ALGO_RLEPSO)
+        hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    else {
+        if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: LDE needs d_state_out");
+        hipLaunchKernelGGL(k_lde_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    }
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }
@@ -359,8 +400,14 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
                         void* stream)
 {
     if (!b || !d_actions) return fail(MBX_E_ARG, "mbx_step: bad arguments");
-    hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                       (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+    if (b->cfg.algo == MBX_ALGO_RLEPSO)
+        hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+    else {
+        if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: LDE needs d_state_out");
+        hipLaunchKernelGGL(k_lde_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+    }
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }
@@ -370,7 +417,7 @@ extern "C" int mbx_results(mbx_batch* b, double* d_cost_curves, double* d_fes, d
 {
     if (!b) return fail(MBX_E_ARG, "null batch");
     hipLaunchKernelGGL(k_results, dim3((b->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->d_state, b->state_stride,
-                       MBX_RLEPSO_ST_SCALARS(b->cfg.np, b->cfg.dim), b->B, b->cfg.n_logpoint, d_cost_curves, d_fes, d_return,
+                       b->sc_off, b->B, b->cfg.n_logpoint, d_cost_curves, d_fes, d_return,
                        d_steps, d_cost_len);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
@@ -379,7 +426,7 @@ extern "C" int mbx_results(mbx_batch* b, double* d_cost_curves, double* d_fes, d
 extern "C" int64_t mbx_instance_state_doubles(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "null batch");
-    return MBX_RLEPSO_STATE_DOUBLES(b->cfg.np, b->cfg.dim, b->cfg.n_logpoint);
+    return geom_of(b->cfg).state_doubles;
 }
 
 extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out)
@@ -389,7 +436,7 @@ extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out
     const int64_t n = mbx_instance_state_doubles(b);
     HIP_TRY(hipMemcpy(host_out, b->d_state + (int64_t)instance * b->state_stride, n * sizeof(double), hipMemcpyDeviceToHost));
     // cost curve is reported padded with its last value, like mbx_results
-    double* sc = host_out + MBX_RLEPSO_ST_SCALARS(b->cfg.np, b->cfg.dim);
+    double* sc = host_out + b->sc_off;
     const int len = (int)sc[MBX_SC_COST_LEN];
     for (int k = len; k <= b->cfg.n_logpoint && len > 0; ++k) sc[MBX_NSCALAR + k] = sc[MBX_NSCALAR + len - 1];
     return MBX_OK;

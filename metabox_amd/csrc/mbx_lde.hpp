@@ -1,0 +1,269 @@
+// mbx_lde.hpp — fused LDE generation kernels for gfx950 (reference: src/optimizer/lde_optimizer.py:6-198).
+//
+// One workgroup owns one instance: DE/current-to-pbest/1 mutation with per-individual F and CR supplied by the
+// policy, binomial crossover, midpoint boundary repair, objective evaluation, selection, then the fitness-sorted
+// population and the [NP + 10] histogram feature vector (the LSTM policy's next input) are produced in the same
+// launch.  The population is kept sorted by fitness in HBM, which is what the reference's __order_by_f leaves
+// behind after every __get_feature.
+#pragma once
+#include "mbx_device.hpp"
+#include "mbx_rlepso.hpp"   // BatchParams, align2
+
+namespace mbx {
+
+struct LdeLds {
+    double *P, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *FIT, *NC, *SF, *CR, *ONEM, *SORTED, *RED, *HS;
+    int *PIDX, *R0, *R1, *JR, *HIST;
+    __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
+};
+
+__host__ __device__ inline int64_t lde_lds_doubles(int NP, int D)
+{
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+                  P = align2(NP), PI = align2((P + 1) / 2);
+    return 3 * NE + SC + 2 * DD + 4 * align2(D) + 6 * P + 16 + 8 + 4 * PI + 8;
+}
+
+__device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
+{
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+                  P = align2(NP), PI = align2((P + 1) / 2);
+    LdeLds L;
+    double* p = base;
+    L.P = p; p += NE;  L.X = p; p += NE;  L.T = p; p += NE;  L.Z = p; p += SC;
+    L.M1T = p; p += DD;  L.M2T = p; p += DD;
+    L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
+    L.FIT = p; p += P;  L.NC = p; p += P;  L.SF = p; p += P;  L.CR = p; p += P;  L.ONEM = p; p += P;  L.SORTED = p; p += P;
+    L.RED = p; p += 16;  L.HS = p; p += 8;
+    L.PIDX = (int*)p; p += PI;  L.R0 = (int*)p; p += PI;  L.R1 = (int*)p; p += PI;  L.JR = (int*)p; p += PI;
+    L.HIST = (int*)p;
+    return L;
+}
+
+// np.histogram(a, 5) bin of one value over uniform bins on [first, last] (numpy/lib/_histograms_impl.py)
+__device__ __forceinline__ int lde_hist_bin(double v, double first, double last)
+{
+    const int nb = MBX_LDE_BINS;
+    const double step = (last - first) / nb;
+    int idx = (int)((v - first) / (last - first) * nb);
+    if (idx == nb) idx -= 1;
+    const double lo = idx == nb ? last : first + idx * step;
+    if (v < lo) idx -= 1;
+    const double hi = idx + 1 == nb ? last : first + (idx + 1) * step;
+    if (v >= hi && idx != nb - 1) idx += 1;
+    return idx;
+}
+
+// __maxmin_norm + np.histogram of an ASCENDING fitness vector F[0..NP) (lde_optimizer.py:81-87,148-151):
+// NORM[i] = normalised fitness, HIST[0..5) = bin counts.  All threads call.
+__device__ __forceinline__ void lde_norm_hist(const double* F, int NP, double* NORM, int* HIST)
+{
+    const int tid = threadIdx.x;
+    if (tid < MBX_LDE_BINS) HIST[tid] = 0;
+    __syncthreads();
+    const double mn = F[0], mx = F[NP - 1];
+    double first = 0., last = mx != mn ? (mx - mn) / (mx - mn) : 0.;
+    if (first == last) { first -= 0.5; last += 0.5; }
+    for (int i = tid; i < NP; i += kThreads) {
+        const double v = mx != mn ? (F[i] - mn) / (mx - mn) : 0.;
+        if (NORM) NORM[i] = v;
+        atomicAdd(&HIST[lde_hist_bin(v, first, last)], 1);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lde_costs(const DevProblem& P, const LdeLds& L, int NP, const Rng& rng, const double* tape_noise,
+                                          uint32_t siteA, uint32_t siteB)
+{
+    eval_rows(P, L.eval(), NP);
+    for (int i = threadIdx.x; i < NP; i += kThreads) {
+        double f = L.NC[i];
+        if (P.noise_kind != MBX_NOISE_NONE) {
+            double a, b, c;
+            if (tape_noise) { a = tape_noise[i]; b = tape_noise[NP + i]; c = tape_noise[2 * NP + i]; }
+            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, b, c);
+            f = apply_noise(P, f, a, b, c);
+        }
+        L.NC[i] = isnan(P.optimum) ? f : f - P.optimum;
+    }
+    __syncthreads();
+}
+
+// __order_by_f (stable) + __get_feature (lde_optimizer.py:74-79,145-157): rows of L.P with fitness L.FIT are written
+// to HBM in ascending-fitness order and the [NP+10] state vector is emitted.  hs/hcount = past_histo sum / length.
+__device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, double* gPop, double* gFit, const double* hs,
+                                              double hcount, double* state_out)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NP; i += kThreads) {
+        const double fi = L.FIT[i];
+        int rank = 0;
+        for (int j = 0; j < NP; ++j) { const double fj = L.FIT[j]; rank += (fj < fi) || (fj == fi && j < i); }
+        L.PIDX[i] = rank;
+        L.SORTED[rank] = fi;
+        gFit[rank] = fi;
+    }
+    __syncthreads();
+    const int NE = NP * D;
+    for (int e = tid; e < NE; e += kThreads) {
+        const int i = e / D, d = e - i * D;
+        gPop[L.PIDX[i] * D + d] = L.P[e];
+    }
+    lde_norm_hist(L.SORTED, NP, state_out, L.HIST);
+    if (tid < MBX_LDE_BINS) {
+        state_out[NP + tid] = (double)L.HIST[tid];
+        state_out[NP + MBX_LDE_BINS + tid] = hs[tid] / hcount;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ reset
+__global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* __restrict__ state_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    const LdeLds L = lde_carve(smem, NP, D);
+    double* S = bp.state + (int64_t)b * bp.state_stride;
+    double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
+    const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
+    const int episode = (int)sc[MBX_SC_EPISODE] + 1;
+    const uint64_t seed = bp.seeds[b];
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, (uint32_t)episode};
+    const double lb = P.lb, ub = P.ub;
+    stage_problem(P, L.eval());
+    for (int e = tid; e < NE; e += kThreads) {                     // pop = lb + U * (ub - lb)   (:65-71,133)
+        double u;
+        if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
+        else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
+        const double x = lb + u * (ub - lb);
+        L.X[e] = x; L.P[e] = x;
+    }
+    __syncthreads();
+    lde_costs(P, L, NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    for (int i = tid; i < NP; i += kThreads) L.FIT[i] = L.NC[i];
+    if (tid < 8) { L.HS[tid] = tid < MBX_LDE_BINS ? (double)NP / MBX_LDE_BINS : 0.; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
+    double gb; int gi;
+    block_argmin(L.NC, NP, L.RED, gb, gi);
+    lde_sort_emit(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, 1., state_out + (int64_t)b * (NP + 10));
+    if (tid == 0) {
+        sc[MBX_SC_GBEST] = gb; sc[MBX_SC_FES] = NP; sc[MBX_SC_LOG_INDEX] = 1; sc[MBX_SC_COST_LEN] = 1;
+        sc[MBX_SC_DONE] = 0; sc[MBX_SC_RETURN] = 0; sc[MBX_SC_GEN] = 0; sc[MBX_SC_EPISODE] = episode; sc[MBX_SC_HCOUNT] = 1;
+        sc[MBX_NSCALAR] = gb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ step
+__global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const float* __restrict__ actions,
+                                                       double* __restrict__ state_out, double* __restrict__ reward_out,
+                                                       uint8_t* __restrict__ done_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    double* S = bp.state + (int64_t)b * bp.state_stride;
+    double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
+    if (sc[MBX_SC_DONE] != 0.) {                                  // finished: state_out keeps the last features
+        if (tid == 0) { if (reward_out) reward_out[b] = 0.; if (done_out) done_out[b] = 1; }
+        return;
+    }
+    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    const LdeLds L = lde_carve(smem, NP, D);
+    const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
+    const float* act = actions + (int64_t)b * (2 * NP);
+    const int gen = (int)sc[MBX_SC_GEN] + 1;
+    const uint64_t seed = bp.seeds[b];
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE]};
+    const double lb = P.lb, ub = P.ub;
+    double fes = sc[MBX_SC_FES];
+    const double hcount = sc[MBX_SC_HCOUNT];
+
+    const double* gPop = S + MBX_LDE_ST_POP(NP, D);
+    for (int e = tid; e < NE; e += kThreads) L.P[e] = gPop[e];
+    for (int i = tid; i < NP; i += kThreads) L.FIT[i] = S[MBX_LDE_ST_FIT(NP, D) + i];
+    if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
+    stage_problem(P, L.eval());
+    // p-best bound (:101-105): p = max(0, (P_MIN - P_INI) fes/maxFEs + P_INI), P_MIN = 2/NP, P_INI = 1
+    const double p_rate = (2. / NP - 1) * fes / bp.max_fes + 1;
+    const int bound = (int)ceil(NP * fmax(0., p_rate));
+    for (int i = tid; i < NP; i += kThreads) {
+        int pidx, r0, r1, jr;
+        if (tape) {
+            pidx = (int)tape[MBX_LDE_TAPE_PIDX(NP, D) + i]; r0 = (int)tape[MBX_LDE_TAPE_R0(NP, D) + i];
+            r1 = (int)tape[MBX_LDE_TAPE_R1(NP, D) + i]; jr = (int)tape[MBX_LDE_TAPE_JRAND(NP, D) + i];
+        } else {
+            const U4 w = rng.draw((uint32_t)i, MBX_SITE_LDE_PART);
+            pidx = (int)__umulhi(w.x, (uint32_t)bound);
+            r0 = (int)__umulhi(w.y, (uint32_t)(NP - 1)); if (r0 >= i) r0 += 1;
+            r1 = (int)__umulhi(w.z, (uint32_t)(NP - 2));
+            const int lo = i < r0 ? i : r0, hi = i < r0 ? r0 : i;
+            if (r1 >= lo) r1 += 1;
+            if (r1 >= hi) r1 += 1;
+            jr = (int)__umulhi(w.w, (uint32_t)D);
+        }
+        L.PIDX[i] = pidx; L.R0[i] = r0; L.R1[i] = r1; L.JR[i] = jr;
+        const float sf32 = act[i];
+        L.SF[i] = (double)sf32; L.ONEM[i] = (double)(1.f - sf32); L.CR[i] = (double)act[NP + i];
+    }
+    __syncthreads();
+    // histogram of the pre-update (sorted) fitness: appended to past_histo at :186
+    lde_norm_hist(L.FIT, NP, nullptr, L.HIST);
+    int my_hist = tid < MBX_LDE_BINS ? L.HIST[tid] : 0;
+
+    // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
+    for (int e = tid; e < NE; e += kThreads) {
+        const int i = e / D, d = e - i * D;
+        double u;
+        if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
+        else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
+        if (d == L.JR[i]) u = 0.;
+        const double xi = L.P[e], sf = L.SF[i], om = L.ONEM[i];
+        const int pidx = L.PIDX[i];
+        double m;
+        if (pidx == i) m = xi;
+        else if (pidx < i) m = sf * L.P[pidx * D + d] + om * xi;
+        else m = om * xi + sf * L.P[pidx * D + d];
+        m = m + sf * (L.P[L.R0[i] * D + d] - L.P[L.R1[i] * D + d]);
+        double c = u <= L.CR[i] ? m : xi;
+        if (c < lb) c = (xi + lb) / 2.;
+        else if (c > ub) c = (xi + ub) / 2.;
+        L.X[e] = c;
+    }
+    __syncthreads();
+    lde_costs(P, L, NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    fes += NP;
+
+    // ---- selection (:55-59): offspring survives when it is better than or equal to its parent
+    const double bsf = L.FIT[0];                                   // population is sorted: minimum first
+    for (int i = tid; i < NP; i += kThreads) {
+        const int surv = L.NC[i] <= L.FIT[i];
+        L.R0[i] = surv;
+        if (surv) L.FIT[i] = L.NC[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < NE; e += kThreads) if (L.R0[e / D]) L.P[e] = L.X[e];
+    double bsf_next; int bi;
+    block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
+    if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
+    __syncthreads();
+    lde_sort_emit(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, hcount + 1, state_out + (int64_t)b * (NP + 10));
+
+    if (tid == 0) {
+        const double reward = (bsf - bsf_next) / bsf;             // :170
+        bool done = fes >= bp.max_fes;
+        if (!isnan(P.optimum) && bp.early_stop) done = done || bsf_next <= 1e-8;
+        int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
+        double* cost = sc + MBX_NSCALAR;
+        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = bsf_next; }
+        if (done) {
+            if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = bsf_next;
+            else cost[cost_len++] = bsf_next;
+        }
+        sc[MBX_SC_GBEST] = bsf_next; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
+        sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += reward; sc[MBX_SC_GEN] = gen; sc[MBX_SC_HCOUNT] = hcount + 1;
+        if (reward_out) reward_out[b] = reward;
+        if (done_out) done_out[b] = done ? 1 : 0;
+    }
+}
+
+}  // namespace mbx

@@ -1,2 +1,3 @@
 from .learnable_optimizer import Learnable_Optimizer
 from .rlepso_optimizer import RLEPSO_Optimizer
+from .lde_optimizer import LDE_Optimizer

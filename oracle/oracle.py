@@ -199,3 +199,97 @@ class NumpyTapeFeeder:
         if not reinit_fired:
             self.rs.set_state(self._rewind)
         self._rewind = None
+
+
+# ======================================================================================== LDE
+def _lde_lib():
+    L = lib()
+    if not getattr(L, '_lde_ready', False):
+        L.orc_lde_new.restype = C.c_void_p
+        L.orc_lde_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_lde_free.argtypes = [C.c_void_p]
+        L.orc_lde_reset.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_lde_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), _dp, _dp, _dp]
+        L.orc_lde_state.argtypes = [C.c_void_p, _dp]
+        L._lde_ready = True
+    return L
+
+
+def lde_state_doubles(NP, D, nlog):
+    return NP * D + NP + 8 + 16 + nlog + 1
+
+
+def split_lde_state(st, NP, D, nlog):
+    o, out = 0, {}
+    for name, n in (('pop', NP * D), ('fit', NP), ('hsum', 8), ('scalars', NSCALAR), ('cost', nlog + 1)):
+        out[name] = st[o:o + n]
+        o += n
+    return out
+
+
+class LdeOracle:
+    """One LDE instance on the CPU (lde_optimizer.py restated in C)."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = _lde_lib().orc_lde_new(C.byref(self._st), float('nan') if optimum is None else float(optimum),
+                                         C.byref(cfg), int(seed))
+        self._state = np.empty(cfg.np + 10)
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            _lde_lib().orc_lde_free(self._h)
+            self._h = None
+
+    def reset(self, tape=None):
+        _lde_lib().orc_lde_reset(self._h, _p(tape) if tape is not None else None, _p(self._state))
+        return self._state.copy()
+
+    def step(self, action, tape=None):
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(-1)
+        out = np.empty(3)
+        _lde_lib().orc_lde_step(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), _p(tape) if tape is not None else None,
+                                _p(self._state), _p(out))
+        return self._state.copy(), out[0], bool(out[1])
+
+    def state(self):
+        out = np.empty(lde_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
+        _lde_lib().orc_lde_state(self._h, _p(out))
+        return out
+
+
+class LdeTapeFeeder:
+    """numpy legacy-stream draws of LDE_Optimizer in the reference's call order (init: uniform(NP,D), eval noise;
+    update: randint(0, ceil(NP*p), (1,NP)), uniform(1,NP,D), randint(0, D, [1,NP]), eval noise).  The torch.randint
+    indices r (after the rejection loop) come from the fixture."""
+
+    def __init__(self, seed, NP, D, noise_kind, max_fes):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise, self.max_fes = NP, D, noise_kind, max_fes
+        self.stride = 7 * NP + NP * D
+        self.fes = NP
+
+    def _noise(self):
+        return NumpyTapeFeeder._noise_rows(self)
+
+    def reset_tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        t[7 * NP:] = self.rs.uniform(size=(NP, D)).ravel()
+        t[4 * NP:7 * NP] = self._noise()
+        self.fes = NP
+        return t
+
+    def step_tape(self, r):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        p_rate = (2 / NP - 1) * self.fes / self.max_fes + 1
+        t[0:NP] = self.rs.randint(0, int(np.ceil(NP * max(0, p_rate))), size=(1, NP)).ravel()
+        t[NP:2 * NP] = r[:, 0]
+        t[2 * NP:3 * NP] = r[:, 1]
+        t[7 * NP:] = self.rs.uniform(size=(1, NP, D)).ravel()
+        t[3 * NP:4 * NP] = self.rs.randint(low=0, high=D, size=[1, NP]).ravel()
+        t[4 * NP:7 * NP] = self._noise()
+        self.fes += NP
+        return t

@@ -1,0 +1,153 @@
+"""GPU: the fused LDE generation kernel — tape replay against the reference's episodes, Philox parity with the
+oracle, and size-independent properties at a large batch."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, load, problems
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+NP = 50
+
+
+def _suite(suite, dim):
+    from metabox_amd.suite import Suite
+    ps = problems(suite, dim)
+    ids = sorted(ps)
+    return Suite([ps[i] for i in ids]), ids
+
+
+def test_lde_tape_replay_matches_reference_episodes():
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_LDE
+    TR = load('lde_traces.npz')
+    cases = [str(c) for c in TR['cases']]
+    groups = {}
+    for c in cases:
+        suite, dim = c.split('/')[:2]
+        groups.setdefault((suite, int(dim)), []).append(c)
+    for (suite, dim), mine in groups.items():
+        s, ids = _suite(suite, dim)
+        maxfes = 2000 * dim
+        pidx = [ids.index(int(c.split('/')[2])) for c in mine]
+        B = len(mine)
+        batch = Batch(s, ALGO_LDE, pidx, np.arange(B), NP, maxfes, maxfes // 50, 50)
+        assert batch.state_dim == NP + 10 and batch.action_dim == 2 * NP
+        feeders = [oracle.LdeTapeFeeder(int(c.split('/')[3]), NP, dim, s.problems[k].noise[0], maxfes) for c, k in zip(mine, pidx)]
+        acts = [TR[f'{c}/actions'] for c in mine]
+        rr = [TR[f'{c}/r'] for c in mine]
+        G = max(len(a) for a in acts)
+        tape = np.stack([f.reset_tape() for f in feeders])
+        batch.set_tape(torch.from_numpy(tape).cuda())
+        st0 = batch.reset().cpu().numpy()
+        for b, c in enumerate(mine):
+            assert np.abs(st0[b] - TR[f'{c}/state0']).max() <= 1e-9, c
+        gb = np.full((B, G), np.nan); fes = np.full((B, G), np.nan); rw = np.zeros((B, G)); dn = np.zeros((B, G), bool)
+        feats = [dict() for _ in range(B)]
+        alive = np.ones(B, bool)
+        sc_off = NP * dim + NP + 8
+        for g in range(G):
+            a = np.zeros((B, 2 * NP), np.float32)
+            for b in range(B):
+                if alive[b]:
+                    tape[b] = feeders[b].step_tape(rr[b][g])
+                    a[b] = acts[b][g]
+            batch.set_tape(torch.from_numpy(tape).cuda())
+            st, r, d = batch.step(torch.from_numpy(a).cuda())
+            torch.cuda.synchronize()
+            st = st.cpu().numpy(); r = r.cpu().numpy(); d = d.cpu().numpy()
+            for b in range(B):
+                if not alive[b]:
+                    continue
+                sc = batch.read_state(b)[sc_off:sc_off + 16]
+                gb[b, g] = sc[0]; fes[b, g] = sc[1]; rw[b, g] = r[b]; dn[b, g] = d[b]
+                feats[b][g] = st[b].copy()
+                if d[b]:
+                    alive[b] = False
+                    assert g == len(acts[b]) - 1, (mine[b], g)
+        assert not alive.any()
+        res = batch.results()
+        cost = res['cost'].cpu().numpy(); clen = res['cost_len'].cpu().numpy()
+        for b, c in enumerate(mine):
+            n = len(acts[b])
+            assert close(gb[b, :n], TR[f'{c}/gbest']), c
+            assert np.array_equal(fes[b, :n], TR[f'{c}/fes']), c
+            assert np.array_equal(dn[b, :n], TR[f'{c}/done']), c
+            ref_r = TR[f'{c}/reward']
+            assert np.all(np.abs(rw[b, :n] - ref_r) <= 1e-5 * np.abs(ref_r) + 1e-9), c
+            for row in TR[f'{c}/states']:
+                assert np.abs(feats[b][int(row[0])] - row[1:]).max() <= 1e-5, (c, int(row[0]))
+            ref_cost = TR[f'{c}/cost']
+            assert clen[b] == len(ref_cost) and close(cost[b, :clen[b]], ref_cost), c
+            fin = oracle.split_lde_state(batch.read_state(b), NP, dim, 50)
+            assert np.abs(fin['pop'].reshape(NP, dim) - TR[f'{c}/final_pop']).max() <= 1e-9, c
+        batch.close()
+
+
+@pytest.mark.parametrize('suite,dim', [('bbob', 10), ('bbob-noisy', 30)])
+def test_lde_philox_parity_with_oracle(suite, dim):
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_LDE
+    s, ids = _suite(suite, dim)
+    B, G = len(ids), 30
+    maxfes = 2000 * dim
+    rs = np.random.RandomState(5)
+    actions = rs.uniform(0, 1, size=(G, B, 2 * NP)).astype(np.float32)
+    seeds = np.arange(B, dtype=np.uint64) * 104729 + 3
+    batch = Batch(s, ALGO_LDE, np.arange(B), seeds, NP, maxfes, maxfes // 50, 50)
+    st0 = batch.reset().cpu().numpy().copy()
+    hist = []
+    for g in range(G):
+        st, r, d = batch.step(torch.from_numpy(actions[g]).cuda())
+        hist.append((st.cpu().numpy().copy(), r.cpu().numpy().copy()))
+    cfg = oracle.make_cfg(2, NP, dim, maxfes, maxfes // 50, 50)
+    for b in range(B):
+        p = s.problems[b]
+        o = oracle.LdeOracle(p.desc(), p.bias, cfg, seed=int(seeds[b]))
+        f0 = o.reset()
+        assert np.abs(f0 - st0[b]).max() <= 1e-7, ids[b]
+        for g in range(G):
+            f, rew, d = o.step(actions[g, b])
+            assert np.abs(f - hist[g][0][b]).max() <= 1e-5, (ids[b], g)
+            assert abs(rew - hist[g][1][b]) <= 1e-5 * abs(rew) + 1e-9, (ids[b], g)
+        want = oracle.split_lde_state(o.state(), NP, dim, 50)
+        got = oracle.split_lde_state(batch.read_state(b), NP, dim, 50)
+        assert close(got['fit'], want['fit']), ids[b]
+        assert np.abs(got['pop'] - want['pop']).max() <= 1e-9, ids[b]
+        assert np.array_equal(got['hsum'], want['hsum'])
+    batch.close()
+
+
+def test_lde_large_batch_properties():
+    """16384 instances (BASELINE.json config 3 size) on bbob-noisy d=30: deterministic, shard-independent, sorted."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_LDE
+    s, ids = _suite('bbob-noisy', 30)
+    B = 16384
+    pidx = np.arange(B) % len(ids)
+    seeds = np.arange(B, dtype=np.uint64) + 99
+    act = torch.rand(B, 2 * NP, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def run(sel):
+        b = Batch(s, ALGO_LDE, pidx[sel], seeds[sel], NP, 60000, 1200, 50)
+        b.reset()
+        for _ in range(6):
+            st, _, _ = b.step(act[sel].contiguous())
+        out = {k: v.cpu().numpy() for k, v in b.results().items()}
+        out['state'] = st.cpu().numpy().copy()
+        fit0 = oracle.split_lde_state(b.read_state(0), NP, 30, 50)['fit']
+        b.close()
+        return out, fit0
+    full, fit0 = run(np.arange(B))
+    again, _ = run(np.arange(B))
+    for k in full:
+        assert np.array_equal(full[k], again[k], equal_nan=True), k
+    part, _ = run(np.arange(B)[::4])
+    for k in full:
+        assert np.array_equal(full[k][::4], part[k], equal_nan=True), k
+    assert np.all(np.diff(fit0) >= 0)                                  # population kept sorted by fitness
+    st = full['state']
+    assert np.all(st[:, 0] == 0) and np.all((st[:, NP - 1] == 1) | (st[:, NP - 1] == 0))   # min-max normalised
+    assert np.all(st[:, NP:NP + 5].sum(1) == NP)                       # histogram counts every individual
+    assert np.all(full['fes'] == NP * 7)

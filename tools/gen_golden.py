@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it writes are data
 (inputs + expected outputs), never reference source.  Re-run: `python tools/gen_golden.py [section ...]`
-with sections in {instances, kat, noise, policy, rlepso}.
+with sections in {instances, kat, noise, policy, rlepso, lde}.
 
 What is recorded
   instances : per (suite, dim) the problem names, biases, optima, a sha256 over every constructor-made
@@ -215,7 +215,123 @@ def gen_rlepso():
     print('rlepso:', len(cases), 'episodes')
 
 
-SECTIONS = {'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def _final_r(calls, NP):
+    """Re-apply the rejection loop of LDE_Optimizer.__add_random (lde_optimizer.py:109-121) to the recorded
+    torch.randint outputs of one update() call -> the indices r[NP,2] that were finally used."""
+    r = calls[0].clone()
+    k = 1
+    pop_index = torch.arange(NP)
+    for col in range(2):
+        while True:
+            rep = [torch.eq(r[:, :, col], r[:, :, i]) for i in range(col)]
+            rep.append(torch.eq(r[:, :, col], pop_index))
+            idx = torch.nonzero(torch.any(torch.stack(rep), dim=0))
+            if idx.size(0) != 0:
+                r[idx[:, 0], idx[:, 1], col] = calls[k]
+                k += 1
+            else:
+                break
+    assert k == len(calls)
+    return r[0].numpy().astype(np.uint8)
+
+
+def run_lde_episode(problem, seed, agent, config, action_mode):
+    from optimizer import LDE_Optimizer
+    from environment import PBO_Env
+    import copy
+    opt = LDE_Optimizer(copy.deepcopy(config))
+    env = PBO_Env(problem, opt)
+    net = agent._LDE_Agent__net
+    NP = 50
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ars = np.random.RandomState(20_000 + seed)
+    state = env.reset()
+    state0 = np.array(state[0])
+    h = torch.zeros(1, 1, 50)
+    c = torch.zeros(1, 1, 50)
+    real_randint = torch.randint
+    rec = dict(actions=[], r=[], gbest=[], fes=[], reward=[], done=[], states=[])
+    done = False
+    g = 0
+    while not done:
+        if action_mode == 'actor':
+            with torch.no_grad():
+                a, h, c = net.sampler(torch.FloatTensor(state[None, :]), h, c)
+            action = np.squeeze(a.reshape(1, 1, -1).cpu().numpy(), axis=0)
+        else:
+            action = ars.uniform(0, 1, size=(1, 2 * NP)).astype(np.float32)
+        calls = []
+
+        def spy(*a_, **k_):
+            out = real_randint(*a_, **k_)
+            calls.append(out.clone())
+            return out
+        torch.randint = spy
+        try:
+            state, r, done = env.step(action)
+        finally:
+            torch.randint = real_randint
+        rec['actions'].append(action[0].astype(np.float32))
+        rec['r'].append(_final_r(calls, NP))
+        rec['gbest'].append(float(opt.gbest_cost))
+        rec['fes'].append(float(opt.fes))
+        rec['reward'].append(float(np.asarray(r).reshape(-1)[0]))
+        rec['done'].append(bool(done))
+        if g % 40 == 0 or done:
+            rec['states'].append(np.concatenate([[g], np.asarray(state[0], dtype=np.float64)]))
+        g += 1
+    out = {k: np.stack(v) if k in ('actions', 'r', 'states') else np.array(v) for k, v in rec.items()}
+    out['cost'] = np.array(opt.cost, dtype=np.float64)
+    out['state0'] = state0
+    out['final_fit'] = np.array(opt._LDE_Optimizer__fit[0])
+    out['final_pop'] = np.array(opt._LDE_Optimizer__pop[0])
+    return out
+
+
+def gen_lde():
+    scratch = tempfile.mkdtemp()
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/LDE_Agent.pkl'))
+    net = agent._LDE_Agent__net
+    pol = {}
+    for k, v in net.state_dict().items():
+        pol['net/' + k] = v.detach().cpu().numpy()
+    torch.manual_seed(0)
+    x = torch.rand(1, 8, 60)
+    h = torch.randn(1, 8, 50) * 0.3
+    c = torch.randn(1, 8, 50) * 0.3
+    with torch.no_grad():
+        mu, sg, h2, c2 = net.forward(x, h, c)
+    pol.update({'io/x': x.numpy(), 'io/h': h.numpy(), 'io/c': c.numpy(), 'io/mu': mu.numpy(), 'io/sigma': sg.numpy(),
+                'io/h_out': h2.numpy(), 'io/c_out': c2.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'lde_policy.npz'), **pol)
+    pkg = os.path.join(os.path.dirname(HERE), 'metabox_amd', 'agent_model')
+    np.savez_compressed(os.path.join(pkg, 'lde_bbob_easy.npz'), **{k: v for k, v in pol.items() if k.startswith('net/')})
+    data, cases = {}, []
+    for suite, dim, fids, seeds, mode in (
+            ('bbob', 10, (1, 5, 3, 16, 21), (0,), 'actor'),
+            ('bbob', 10, (8,), (1,), 'uniform'),
+            ('bbob-noisy', 10, (101, 117, 124), (0,), 'actor'),
+            ('bbob-noisy', 30, (102,), (2,), 'actor')):
+        config = ref_import.ref_config(['--problem', suite, '--dim', str(dim)], scratch)
+        tr, te, _ = all_problems(suite, dim)
+        byid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            for seed in seeds:
+                p = byid[fid]
+                p.reset()
+                rec = run_lde_episode(p, seed, agent, config, mode)
+                key = f'{suite}/{dim}/{fid}/{seed}/{mode}'
+                cases.append(key)
+                for k, v in rec.items():
+                    data[f'{key}/{k}'] = v
+                print(f'{key}: gens={len(rec["gbest"])} fes={rec["fes"][-1]:.0f} final={rec["gbest"][-1]:.6g}')
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'lde_traces.npz'), **data)
+    print('lde:', len(cases), 'episodes')
+
+
+SECTIONS = {'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
