@@ -65,7 +65,7 @@ typedef struct mbx_problem_desc {
     const double* v2;
     const double* py;     /* Gallagher peaks  [n_peaks,dim]; protein: basis/sqrt(eigval) [dim,3*n] */
     const double* pc;     /* Gallagher C      [n_peaks,dim]; protein: coor_init [n,3]            */
-    const double* pw;     /* Gallagher w      [n_peaks];     protein: q|sqrt(e)|r  [3,n,n]       */
+    const double* pw;     /* Gallagher w      [n_peaks];     protein: sqrt(e)|q|r  [3,n,n]       */
 } mbx_problem_desc;
 
 typedef struct mbx_suite mbx_suite;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void k_eval(const DevProblem* problems, i
     const int D = P.dim, tid = threadIdx.x;
     const int row0 = blockIdx.x * rows;
     const int m = min(rows, n - row0);
-    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D);
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D);
     const int64_t DV = align2(D);
     double* X = smem;
     double* T = X + NE;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void k_eval(const DevProblem* problems, i
 
 static size_t eval_lds_bytes(int rows, int D)
 {
-    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D);
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D);
     return (size_t)(2 * NE + SC + 2 * DD + 4 * align2(D) + align2(rows)) * sizeof(double);
 }
 
@@ -202,9 +202,11 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
     for (int i = 0; i < n_problems; ++i) {
         const mbx_problem_desc& d = descs[i];
         if (d.dim != D) return fail(MBX_E_ARG, "problem %d has dim %d, suite dim is %d", i, d.dim, D);
-        const bool bbob = d.kind >= 1 && d.kind <= 24;
-        if (!bbob) return fail(MBX_E_UNSUPPORTED, "problem %d: objective kind %d is not implemented", i, d.kind);
-        if (!d.dshift || !d.m1) return fail(MBX_E_ARG, "problem %d: dshift/m1 missing", i);
+        const bool bbob = d.kind >= 1 && d.kind <= 24, protein = d.kind == MBX_KIND_PROTEIN;
+        if (!bbob && !protein) return fail(MBX_E_UNSUPPORTED, "problem %d: objective kind %d is not implemented", i, d.kind);
+        if (bbob && (!d.dshift || !d.m1)) return fail(MBX_E_ARG, "problem %d: dshift/m1 missing", i);
+        if (protein && (!d.v0 || !d.py || !d.pc || !d.pw || d.n_peaks < 2 || d.n_peaks > 160))
+            return fail(MBX_E_ARG, "problem %d: protein tables missing (v0, py, pc, pw) or n_atoms outside [2,160]", i);
         if ((d.kind == 21 || d.kind == 22) && (!d.py || !d.pc || !d.pw || d.n_peaks <= 0))
             return fail(MBX_E_ARG, "problem %d: Gallagher tables missing", i);
         DevProblem& p = hp[i];
@@ -213,23 +215,26 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
         p.bias = d.bias; p.lb = d.lb; p.ub = d.ub; p.pen_coef = d.pen_coef;
         for (int k = 0; k < 4; ++k) p.s[k] = d.s[k];
         p.noise_a = d.noise_a; p.noise_b = d.noise_b; p.optimum = NAN;
-        const size_t DD = (size_t)D * D, PK = (size_t)d.n_peaks * D;
+        const size_t DD = (size_t)D * D, NA = (size_t)d.n_peaks;
+        const size_t PK = protein ? 3 * NA * D : NA * D;                // basis [D,3n]   | Gallagher y [n_peaks,D]
+        const size_t PC = protein ? 3 * NA : NA * D;                    // coor_init [3n] | Gallagher C
+        const size_t PW = protein ? 3 * NA * NA : NA;                   // sqrt(e)|q|r    | Gallagher w
         Off& o = offs[i];
         o.o[0] = push(d.dshift, D); o.o[1] = push(d.m1, DD); o.o[2] = push(d.m2, DD);
         o.o[3] = push(d.v0, D); o.o[4] = push(d.v1, D); o.o[5] = push(d.v2, D);
-        o.o[6] = push(d.py, PK); o.o[7] = push(d.pc, PK); o.o[8] = push(d.pw, d.n_peaks);
+        o.o[6] = push(d.py, PK); o.o[7] = push(d.pc, PC); o.o[8] = push(d.pw, PW);
         o.o[9] = -1;
         if (d.kind == 21 || d.kind == 22) {
             // R y_k for every peak: z_k = R (x - y_k) = R x - R y_k lets the kernel rotate x once per row
             // instead of once per (row, peak) pair (10x fewer flops at D = 10); rounding differs by O(ulp |R x|).
-            std::vector<double> ry(PK);
+            std::vector<double> ry(NA * D);
             for (int k = 0; k < d.n_peaks; ++k)
                 for (int r = 0; r < D; ++r) {
                     double acc = 0.;
                     for (int j = 0; j < D; ++j) acc += d.m1[(size_t)r * D + j] * d.py[(size_t)k * D + j];
                     ry[(size_t)k * D + r] = acc;
                 }
-            o.o[9] = push(ry.data(), PK);
+            o.o[9] = push(ry.data(), NA * D);
         }
     }
     mbx_suite* s = new mbx_suite();

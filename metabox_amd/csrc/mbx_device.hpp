@@ -192,7 +192,7 @@ __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds
         if (P.m2) L.M2T[k * D + d] = P.m2[t];
     }
     for (int d = threadIdx.x; d < D; d += kThreads) {
-        L.DSH[d] = P.dshift[d];
+        L.DSH[d] = P.dshift ? P.dshift[d] : 0.;
         L.V0[d] = P.v0 ? P.v0[d] : 0.;
         L.V1[d] = P.v1 ? P.v1[d] : 0.;
         L.V2[d] = P.v2 ? P.v2[d] : 0.;
@@ -214,6 +214,62 @@ __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, 
     }
 }
 
+// sum of v over the block (all threads call; result to every thread).  red: >= 8 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
+
+// Protein-docking energy (src/problem/protein_docking.py:28-48) of n individuals X[n][D] -> F[n].  The individuals
+// are processed one after the other; for each, the 3n displaced coordinates are built cooperatively in LDS, then the
+// n^2 atom pairs are spread over the block (pair index == address in the [n,n] tables: coalesced L2 reads) and the
+// energy mean_j sum_i term_ij = (sum of all terms)/n is reduced with wave shuffles.
+// P.v0 = 1/sqrt(eigval), P.py = basis [D,3n], P.pc = coor_init [3n], P.pw = sqrt(e) | q | r tables.
+__device__ void eval_rows_protein(const DevProblem& P, const EvalLds& L, int n_rows)
+{
+    const int D = P.dim, n = P.n_peaks, m3 = 3 * n, tid = threadIdx.x;
+    double* COOR = L.Z;
+    double* P2 = L.Z + ((m3 + 1) & ~1);
+    double* RED = P2 + ((n + 1) & ~1);
+    const double* __restrict__ se = P.pw;
+    const double* __restrict__ qm = P.pw + (size_t)n * n;
+    const double* __restrict__ rm = P.pw + 2 * (size_t)n * n;
+    for (int r = 0; r < n_rows; ++r) {
+        const double* x = L.X + r * D;
+        for (int m = tid; m < m3; m += kThreads) {
+            double s = 0.;
+            for (int k = 0; k < D; ++k) s += (x[k] * L.V0[k]) * P.py[(size_t)k * m3 + m];
+            COOR[m] = s + P.pc[m];
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += kThreads)
+            P2[i] = COOR[3 * i] * COOR[3 * i] + COOR[3 * i + 1] * COOR[3 * i + 1] + COOR[3 * i + 2] * COOR[3 * i + 2];
+        __syncthreads();
+        double acc = 0.;
+        for (int w = tid; w < n * n; w += kThreads) {
+            const int i = w / n, j = w - i * n;
+            const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
+            double pd = sqrt(P2[i] - 2 * p3 + P2[j] + 0.01);
+            const double m1 = (pd > 0.11 && pd < 7.0) ? 1. : 0., m2 = (pd > 7.0 && pd < 9.0) ? 1. : 0.;
+            if (i == j) pd += 1.;
+            const double rr = rm[w] / pd;
+            const double r2 = rr * rr, r6 = r2 * r2 * r2;
+            const double coeff = qm[w] / (4. * pd) + se[w] * (r6 * r6 - r6);
+            acc += 10 * m1 * coeff + 10 * m2 * coeff * ((9 - pd) * (9 - pd) * (-12 + 2 * pd) / 8);
+        }
+        const double total = block_sum(acc, RED);
+        if (tid == 0) L.F[r] = total / n;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block-cooperative objective: F[i] = func(X[i,:]) for i < n, bias and boundary penalty included
 // (the value F*.func returns).  All arrays of `L` live in LDS; stage_problem() must have been called.
@@ -221,6 +277,7 @@ __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, 
 // ------------------------------------------------------------------------------------------------
 __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
 {
+    if (P.kind == MBX_KIND_PROTEIN) { eval_rows_protein(P, L, n); return; }
     const int D = P.dim, NE = n * D, kind = P.kind, tid = threadIdx.x;
     const double ub = P.ub, bias = P.bias;
     const double* X = L.X;

@@ -19,14 +19,14 @@ struct LdeLds {
 
 __host__ __device__ inline int64_t lde_lds_doubles(int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP), PI = align2((P + 1) / 2);
     return 3 * NE + SC + 2 * DD + 4 * align2(D) + 6 * P + 16 + 8 + 4 * PI + 8;
 }
 
 __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP), PI = align2((P + 1) / 2);
     LdeLds L;
     double* p = base;

@@ -34,7 +34,7 @@ __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_
 
 __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP);
     // PB, X, T: NE each; Z: SC; M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each;
     // COEF: 6*16; RED: 16; 3 int arrays
@@ -43,7 +43,7 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > kThreads ? NE : kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP);
     RlLds L;
     double* p = base;

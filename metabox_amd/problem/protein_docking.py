@@ -1,0 +1,128 @@
+"""Protein-docking problems (280 instances: 28 complexes x 10 ZDOCK starting models) — host side.
+
+Reference: src/problem/protein_docking.py:9-48 (energy), :121-208 (dataset).  The energy of a 12-dimensional
+normal-mode displacement x is the mean over atoms j of the sum over atoms i of a switched Coulomb + Lennard-Jones
+term between the displaced interface atoms; it is evaluated on the GPU (kind MBX_KIND_PROTEIN).  The input tensors
+ship packed in ``protein_docking_data.npz`` (tools/pack_protein.py).
+"""
+import os
+
+import numpy as np
+
+from .basic_problem import Basic_Problem
+
+MBX_KIND_PROTEIN = 100
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'protein_docking_data.npz')
+
+
+class Protein_Docking(Basic_Problem):
+    n_atoms = 100     # interface atoms considered
+    dim = 12
+    lb = -1.5
+    ub = 1.5
+
+    def __init__(self, coor_init, q, e, r, basis, eigval, problem_id):
+        self.coor_init = coor_init      # [n_atoms, 3]
+        self.q = q                      # [n_atoms, n_atoms]  q_i q_j
+        self.e = e                      # [n_atoms, n_atoms]  sqrt(e_i e_j)
+        self.r = r                      # [n_atoms, n_atoms]  (r_i + r_j) / 2
+        self.basis = basis              # [dim, 3*n_atoms]
+        self.eigval = eigval            # [dim]
+        self.problem_id = problem_id
+        self.optimum = None             # unknown
+        self.opt = None
+        self.T1 = 0
+        self._suite = None
+        self._suite_index = None
+
+    def __str__(self):
+        return self.problem_id
+
+    def desc(self):
+        n = self.n_atoms
+        # the kernel needs q_i q_j, sqrt(e_ij) and r_ij per atom pair: the three [n, n] tables, sqrt pre-applied
+        # exactly as func() does on every call (protein_docking.py:41)
+        pw = np.concatenate([np.sqrt(self.e).ravel(), np.ascontiguousarray(self.q).ravel(),
+                             np.ascontiguousarray(self.r).ravel()])          # sqrt(e) | q | r  (include/mbx.h)
+        return dict(func_id=0, kind=MBX_KIND_PROTEIN, dim=self.dim, n_peaks=n, bias=0.0, lb=float(self.lb), ub=float(self.ub),
+                    pen_coef=0.0, s=[0.0, 0.0, 0.0, 0.0], noise_kind=0, noise_a=0.0, noise_b=0.0,
+                    dshift=np.zeros(self.dim), m1=None, m2=None,
+                    v0=1.0 / np.sqrt(self.eigval), v1=None, v2=None,
+                    py=np.ascontiguousarray(self.basis, dtype=np.float64),
+                    pc=np.ascontiguousarray(self.coor_init, dtype=np.float64).ravel(),
+                    pw=pw)
+
+    def _bound_suite(self):
+        if self._suite is None:
+            from ..suite import Suite
+            Suite([self])
+        return self._suite
+
+    def func(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        return self._bound_suite().eval(self._suite_index, x, noisy=False)
+
+
+class Protein_Docking_Dataset:
+    proteins_set = {'rigid': ['1AVX', '1BJ1', '1BVN', '1CGI', '1DFJ', '1EAW', '1EWY', '1EZU', '1IQD', '1JPS',
+                              '1KXQ', '1MAH', '1N8O', '1PPE', '1R0R', '2B42', '2I25', '2JEL', '7CEI', '1AY7'],
+                    'medium': ['1GRN', '1IJK', '1M10', '1XQS', '2HRK'],
+                    'difficult': ['1ATN', '1IBR', '2C0L']}
+    n_start_points = 10      # top models from ZDOCK
+
+    def __init__(self, data, batch_size=1):
+        self.data = data
+        self.batch_size = batch_size
+        self.N = len(self.data)
+        self.ptr = list(range(0, self.N, batch_size))
+        self.index = np.arange(self.N)
+
+    @staticmethod
+    def get_datasets(version, train_batch_size=1, test_batch_size=1, difficulty='easy', dataset_seed=1035, data_file=None):
+        if version not in ('protein',):
+            raise ValueError(f'{version} version is invalid or is not supported yet.')
+        if difficulty == 'easy':
+            ratio = 0.75
+        elif difficulty == 'difficult':
+            ratio = 0.25
+        else:
+            raise ValueError
+        if dataset_seed > 0:
+            np.random.seed(dataset_seed)
+        train_ids, test_ids = [], []
+        for key in Protein_Docking_Dataset.proteins_set.keys():          # per-category split (protein_docking.py:146-160)
+            perm = np.random.permutation(Protein_Docking_Dataset.proteins_set[key])
+            n_train = max(1, min(int(len(perm) * ratio), len(perm) - 1))
+            train_ids.extend(perm[:n_train])
+            test_ids.extend(perm[n_train:])
+        pack = np.load(data_file or _DATA)
+        row = {pid: k for k, pid in enumerate(pack['ids'])}
+        data = []
+        for prot in train_ids + test_ids:
+            for j in range(Protein_Docking_Dataset.n_start_points):
+                pid = f'{prot}_{j + 1}'
+                k = row[pid]
+                q = np.tile(pack['q'][k], (1, 1))
+                e = np.tile(pack['e'][k], (1, 1))
+                r = np.tile(pack['r'][k], (len(pack['r'][k]), 1))
+                q = np.matmul(q.T, q)                                    # :175-181
+                e = np.sqrt(np.matmul(e.T, e))
+                r = (r + r.T) / 2
+                data.append(Protein_Docking(pack['coor_init'][k], q, e, r, pack['basis'][k], pack['eigval'][k], pid))
+        n_train = len(train_ids) * Protein_Docking_Dataset.n_start_points
+        return Protein_Docking_Dataset(data[:n_train], train_batch_size), Protein_Docking_Dataset(data[n_train:], test_batch_size)
+
+    def __getitem__(self, item):
+        if self.batch_size < 2:
+            return self.data[self.index[item]]
+        lo = self.ptr[item]
+        return [self.data[j] for j in self.index[lo: min(lo + self.batch_size, self.N)]]
+
+    def __len__(self):
+        return self.N
+
+    def __add__(self, other):
+        return Protein_Docking_Dataset(self.data + other.data, self.batch_size)
+
+    def shuffle(self):
+        self.index = np.random.permutation(self.N)

@@ -1,0 +1,134 @@
+"""Protein docking: dataset split, oracle energy vs the reference's KATs (CPU); HIP energy, RLEPSO and LDE episodes on
+protein problems replayed against the reference (GPU)."""
+import functools
+
+import numpy as np
+import pytest
+
+from helpers import close, load
+from oracle import oracle
+
+KAT = load('protein_kat.npz')
+TR = load('protein_traces.npz')
+
+
+@functools.lru_cache(maxsize=None)
+def protein():
+    from metabox_amd.problem.protein_docking import Protein_Docking_Dataset
+    tr, te = Protein_Docking_Dataset.get_datasets('protein', difficulty='easy')
+    nxt = float(np.random.rand())
+    return {str(p): p for p in tr.data + te.data}, [str(p) for p in tr.data], [str(p) for p in te.data], nxt
+
+
+def test_dataset_split_matches_reference():
+    byid, tr, te, nxt = protein()
+    assert tr == [str(x) for x in KAT['train_ids']] and te == [str(x) for x in KAT['test_ids']]
+    assert nxt == float(KAT['next_rand'])
+    assert len(tr) == 200 and len(te) == 80
+    p = byid['1AVX_1']
+    assert (p.dim, p.lb, p.ub, p.optimum, p.n_atoms) == (12, -1.5, 1.5, None, 100)
+    assert p.q.shape == (100, 100) and p.basis.shape == (12, 300)
+
+
+def test_oracle_energy_matches_reference():
+    byid = protein()[0]
+    for key in [k for k in KAT.files if k.startswith('f/')]:
+        f = oracle.evaluate(byid[key[2:]].desc(), KAT['x'])
+        assert np.all(np.abs(f - KAT[key]) <= 1e-10 * np.abs(KAT[key])), key
+
+
+def _replay_rlepso_oracle(case):
+    _, pid, seed = case.split('/')
+    p = protein()[0][pid]
+    cfg = oracle.make_cfg(1, 100, 12, 1000, 200, 5)
+    o = oracle.RlepsoOracle(p.desc(), None, cfg)
+    fd = oracle.NumpyTapeFeeder(int(seed), 100, 12, 0)
+    o.reset(fd.reset_tape())
+    rows = []
+    for a in TR[f'{case}/actions']:
+        s, r, d = o.step(a, fd.step_tape())
+        sc = oracle.split_rlepso_state(o.state(), 100, 12, 5)['scalars']
+        fd.commit(sc[oracle.SC_REINIT] > 0)
+        rows.append((sc[0], sc[1], r, d))
+    return np.array(rows), oracle.split_rlepso_state(o.state(), 100, 12, 5)
+
+
+@pytest.mark.parametrize('case', [str(c) for c in TR['cases'] if str(c).startswith('rlepso')])
+def test_oracle_rlepso_on_protein(case):
+    rows, st = _replay_rlepso_oracle(case)
+    assert close(rows[:, 0], TR[f'{case}/gbest'], rtol=1e-9)
+    assert np.array_equal(rows[:, 1], TR[f'{case}/fes']) and np.array_equal(rows[:, 3].astype(bool), TR[f'{case}/done'])
+    n = int(st['scalars'][3])
+    assert n == len(TR[f'{case}/cost']) == 6 and close(st['cost'][:n], TR[f'{case}/cost'], rtol=1e-9)   # n_logpoint = 5
+
+
+@pytest.mark.parametrize('case', [str(c) for c in TR['cases'] if str(c).startswith('lde')])
+def test_oracle_lde_on_protein(case):
+    _, pid, seed = case.split('/')
+    p = protein()[0][pid]
+    cfg = oracle.make_cfg(2, 50, 12, 1000, 200, 5)
+    o = oracle.LdeOracle(p.desc(), None, cfg)
+    fd = oracle.LdeTapeFeeder(int(seed), 50, 12, 0, 1000)
+    s0 = o.reset(fd.reset_tape())
+    assert np.abs(s0 - TR[f'{case}/state0']).max() <= 1e-9
+    for g, (a, r) in enumerate(zip(TR[f'{case}/actions'], TR[f'{case}/r'])):
+        s, rew, d = o.step(a, fd.step_tape(r))
+        assert abs(oracle.split_lde_state(o.state(), 50, 12, 5)['scalars'][0] - TR[f'{case}/gbest'][g]) <= 1e-9 * abs(TR[f'{case}/gbest'][g])
+        assert d == TR[f'{case}/done'][g]
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_energy_matches_reference_and_oracle():
+    from metabox_amd.suite import Suite
+    byid = protein()[0]
+    keys = [k[2:] for k in KAT.files if k.startswith('f/')]
+    s = Suite([byid[k] for k in keys])
+    assert s.optimum(0) is None and byid[keys[0]].optimum is None
+    X = np.random.RandomState(1).uniform(-1.5, 1.5, size=(130, 12))          # more than one block of rows
+    for k, pid in enumerate(keys):
+        f = s.eval(k, KAT['x'])
+        assert np.all(np.abs(f - KAT[f'f/{pid}']) <= 1e-9 * np.abs(KAT[f'f/{pid}'])), pid
+        g = oracle.evaluate(byid[pid].desc(), X)
+        assert np.all(np.abs(s.eval(k, X) - g) <= 1e-9 * np.abs(g)), pid
+    p = byid[keys[0]]
+    assert np.ndim(p.eval(KAT['x'][0])) == 0 and p.eval(KAT['x']).shape == (12,)
+
+
+@pytest.mark.gpu
+def test_hip_rlepso_and_lde_on_protein_replay_reference():
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_LDE, ALGO_RLEPSO
+    byid = protein()[0]
+    cases = [str(c) for c in TR['cases']]
+    pids = sorted({c.split('/')[1] for c in cases})
+    s = Suite([byid[p] for p in pids])
+    for c in cases:
+        algo, pid, seed = c.split('/')
+        k = pids.index(pid)
+        acts = TR[f'{c}/actions']
+        if algo == 'rlepso':
+            b = Batch(s, ALGO_RLEPSO, [k], [0], 100, 1000, 200, 5)
+            fd = oracle.NumpyTapeFeeder(int(seed), 100, 12, 0)
+            sc_off = 3 * 100 * 12 + 3 * 100 + 12
+        else:
+            b = Batch(s, ALGO_LDE, [k], [0], 50, 1000, 200, 5)
+            fd = oracle.LdeTapeFeeder(int(seed), 50, 12, 0, 1000)
+            sc_off = 50 * 12 + 50 + 8
+        b.set_tape(torch.from_numpy(fd.reset_tape()[None]).cuda())
+        b.reset()
+        for g, a in enumerate(acts):
+            tape = fd.step_tape() if algo == 'rlepso' else fd.step_tape(TR[f'{c}/r'][g])
+            b.set_tape(torch.from_numpy(tape[None]).cuda())
+            st, r, d = b.step(torch.from_numpy(a[None].astype(np.float32)).cuda())
+            sc = b.read_state(0)[sc_off:sc_off + 16]
+            if algo == 'rlepso':
+                fd.commit(sc[oracle.SC_REINIT] > 0)
+            assert close(sc[0], TR[f'{c}/gbest'][g]), (c, g)
+            assert sc[1] == TR[f'{c}/fes'][g] and bool(d[0].item()) == bool(TR[f'{c}/done'][g]), (c, g)
+        res = b.results()
+        n = int(res['cost_len'][0].item())
+        assert n == len(TR[f'{c}/cost']) and close(res['cost'][0, :n].cpu().numpy(), TR[f'{c}/cost']), c
+        assert res['cost'].shape[1] == 6
+        b.close()

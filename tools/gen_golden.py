@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it writes are data
 (inputs + expected outputs), never reference source.  Re-run: `python tools/gen_golden.py [section ...]`
-with sections in {instances, kat, noise, policy, rlepso, lde}.
+with sections in {instances, kat, noise, policy, rlepso, lde, protein}.
 
 What is recorded
   instances : per (suite, dim) the problem names, biases, optima, a sha256 over every constructor-made
@@ -331,7 +331,53 @@ def gen_lde():
     print('lde:', len(cases), 'episodes')
 
 
-SECTIONS = {'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def protein_problems():
+    from problem.protein_docking import Protein_Docking_Dataset
+    tr, te = Protein_Docking_Dataset.get_datasets('protein', difficulty='easy')
+    return {str(p): p for p in tr.data + te.data}, [str(p) for p in tr.data], [str(p) for p in te.data]
+
+
+def gen_protein():
+    byid, tr, te = protein_problems()
+    nxt = float(np.random.rand())
+    rs = np.random.RandomState(4242)
+    X = np.concatenate([np.zeros((1, 12)), rs.uniform(-1.5, 1.5, size=(9, 12)), rs.uniform(-0.05, 0.05, size=(2, 12))])
+    data = {'x': X, 'train_ids': np.array(tr), 'test_ids': np.array(te), 'next_rand': np.float64(nxt)}
+    for pid in ('1AVX_1', '1ATN_7', '2HRK_10', '7CEI_3', tr[0], te[-1]):
+        byid[pid].reset()
+        data[f'f/{pid}'] = np.asarray(byid[pid].eval(X.copy()), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'protein_kat.npz'), **data)
+    print('protein:', {k: v.shape for k, v in data.items() if k.startswith('f/')})
+    # short RLEPSO / LDE episodes on protein problems (maxFEs = 1000, optimum None => no early stop)
+    scratch = tempfile.mkdtemp()
+    out, cases = {}, []
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/RLEPSO_Agent.pkl'))
+    config = ref_import.ref_config(['--problem', 'protein'], scratch)
+    for pid, seed in (('1AVX_1', 0), ('1ATN_7', 1), ('2HRK_10', 2)):
+        p = byid[pid]
+        p.reset()
+        rec = run_rlepso_episode(p, seed, agent, config, 'actor')
+        key = f'rlepso/{pid}/{seed}'
+        cases.append(key)
+        for k, v in rec.items():
+            out[f'{key}/{k}'] = v
+        print(key, len(rec['gbest']), rec['fes'][-1], rec['gbest'][-1])
+    lde = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/LDE_Agent.pkl'))
+    config = ref_import.ref_config(['--problem', 'protein'], scratch)
+    for pid, seed in (('1AVX_1', 3), ('7CEI_3', 4)):
+        p = byid[pid]
+        p.reset()
+        rec = run_lde_episode(p, seed, lde, config, 'actor')
+        key = f'lde/{pid}/{seed}'
+        cases.append(key)
+        for k, v in rec.items():
+            out[f'{key}/{k}'] = v
+        print(key, len(rec['gbest']), rec['fes'][-1], rec['gbest'][-1])
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'protein_traces.npz'), **out)
+
+
+SECTIONS = {'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
