@@ -122,6 +122,51 @@
 #define MBX_SITE_LDE_PART  11u
 #define MBX_SITE_LDE_ELEM  12u
 
+/* ---------------------------------------------------------------- 5. DE-DDQN (de_ddqn_optimizer.py) layouts
+ * tape per step (draw order of update(): binomial's randint(D,1) and rand(1,D) (operators/crossover.py:11,14), eval
+ * noise of the single trial, then __get_state's randint(0,NP,5) (:85)):
+ *   r[5] @0 | jrand @5 | noise[3] @8 | cross_u[D] @16
+ * mbx_reset: r[5] @0 | pos_u[NP*D] @16 | noise_init[3*NP] @16+NP*D.
+ * state block: X[NP*D] cost[NP] gbest_pos[D] prebest_pos[D] r[8] N_tot[4*10] N_succ[4*4*10] OM_sum[4*4*10]
+ *   OM_max[4*4*10] OM_W[50*6] extra[16] scalars[16] cost_curve[nlog+1].
+ * The generation deques (maxlen gen_max = 10, appendleft) are rings: generation-back index g lives in slot
+ * (g - gen) mod 10.  extra[]: see MBX_DQ_X_*.  Philox: MBX_SITE_DQ_R(idx 0: w0..w3 -> r0..r3, idx 1: w0 -> r4),
+ * MBX_SITE_DQ_JRAND(idx 0: w0), cross_u -> MBX_SITE_LDE_ELEM(d), init positions -> MBX_SITE_LDE_ELEM(e).        */
+#define MBX_DQ_GENMAX 10
+#define MBX_DQ_W      50
+#define MBX_DQ_NFEAT  99
+#define MBX_DQ_TAPE_R(NP, D)       ((int64_t)0)
+#define MBX_DQ_TAPE_JRAND(NP, D)   ((int64_t)5)
+#define MBX_DQ_TAPE_NOISE(NP, D)   ((int64_t)8)
+#define MBX_DQ_TAPE_CROSS(NP, D)   ((int64_t)16)
+#define MBX_DQ_TAPE_POS(NP, D)     ((int64_t)16)
+#define MBX_DQ_TAPE_NOISE_INIT(NP, D) ((int64_t)16 + (int64_t)(NP) * (D))
+#define MBX_DQ_TAPE_STRIDE(NP, D)  ((int64_t)16 + (int64_t)(NP) * (D) + 3 * (int64_t)(NP))
+#define MBX_DQ_ST_X(NP, D)        ((int64_t)0)
+#define MBX_DQ_ST_COST(NP, D)     ((int64_t)(NP) * (D))
+#define MBX_DQ_ST_GBPOS(NP, D)    ((int64_t)(NP) * (D) + (NP))
+#define MBX_DQ_ST_PREPOS(NP, D)   (MBX_DQ_ST_GBPOS(NP, D) + (D))
+#define MBX_DQ_ST_R(NP, D)        (MBX_DQ_ST_PREPOS(NP, D) + (D))
+#define MBX_DQ_ST_NTOT(NP, D)     (MBX_DQ_ST_R(NP, D) + 8)
+#define MBX_DQ_ST_NSUCC(NP, D)    (MBX_DQ_ST_NTOT(NP, D) + 40)
+#define MBX_DQ_ST_OMSUM(NP, D)    (MBX_DQ_ST_NSUCC(NP, D) + 160)
+#define MBX_DQ_ST_OMMAX(NP, D)    (MBX_DQ_ST_OMSUM(NP, D) + 160)
+#define MBX_DQ_ST_OMW(NP, D)      (MBX_DQ_ST_OMMAX(NP, D) + 160)
+#define MBX_DQ_ST_EXTRA(NP, D)    (MBX_DQ_ST_OMW(NP, D) + 300)
+#define MBX_DQ_ST_SCALARS(NP, D)  (MBX_DQ_ST_EXTRA(NP, D) + 16)
+#define MBX_DQ_STATE_DOUBLES(NP, D, NLOG) (MBX_DQ_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_DQ_X_GWORST   0   /* c_gworst                                            */
+#define MBX_DQ_X_CPRE     1   /* c_prebest (never updated after init: reference :135) */
+#define MBX_DQ_X_POINTER  2
+#define MBX_DQ_X_GEN      3   /* the reference's __gen (population sweeps started)    */
+#define MBX_DQ_X_STAG     4
+#define MBX_DQ_X_OMWLEN   5
+#define MBX_DQ_X_G0       6   /* row that X_gbest / X_prebest alias while they are numpy views (:55,58) */
+#define MBX_DQ_X_GBVIEW   7
+#define MBX_DQ_X_PREVIEW  8
+#define MBX_SITE_DQ_R      13u
+#define MBX_SITE_DQ_JRAND  14u
+
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u
 #define MBX_PHILOX_W0 0x9E3779B9u

@@ -1,3 +1,4 @@
 from .basic_agent import Basic_Agent
 from .rlepso_agent import RLEPSO_Agent
 from .lde_agent import LDE_Agent
+from .de_ddqn_agent import DE_DDQN_Agent

@@ -12,6 +12,7 @@
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"
 #include "mbx_lde.hpp"
+#include "mbx_ddqn.hpp"
 
 using namespace mbx;
 
@@ -77,6 +78,12 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_LDE_TAPE_STRIDE(c.np, c.dim);
         g.lds_doubles = lde_lds_doubles(c.np, c.dim);
         g.state_dim = c.np + 2 * MBX_LDE_BINS; g.action_dim = 2 * c.np;
+    } else if (c.algo == MBX_ALGO_DEDDQN) {
+        g.state_doubles = MBX_DQ_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_DQ_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_DQ_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = dq_lds_doubles(c.np, c.dim);
+        g.state_dim = MBX_DQ_NFEAT; g.action_dim = 1;
     }
     return g;
 }
@@ -298,7 +305,7 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo != MBX_ALGO_RLEPSO && c->algo != MBX_ALGO_LDE)
+    if (c->algo != MBX_ALGO_RLEPSO && c->algo != MBX_ALGO_LDE && c->algo != MBX_ALGO_DEDDQN)
         return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
     if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
     if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
@@ -354,9 +361,12 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     if (cfg->algo == MBX_ALGO_RLEPSO) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    } else {
+    } else if (cfg->algo == MBX_ALGO_LDE) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     *out = b;
     return MBX_OK;
@@ -394,8 +404,11 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
     if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
-        if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: LDE needs d_state_out");
-        hipLaunchKernelGGL(k_lde_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
+        if (b->cfg.algo == MBX_ALGO_LDE)
+            hipLaunchKernelGGL(k_lde_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        else
+            hipLaunchKernelGGL(k_dq_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     }
     HIP_TRY(hipGetLastError());
     return MBX_OK;
@@ -409,9 +422,13 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
     else {
-        if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: LDE needs d_state_out");
-        hipLaunchKernelGGL(k_lde_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+        if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
+        if (b->cfg.algo == MBX_ALGO_LDE)
+            hipLaunchKernelGGL(k_lde_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                               (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+        else
+            hipLaunchKernelGGL(k_dq_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                               (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
     }
     HIP_TRY(hipGetLastError());
     return MBX_OK;

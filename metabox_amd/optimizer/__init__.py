@@ -1,3 +1,4 @@
 from .learnable_optimizer import Learnable_Optimizer
 from .rlepso_optimizer import RLEPSO_Optimizer
 from .lde_optimizer import LDE_Optimizer
+from .de_ddqn_optimizer import DE_DDQN_Optimizer

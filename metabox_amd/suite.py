@@ -137,8 +137,9 @@ class Batch:
     def step(self, actions):
         """actions: CUDA tensor [B, action_dim] (float32).  Returns (state, reward, done) device tensors that are
         overwritten by the next call."""
-        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == torch.float32
-        assert tuple(actions.shape) == (self.B, self.action_dim)
+        want = torch.int32 if self.cfg.algo == _abi.ALGO_DEDDQN else torch.float32
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == want
+        assert actions.numel() == self.B * self.action_dim
         _abi.check(self.lib.mbx_step(self._h, _ptr(actions), _ptr(self.state), _ptr(self.reward), _ptr(self.done), _stream()))
         return self.state, self.reward, self.done
 

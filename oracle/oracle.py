@@ -293,3 +293,99 @@ class LdeTapeFeeder:
         t[4 * NP:7 * NP] = self._noise()
         self.fes += NP
         return t
+
+
+# ======================================================================================== DE-DDQN
+def _dq_lib():
+    L = lib()
+    if not getattr(L, '_dq_ready', False):
+        L.orc_dq_new.restype = C.c_void_p
+        L.orc_dq_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_dq_free.argtypes = [C.c_void_p]
+        L.orc_dq_reset.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_dq_step.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        L.orc_dq_state.argtypes = [C.c_void_p, _dp]
+        L._dq_ready = True
+    return L
+
+
+def dq_state_doubles(NP, D, nlog):
+    return NP * D + NP + 2 * D + 8 + 40 + 3 * 160 + 300 + 16 + 16 + nlog + 1
+
+
+def split_dq_state(st, NP, D, nlog):
+    o, out = 0, {}
+    for name, n in (('X', NP * D), ('cost', NP), ('gbpos', D), ('prepos', D), ('r', 8), ('ntot', 40), ('nsucc', 160),
+                    ('omsum', 160), ('ommax', 160), ('omw', 300), ('extra', 16), ('scalars', NSCALAR), ('clog', nlog + 1)):
+        out[name] = st[o:o + n]
+        o += n
+    return out
+
+
+class DqOracle:
+    """One DE-DDQN instance on the CPU (de_ddqn_optimizer.py restated in C)."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = _dq_lib().orc_dq_new(C.byref(self._st), float('nan') if optimum is None else float(optimum), C.byref(cfg), int(seed))
+        self._state = np.empty(99)
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            _dq_lib().orc_dq_free(self._h)
+            self._h = None
+
+    def reset(self, tape=None):
+        _dq_lib().orc_dq_reset(self._h, _p(tape) if tape is not None else None, _p(self._state))
+        return self._state.copy()
+
+    def step(self, action, tape=None):
+        out = np.empty(3)
+        _dq_lib().orc_dq_step(self._h, int(action), _p(tape) if tape is not None else None, _p(self._state), _p(out))
+        return self._state.copy(), out[0], bool(out[1])
+
+    def state(self):
+        out = np.empty(dq_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
+        _dq_lib().orc_dq_state(self._h, _p(out))
+        return out
+
+
+class DqTapeFeeder:
+    """numpy legacy-stream draws of DE_DDQN_Optimizer in the reference's call order (init: rand(NP,D), eval noise,
+    randint(0,NP,5); update: randint(D,size=1), rand(1,D), eval noise of one value, randint(0,NP,5))."""
+
+    def __init__(self, seed, NP, D, noise_kind):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise = NP, D, noise_kind
+        self.stride = 16 + NP * D + 3 * NP
+
+    def _noise(self, n):
+        rows = np.zeros((3, n))
+        if self.noise == 1:
+            rows[0] = self.rs.randn(n) if n > 1 else self.rs.randn()
+        elif self.noise == 2:
+            rows[0] = self.rs.rand(n) if n > 1 else self.rs.rand()
+            rows[1] = self.rs.rand(n) if n > 1 else self.rs.rand()
+        elif self.noise == 3:
+            rows[0] = self.rs.rand(n) if n > 1 else self.rs.rand()
+            rows[1] = self.rs.randn(n) if n > 1 else self.rs.randn()
+            rows[2] = self.rs.randn(n) if n > 1 else self.rs.randn()
+        return rows
+
+    def reset_tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        t[16:16 + NP * D] = self.rs.rand(NP, D).ravel()
+        t[16 + NP * D:16 + NP * D + 3 * NP] = self._noise(NP).ravel()
+        t[0:5] = self.rs.randint(0, NP, 5)
+        return t
+
+    def step_tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        t[5] = self.rs.randint(D, size=1)[0]
+        t[16:16 + D] = self.rs.rand(1, D).ravel()
+        t[8:11] = self._noise(1).ravel()
+        t[0:5] = self.rs.randint(0, NP, 5)
+        return t

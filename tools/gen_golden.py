@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it writes are data
 (inputs + expected outputs), never reference source.  Re-run: `python tools/gen_golden.py [section ...]`
-with sections in {instances, kat, noise, policy, rlepso, lde, protein}.
+with sections in {instances, kat, noise, policy, rlepso, lde, protein, ddqn}.
 
 What is recorded
   instances : per (suite, dim) the problem names, biases, optima, a sha256 over every constructor-made
@@ -377,7 +377,86 @@ def gen_protein():
     np.savez_compressed(os.path.join(OUT, 'protein_traces.npz'), **out)
 
 
-SECTIONS = {'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def run_ddqn_episode(problem, seed, agent, config):
+    from optimizer import DE_DDQN_Optimizer
+    from environment import PBO_Env
+    import copy
+    opt = DE_DDQN_Optimizer(copy.deepcopy(config))
+    env = PBO_Env(problem, opt)
+    net = agent._DE_DDQN_Agent__pred_func
+    np.random.seed(seed)
+    ars = np.random.RandomState(30_000 + seed)
+    state = env.reset()
+    rec = dict(actions=[], gbest=[], reward=[], done=[], feats=[np.concatenate([[-1], state])])
+    done, g = False, 0
+    while not done:
+        with torch.no_grad():
+            a = int(torch.argmax(net(torch.Tensor(state))))
+        if ars.rand() < 0.35:
+            a = int(ars.randint(0, 4))
+        state, r, done = env.step(a)
+        rec['actions'].append(a)
+        rec['gbest'].append(float(opt._DE_DDQN_Optimizer__c_gbest))
+        rec['reward'].append(float(r))
+        rec['done'].append(bool(done))
+        if g % 97 == 0 or done or g < 3 or 99 <= g <= 102 or 199 <= g <= 201:
+            rec['feats'].append(np.concatenate([[g], state]))
+        g += 1
+    out = {'actions': np.array(rec['actions'], dtype=np.uint8), 'gbest': np.array(rec['gbest']), 'reward': np.array(rec['reward']),
+           'done': np.array(rec['done']), 'feats': np.stack(rec['feats']), 'cost': np.array(opt.cost, dtype=np.float64),
+           'fes': np.float64(opt.fes), 'final_cost': np.array(opt._DE_DDQN_Optimizer__cost),
+           'final_X': np.array(opt._DE_DDQN_Optimizer__X)}
+    return out
+
+
+def gen_ddqn():
+    scratch = tempfile.mkdtemp()
+    data, cases = {}, []
+    config = ref_import.ref_config(['--problem', 'protein'], scratch)
+    torch.manual_seed(123)
+    from agent import DE_DDQN_Agent
+    agent = DE_DDQN_Agent(copy_config(config))
+    pol = {'net/' + k: v.detach().cpu().numpy() for k, v in agent._DE_DDQN_Agent__pred_func.state_dict().items()}
+    x = torch.rand(16, 99)
+    with torch.no_grad():
+        pol['io/x'] = x.numpy()
+        pol['io/q'] = agent._DE_DDQN_Agent__pred_func(x).numpy()
+    np.savez_compressed(os.path.join(OUT, 'ddqn_policy.npz'), **pol)
+    byid, _, _ = protein_problems()
+    for pid, seed in (('1AVX_1', 0), ('1ATN_7', 1), ('2HRK_10', 2)):
+        p = byid[pid]
+        p.reset()
+        rec = run_ddqn_episode(p, seed, agent, config)
+        key = f'protein/12/{pid}/{seed}'
+        cases.append(key)
+        for k, v in rec.items():
+            data[f'{key}/{k}'] = v
+        print(key, len(rec['gbest']), rec['gbest'][-1], np.bincount(rec['actions'], minlength=4))
+    for suite, fids, seed in (('bbob', (1, 15, 21), 3), ('bbob-noisy', (103, 117), 4)):
+        config = ref_import.ref_config(['--problem', suite, '--dim', '10'], scratch)
+        config.maxFEs = 3000                      # shortened budget keeps the fixture small (log_interval follows)
+        config.log_interval = config.maxFEs // config.n_logpoint
+        tr, te, _ = all_problems(suite, 10)
+        byfid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            p = byfid[fid]
+            p.reset()
+            rec = run_ddqn_episode(p, seed, agent, config)
+            key = f'{suite}/10/{fid}/{seed}'
+            cases.append(key)
+            for k, v in rec.items():
+                data[f'{key}/{k}'] = v
+            print(key, len(rec['gbest']), rec['gbest'][-1], np.bincount(rec['actions'], minlength=4))
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'ddqn_traces.npz'), **data)
+
+
+def copy_config(config):
+    import copy
+    return copy.deepcopy(config)
+
+
+SECTIONS = {'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
