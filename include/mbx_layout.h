@@ -167,6 +167,16 @@
 #define MBX_SITE_DQ_R      13u
 #define MBX_SITE_DQ_JRAND  14u
 
+/* ---------------------------------------------------------------- 6. Random_search (random_search.py) layouts
+ * tape per step / reset: pos_u[NP*D] | noise[3*NP];  state block: scalars[16] cost_curve[nlog+1].
+ * Philox: positions MBX_SITE_LDE_ELEM(e), noise MBX_SITE_NOISE0_A/B(i), generation counter = number of populations
+ * drawn so far in the episode (0 for the initial one).                                                              */
+#define MBX_RS_TAPE_POS(NP, D)     ((int64_t)0)
+#define MBX_RS_TAPE_NOISE(NP, D)   ((int64_t)(NP) * (D))
+#define MBX_RS_TAPE_STRIDE(NP, D)  ((int64_t)(NP) * (D) + 3 * (int64_t)(NP))
+#define MBX_RS_ST_SCALARS(NP, D)   ((int64_t)0)
+#define MBX_RS_STATE_DOUBLES(NP, D, NLOG) ((int64_t)MBX_NSCALAR + (int64_t)(NLOG) + 1)
+
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u
 #define MBX_PHILOX_W0 0x9E3779B9u

@@ -99,9 +99,9 @@ class DE_DDQN_Agent(Basic_Agent):
 
     @torch.no_grad()
     def rollout_batch(self, env, max_steps=None):
-        c = self.__config
         if max_steps is None:
-            max_steps = c.maxFEs - c.NP                  # one evaluation per step
+            bc = env.batch.cfg
+            max_steps = bc.max_fes - bc.np                # one evaluation per step
         state = env.reset()
         for _ in range(max_steps):
             actions = torch.argmax(self.__pred_func(state.to(torch.float32)), dim=1).to(torch.int32)

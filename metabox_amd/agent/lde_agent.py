@@ -115,9 +115,9 @@ class LDE_Agent(Basic_Agent):
 
     @torch.no_grad()
     def rollout_batch(self, env, max_steps=None):
-        c = self.__config
         if max_steps is None:
-            max_steps = -(-(c.maxFEs - c.NP) // c.NP)
+            bc = env.batch.cfg
+            max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         state = env.reset()
         h, cc = self.__zeros(env.B)
         for _ in range(max_steps):

@@ -148,9 +148,9 @@ class RLEPSO_Agent(Basic_Agent):
         Every update() bills at least NP evaluations, so after ceil((maxFEs-NP)/NP) generations every instance has
         reached ``fes >= maxFEs``; instances that finish earlier idle inside the kernel.
         """
-        c = self.__config
         if max_steps is None:
-            max_steps = -(-(c.maxFEs - c.NP) // c.NP)
+            bc = env.batch.cfg                       # the optimizer's own NP / maxFEs (it may differ from the agent's config copy)
+            max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         state = env.reset()
         for _ in range(max_steps):
             actions = self.__actor.act_batch(state.to(torch.float32))

@@ -13,6 +13,7 @@
 #include "mbx_rlepso.hpp"
 #include "mbx_lde.hpp"
 #include "mbx_ddqn.hpp"
+#include "mbx_rs.hpp"
 
 using namespace mbx;
 
@@ -84,6 +85,12 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_DQ_TAPE_STRIDE(c.np, c.dim);
         g.lds_doubles = dq_lds_doubles(c.np, c.dim);
         g.state_dim = MBX_DQ_NFEAT; g.action_dim = 1;
+    } else if (c.algo == MBX_ALGO_RANDOM_SEARCH) {
+        g.state_doubles = MBX_RS_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_RS_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_RS_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = rs_lds_doubles(c.np, c.dim);
+        g.state_dim = 1; g.action_dim = 0;
     }
     return g;
 }
@@ -305,7 +312,7 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo != MBX_ALGO_RLEPSO && c->algo != MBX_ALGO_LDE && c->algo != MBX_ALGO_DEDDQN)
+    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_RANDOM_SEARCH)
         return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
     if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
     if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
@@ -364,9 +371,11 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     } else if (cfg->algo == MBX_ALGO_LDE) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    } else {
+    } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rs_population, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     *out = b;
     return MBX_OK;
@@ -401,7 +410,10 @@ static BatchParams make_params(const mbx_batch* b)
 extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
 {
     if (!b) return fail(MBX_E_ARG, "null batch");
-    if (b->cfg.algo == MBX_ALGO_RLEPSO)
+    if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
+        hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 1, d_state_out,
+                           (double*)nullptr, (uint8_t*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
@@ -417,8 +429,11 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
 extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out, uint8_t* d_done_out,
                         void* stream)
 {
-    if (!b || !d_actions) return fail(MBX_E_ARG, "mbx_step: bad arguments");
-    if (b->cfg.algo == MBX_ALGO_RLEPSO)
+    if (!b || (!d_actions && b->cfg.algo != MBX_ALGO_RANDOM_SEARCH)) return fail(MBX_E_ARG, "mbx_step: bad arguments");
+    if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
+        hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 0, d_state_out,
+                           d_reward_out, d_done_out);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
     else {

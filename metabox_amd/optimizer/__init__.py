@@ -2,3 +2,5 @@ from .learnable_optimizer import Learnable_Optimizer
 from .rlepso_optimizer import RLEPSO_Optimizer
 from .lde_optimizer import LDE_Optimizer
 from .de_ddqn_optimizer import DE_DDQN_Optimizer
+from .basic_optimizer import Basic_Optimizer
+from .random_search import Random_search

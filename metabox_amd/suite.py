@@ -137,9 +137,12 @@ class Batch:
     def step(self, actions):
         """actions: CUDA tensor [B, action_dim] (float32).  Returns (state, reward, done) device tensors that are
         overwritten by the next call."""
-        want = torch.int32 if self.cfg.algo == _abi.ALGO_DEDDQN else torch.float32
-        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == want
-        assert actions.numel() == self.B * self.action_dim
+        if self.action_dim > 0:
+            want = torch.int32 if self.cfg.algo == _abi.ALGO_DEDDQN else torch.float32
+            assert actions.is_cuda and actions.is_contiguous() and actions.dtype == want
+            assert actions.numel() == self.B * self.action_dim
+        else:
+            actions = None                     # Random_search takes no action
         _abi.check(self.lib.mbx_step(self._h, _ptr(actions), _ptr(self.state), _ptr(self.reward), _ptr(self.done), _stream()))
         return self.state, self.reward, self.done
 

@@ -1,0 +1,251 @@
+"""Testing / rollout harness — batched re-statement of the reference loops (src/tester.py).
+
+``Tester(config).test()``   51 seeded runs x test problems x (agent, optimizer) pairs  (tester.py:180-263)
+``rollout(config)``         21 checkpoints x train problems x 5 runs                   (tester.py:266-352)
+``test_for_random_search``  Random_search over train+test problems, 51 runs            (tester.py:355-407)
+
+Where the reference runs one (problem, run) episode at a time, here the whole (problem x run) table of a pair is ONE
+lock-step batch on the GPU (sharded over ranks when torch.distributed is initialised; rows are all-gathered at the end
+of the epoch).  The result dictionaries and the pickle files keep the reference's schema:
+``{'cost': {problem: {name: [runs][51]}}, 'fes': {problem: {name: [runs]}}, 'T0', 'T1': {name}, 'T2': {name}}``.
+
+Timing fields: T0 is the reference's host calibration loop.  The fused kernel cannot separate evaluation time from the
+rest, so T1 (time inside problem.eval) is reported as 0 and T2 (wall ms per run) as batch wall time / instances.
+"""
+import copy
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from . import agent as _agents
+from . import optimizer as _optimizers
+from .distributed import gather_rows, instance_table, pack_rows, philox_seed, shard_range, unpack_rows
+from .environment import BatchedPBO_Env
+from .utils import construct_problem_set
+
+N_COST = 51          # cost rows are padded to 51 entries whatever n_logpoint is (tester.py:204-205, 330-331)
+
+
+def _lookup(module, name):
+    try:
+        return getattr(module, name)
+    except AttributeError:
+        raise NotImplementedError(f'{name} is not part of the accelerated path of this build (SURVEY.md §2)')
+
+
+def cal_t0(dim, fes):
+    """Host speed calibration (tester.py:59-74): 10 repetitions of `fes` tiny numpy operations, ms."""
+    T0 = 0
+    for _ in range(10):
+        start = time.perf_counter()
+        for _ in range(fes):
+            x = np.random.rand(dim)
+            x + x
+            x / (x + 2)
+            x * x
+            np.sqrt(x)
+            np.log(x)
+            np.exp(x)
+        T0 += (time.perf_counter() - start) * 1000
+    return T0 / 10
+
+
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _pad51(row):
+    row = list(row)
+    while len(row) < N_COST:
+        row.append(row[-1])
+    return row
+
+
+def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0):
+    """Run `runner(suite_problems, problem_idx, seeds) -> results dict` over the (problem x run) table, sharded over
+    ranks and optionally chunked; returns (cost [N, nlog+1], fes [N], ret [N]) as numpy arrays in table order plus the
+    wall time in ms."""
+    pidx, run = instance_table(len(problems), runs)
+    n_total = len(pidx)
+    rank, world = _world()
+    lo, hi = shard_range(n_total, rank, world)
+    seeds = philox_seed(run, np.arange(n_total), epoch_salt)
+    cap = n_instances_cap if n_instances_cap and n_instances_cap > 0 else (hi - lo)
+    rows = []
+    t0 = time.perf_counter()
+    for a in range(lo, hi, max(cap, 1)):
+        b = min(a + cap, hi)
+        rows.append(pack_rows(runner(problems, pidx[a:b], seeds[a:b])))
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1000
+    local = torch.cat(rows, 0) if rows else torch.zeros(0, 1)
+    full = unpack_rows(gather_rows(local, n_total))
+    return full['cost'].cpu().numpy(), full['fes'].cpu().numpy(), full['return'].cpu().numpy(), wall_ms
+
+
+def _learnable_runner(agent, optimizer, suite_cache, early_stop=True):
+    def run(problems, pidx, seeds):
+        from .suite import Suite
+        key = id(problems)
+        if key not in suite_cache:
+            suite_cache[key] = Suite(problems)
+        env = BatchedPBO_Env(problems, optimizer, pidx, seeds, early_stop=early_stop, suite=suite_cache[key])
+        out = agent.rollout_batch(env)
+        env.close()
+        return out
+    return run
+
+
+def _random_search_runner(optimizer, suite_cache):
+    def run(problems, pidx, seeds):
+        from .suite import Suite
+        key = id(problems)
+        if key not in suite_cache:
+            suite_cache[key] = Suite(problems)
+        res = optimizer.run_batch(suite_cache[key], pidx, seeds)
+        res['return'] = torch.zeros_like(res['fes'])
+        return res
+    return run
+
+
+def _fill(results, problems, name, runs, cost, fes):
+    for k, p in enumerate(problems):
+        rows = slice(k * runs, (k + 1) * runs)
+        results['cost'][str(p)][name] = [_pad51(r) for r in cost[rows]]
+        results['fes'][str(p)][name] = [float(v) for v in fes[rows]]
+
+
+class Tester(object):
+    def __init__(self, config):
+        self.config = config
+        self.agent_name_list = list(config.agent_for_cp)
+        self.agent_for_cp = []
+        for name in config.agent_for_cp:
+            with open(config.agent_load_dir + name + '.pkl', 'rb') as f:
+                self.agent_for_cp.append(pickle.load(f))
+        self.l_optimizer_for_cp = [_lookup(_optimizers, n)(copy.deepcopy(config)) for n in config.l_optimizer_for_cp]
+        self.t_optimizer_for_cp, self.skipped = [], []
+        for n in config.t_optimizer_for_cp:
+            if hasattr(_optimizers, n):
+                self.t_optimizer_for_cp.append(getattr(_optimizers, n)(copy.deepcopy(config)))
+            else:
+                self.skipped.append(n)      # DEAP_* / Bayesian / ...: arithmetic lives in un-vendored packages (parity unpinned)
+        if config.agent is not None:
+            with open(config.agent_load_dir + config.agent + '.pkl', 'rb') as f:
+                self.agent_for_cp.append(pickle.load(f))
+            self.agent_name_list.append(config.agent)
+            self.l_optimizer_for_cp.append(_lookup(_optimizers, config.optimizer)(copy.deepcopy(config)))
+        elif config.optimizer is not None:
+            self.t_optimizer_for_cp.append(_lookup(_optimizers, config.optimizer)(copy.deepcopy(config)))
+        self.log_dir = config.test_log_dir
+        os.makedirs(self.log_dir, exist_ok=True)
+        if config.problem[-6:] == '-torch':
+            config.problem = config.problem[:-6]
+        _, self.test_set = construct_problem_set(config)
+        self.runs = getattr(config, 'test_runs', 51)
+        self.test_results = {'cost': {}, 'fes': {}, 'T0': 0., 'T1': {}, 'T2': {}}
+        names = self.agent_name_list + [type(o).__name__ for o in self.t_optimizer_for_cp]
+        for n in names:
+            self.test_results['T1'][n] = 0.
+            self.test_results['T2'][n] = 0.
+        for p in self.test_set.data:
+            self.test_results['cost'][str(p)] = {n: [] for n in names}
+            self.test_results['fes'][str(p)] = {n: [] for n in names}
+
+    def test(self):
+        cfg = self.config
+        self.test_results['T0'] = cal_t0(cfg.dim, cfg.maxFEs)
+        problems = self.test_set.data
+        cache = {}
+        cap = getattr(cfg, 'n_instances', 0)
+        early = not getattr(cfg, 'fixed_horizon', False)
+        for name, agent, optimizer in zip(self.agent_name_list, self.agent_for_cp, self.l_optimizer_for_cp):
+            if hasattr(agent, 'to'):
+                agent.to(cfg.device)
+            cost, fes, _, wall = run_pairs(problems, _learnable_runner(agent, optimizer, cache, early), self.runs, cap)
+            _fill(self.test_results, problems, name, self.runs, cost, fes)
+            self.test_results['T1'][name] = 0.
+            self.test_results['T2'][name] = wall / len(cost)
+        for optimizer in self.t_optimizer_for_cp:
+            name = type(optimizer).__name__
+            cost, fes, _, wall = run_pairs(problems, _random_search_runner(optimizer, cache), self.runs, cap)
+            _fill(self.test_results, problems, name, self.runs, cost, fes)
+            self.test_results['T1'][name] = 0.
+            self.test_results['T2'][name] = wall / len(cost)
+        rank, _ = _world()
+        random_search_results = test_for_random_search(cfg)
+        if rank == 0:
+            with open(self.log_dir + 'test.pkl', 'wb') as f:
+                pickle.dump(self.test_results, f, -1)
+            with open(self.log_dir + 'random_search_baseline.pkl', 'wb') as f:
+                pickle.dump(random_search_results, f, -1)
+        return self.test_results
+
+
+def test_for_random_search(config):
+    """Random_search over train + test problems with the single key 'Random_search' (tester.py:355-407)."""
+    train_set, test_set = construct_problem_set(config)
+    problems = (train_set + test_set).data
+    optimizer = _optimizers.Random_search(copy.deepcopy(config))
+    name = type(optimizer).__name__
+    res = {'cost': {}, 'fes': {}, 'T0': cal_t0(config.dim, config.maxFEs), 'T1': {name: 0.}, 'T2': {name: 0.}}
+    for p in problems:
+        res['cost'][str(p)] = {name: []}
+        res['fes'][str(p)] = {name: []}
+    runs = getattr(config, 'test_runs', 51)
+    cost, fes, _, wall = run_pairs(problems, _random_search_runner(optimizer, {}), runs, getattr(config, 'n_instances', 0))
+    _fill(res, problems, name, runs, cost, fes)
+    res['T2'][name] = wall / len(cost)
+    return res
+
+
+def rollout(config):
+    """21 checkpoints x train problems x 5 runs -> rollout.pkl with keys cost / fes / return
+    [problem][agent][checkpoint] -> list over runs (tester.py:266-352)."""
+    if config.problem[-6:] == '-torch':
+        config.problem = config.problem[:-6]
+    train_set, _ = construct_problem_set(config)
+    problems = train_set.data
+    runs = getattr(config, 'rollout_runs', 5)
+    n_cp = config.n_checkpoint
+    results = {'cost': {}, 'fes': {}, 'return': {}}
+    for p in problems:
+        for k in results:
+            results[k][str(p)] = {a: [[] for _ in range(n_cp + 1)] for a in config.agent_for_rollout}
+    cache = {}
+    for agent_name, opt_name in zip(config.agent_for_rollout, config.optimizer_for_rollout):
+        optimizer = _lookup(_optimizers, opt_name)(copy.deepcopy(config))
+        for cp in range(n_cp + 1):
+            with open(config.agent_load_dir + agent_name + '/checkpoint' + str(cp) + '.pkl', 'rb') as f:
+                agent = pickle.load(f)
+            if hasattr(agent, 'to'):
+                agent.to(config.device)
+            cost, fes, ret, _ = run_pairs(problems, _learnable_runner(agent, optimizer, cache), runs,
+                                          getattr(config, 'n_instances', 0), epoch_salt=cp)
+            for k, p in enumerate(problems):
+                rows = slice(k * runs, (k + 1) * runs)
+                results['cost'][str(p)][agent_name][cp] = [_pad51(r) for r in cost[rows]]
+                results['fes'][str(p)][agent_name][cp] = [float(v) for v in fes[rows]]
+                results['return'][str(p)][agent_name][cp] = [float(v) for v in ret[rows]]
+    rank, _ = _world()
+    if rank == 0:
+        os.makedirs(config.rollout_log_dir, exist_ok=True)
+        with open(config.rollout_log_dir + 'rollout.pkl', 'wb') as f:
+            pickle.dump(results, f, -1)
+    return results
+
+
+def name_translate(problem):
+    if problem in ['bbob', 'bbob-torch']:
+        return 'Synthetic'
+    if problem in ['bbob-noisy', 'bbob-noisy-torch']:
+        return 'Noisy-Synthetic'
+    if problem in ['protein', 'protein-torch']:
+        return 'Protein-Docking'
+    raise ValueError(problem + ' is not defined!')

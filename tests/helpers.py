@@ -29,3 +29,30 @@ def problems(suite, dim):
 
 def load(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+def fake_results(rs, names, problem_names):
+    """Synthetic test.pkl-shaped results dict (schema of src/tester.py:123-127) drawn from RandomState `rs`; shared by
+    tools/gen_golden.py (which feeds it to the reference's metric functions) and the metric tests."""
+    d = {'cost': {}, 'fes': {}, 'T0': 31.25, 'T1': {}, 'T2': {}}
+    for a in names:
+        d['T1'][a] = float(rs.uniform(5, 20))
+        d['T2'][a] = float(d['T1'][a] + rs.uniform(50, 900))
+    for p in problem_names:
+        d['cost'][p], d['fes'][p] = {}, {}
+        for a in names:
+            c = np.sort(rs.lognormal(0, 2, size=(51, 51)), axis=1)[:, ::-1] * rs.uniform(0.1, 10)
+            d['cost'][p][a] = [list(r) for r in c]
+            d['fes'][p][a] = [float(v) for v in rs.randint(5000, 20001, size=51)]
+    return d
+
+
+METRIC_PROBLEMS = ['Sphere', 'Schwefel', 'Rastrigin_F15']
+METRIC_AGENTS = ['RLEPSO_Agent', 'LDE_Agent', 'DEAP_CMAES', 'Random_search']
+
+
+def metric_inputs():
+    rs = np.random.RandomState(99)
+    test = fake_results(rs, METRIC_AGENTS, METRIC_PROBLEMS)
+    rand = fake_results(rs, ['Random_search'], METRIC_PROBLEMS + ['Ellipsoidal'])
+    return test, rand

@@ -1,0 +1,196 @@
+"""Metrics (AEI / CEC / Random_search baseline) against the reference's outputs (CPU); Random_search oracle vs the
+reference's episodes (CPU); batched Tester / rollout / Random_search on the GPU."""
+import copy
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, close, load, metric_inputs, problems
+from oracle import oracle
+
+RS = load('random_search.npz')
+METRICS = json.load(open(os.path.join(GOLDEN, 'metrics.json')))
+
+
+def test_metrics_match_reference():
+    from metabox_amd.config import get_config
+    from metabox_amd.logger import Logger, get_random_baseline
+    test, rand = metric_inputs()
+    base = get_random_baseline(rand, 20000)
+    for k, v in METRICS['baseline'].items():
+        assert np.isclose(base[k], v, rtol=1e-12), k
+    lg = Logger(get_config(['--problem', 'bbob', '--dim', '10']))
+    mean, std = lg.aei_metric(copy.deepcopy(test), rand, maxFEs=20000)
+    assert set(mean) == set(METRICS['aei_mean']) and 'Random_search' not in mean
+    for k in mean:
+        assert np.isclose(mean[k], METRICS['aei_mean'][k], rtol=1e-12) and np.isclose(std[k], METRICS['aei_std'][k], rtol=1e-12)
+    mean_p, std_p = Logger(get_config(['--problem', 'protein'])).aei_metric(copy.deepcopy(test), rand, maxFEs=1000)
+    for k in mean_p:
+        assert np.isclose(mean_p[k], METRICS['aei_mean_protein'][k], rtol=1e-12)
+        assert np.isclose(std_p[k], METRICS['aei_std_protein'][k], rtol=1e-12)           # protein: std x 5 (logger.py:641-644)
+    cec = lg.cec_metric(copy.deepcopy(test))
+    for k, v in METRICS['cec'].items():
+        assert np.isclose(cec[k], v, rtol=1e-12), k
+
+
+def _rs_problem(suite, dim, fid):
+    if suite == 'protein':
+        from test_protein import protein
+        return protein()[0][fid], None, 1000, 5, 0
+    p = problems(suite, dim)[int(fid)]
+    return p, p.bias, 2000 * dim, 50, p.noise[0]
+
+
+class _RsFeeder:
+    def __init__(self, seed, NP, D, noise, lb, ub):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise = NP, D, noise
+
+    def tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(NP * D + 3 * NP)
+        t[:NP * D] = self.rs.random_sample((NP, D)).ravel()           # uniform(lb, ub) = lb + (ub-lb)*u
+        t[NP * D:] = oracle.NumpyTapeFeeder._noise_rows(self)
+        return t
+
+
+@pytest.mark.parametrize('case', [str(c) for c in RS['cases']])
+def test_oracle_random_search_replays_reference(case):
+    import ctypes as C
+    _, suite, dim, fid, seed = case.split('/')
+    dim = int(dim)
+    p, opt, maxfes, nlog, nk = _rs_problem(suite, dim, fid)
+    L = oracle.lib()
+    L.orc_rs_new.restype = C.c_void_p
+    L.orc_rs_new.argtypes = [C.POINTER(oracle.ProblemDesc), C.c_double, C.POINTER(oracle.AlgoCfg), C.c_uint64]
+    dp = C.POINTER(C.c_double)
+    L.orc_rs_reset.argtypes = [C.c_void_p, dp]
+    L.orc_rs_step.argtypes = [C.c_void_p, dp]
+    L.orc_rs_result.argtypes = [C.c_void_p, dp, dp, C.POINTER(C.c_int)]
+    L.orc_rs_free.argtypes = [C.c_void_p]
+    st, keep = oracle.pack_desc(p.desc())
+    cfg = oracle.make_cfg(4, 100, dim, maxfes, maxfes // nlog, nlog)
+    h = L.orc_rs_new(C.byref(st), float('nan') if opt is None else opt, C.byref(cfg), 0)
+    fd = _RsFeeder(int(seed), 100, dim, nk, p.lb, p.ub)
+    t = fd.tape()
+    L.orc_rs_reset(h, t.ctypes.data_as(dp))
+    done = 0
+    while not done:
+        t = fd.tape()
+        done = L.orc_rs_step(h, t.ctypes.data_as(dp))
+    cost = np.zeros(nlog + 1); fes = C.c_double(); n = C.c_int()
+    L.orc_rs_result(h, cost.ctypes.data_as(dp), C.byref(fes), C.byref(n))
+    L.orc_rs_free(h)
+    ref = RS[f'{case}/cost']
+    assert n.value == len(ref) and fes.value == RS[f'{case}/fes']
+    assert close(cost[:n.value], ref, rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_random_search_replays_reference_and_batches():
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RANDOM_SEARCH
+    for case in [str(c) for c in RS['cases']]:
+        _, suite, dim, fid, seed = case.split('/')
+        dim = int(dim)
+        p, opt, maxfes, nlog, nk = _rs_problem(suite, dim, fid)
+        s = Suite([p])
+        b = Batch(s, ALGO_RANDOM_SEARCH, [0], [0], 100, maxfes, maxfes // nlog, nlog)
+        fd = _RsFeeder(int(seed), 100, dim, nk, p.lb, p.ub)
+        b.set_tape(torch.from_numpy(fd.tape()[None]).cuda())
+        b.reset()
+        for _ in range((maxfes - 100) // 100):
+            b.set_tape(torch.from_numpy(fd.tape()[None]).cuda())
+            _, _, d = b.step(None)
+            if d[0].item():
+                break
+        res = b.results()
+        n = int(res['cost_len'][0].item())
+        ref = RS[f'{case}/cost']
+        assert n == len(ref) and float(res['fes'][0].item()) == RS[f'{case}/fes'], case
+        assert close(res['cost'][0, :n].cpu().numpy(), ref), case
+        b.close()
+
+
+@pytest.mark.gpu
+def test_tester_and_rollout_write_reference_schema(tmp_path):
+    import torch
+    from metabox_amd.agent import RLEPSO_Agent
+    from metabox_amd.agent.utils import save_class
+    from metabox_amd.config import get_config
+    from metabox_amd.tester import Tester, rollout
+    load_dir = str(tmp_path / 'models') + '/'
+    common = ['--problem', 'bbob', '--dim', '10', '--device', 'cuda', '--log_dir', str(tmp_path / 'out'),
+              '--agent_load_dir', load_dir, '--test_runs', '3', '--rollout_runs', '2', '--n_checkpoint', '1']
+    cfg = get_config(common + ['--test', '--agent_for_cp', 'RLEPSO_Agent', '--l_optimizer_for_cp', 'RLEPSO_Optimizer'])
+    acfg = copy.deepcopy(cfg)
+    acfg.agent_save_dir = None
+    agent = RLEPSO_Agent(acfg).load_exported_weights(np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'metabox_amd',
+                                                                           'agent_model', 'rlepso_bbob_easy.npz')))
+    save_class(load_dir, 'RLEPSO_Agent', agent)
+    for cp in (0, 1):
+        save_class(load_dir + 'RLEPSO_Agent/', f'checkpoint{cp}', agent)
+    tester = Tester(cfg)
+    assert tester.skipped == ['DEAP_CMAES']            # always appended by get_config; un-vendored => not run
+    res = tester.test()
+    names = {'RLEPSO_Agent', 'Random_search'}
+    assert set(res['T1']) == names and set(res['T2']) == names and res['T0'] > 0
+    test_names = ['Sphere', 'Linear_Slope', 'Attractive_Sector', 'Ellipsoidal_high_cond', 'Rastrigin_F15', 'Schwefel']
+    assert list(res['cost']) == test_names                                    # bbob-easy test split
+    for p in test_names:
+        for n in names:
+            rows = res['cost'][p][n]
+            assert len(rows) == 3 and all(len(r) == 51 for r in rows) and len(res['fes'][p][n]) == 3
+            assert all(r[0] >= r[-1] for r in rows)
+    # the trained policy solves Sphere to the 1e-8 stop threshold well before the budget (reference: 7.1e3 FEs on average)
+    assert max(r[-1] for r in res['cost']['Sphere']['RLEPSO_Agent']) <= 1e-8
+    assert max(res['fes']['Sphere']['RLEPSO_Agent']) < 20000 <= min(res['fes']['Schwefel']['RLEPSO_Agent'])
+    with open(cfg.test_log_dir + 'test.pkl', 'rb') as f:
+        assert pickle.load(f)['cost'].keys() == res['cost'].keys()
+    with open(cfg.test_log_dir + 'random_search_baseline.pkl', 'rb') as f:
+        rsb = pickle.load(f)
+    assert len(rsb['cost']) == 24 and list(rsb['T2']) == ['Random_search']
+    from metabox_amd.logger import Logger
+    mean, std = Logger(cfg).aei_metric(copy.deepcopy(res), rsb, maxFEs=cfg.maxFEs)
+    assert mean['RLEPSO_Agent'] > 0 and np.isfinite(std['RLEPSO_Agent'])
+    rcfg = get_config(common + ['--rollout', '--agent_for_rollout', 'RLEPSO_Agent', '--optimizer_for_rollout', 'RLEPSO_Optimizer'])
+    out = rollout(rcfg)
+    assert set(out) == {'cost', 'fes', 'return'} and len(out['cost']) == 18
+    one = out['return']['Rastrigin']['RLEPSO_Agent']
+    assert len(one) == 2 and len(one[0]) == 2 and len(out['cost']['Rastrigin']['RLEPSO_Agent'][1][0]) == 51
+    assert os.path.exists(rcfg.rollout_log_dir + 'rollout.pkl')
+
+
+@pytest.mark.gpu
+def test_single_env_protocol_and_short_training(tmp_path):
+    """The reference's B = 1 protocol (env.reset / env.step with numpy in/out) and a few PPO / REINFORCE / DDQN updates."""
+    import torch
+    from metabox_amd.agent import DE_DDQN_Agent, LDE_Agent, RLEPSO_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import PBO_Env
+    from metabox_amd.optimizer import DE_DDQN_Optimizer, LDE_Optimizer, RLEPSO_Optimizer
+    from metabox_amd.utils import construct_problem_set
+    for A, O, argv in ((RLEPSO_Agent, RLEPSO_Optimizer, ['--problem', 'bbob', '--dim', '10']),
+                       (LDE_Agent, LDE_Optimizer, ['--problem', 'bbob-noisy', '--dim', '10']),
+                       (DE_DDQN_Agent, DE_DDQN_Optimizer, ['--problem', 'protein'])):
+        cfg = get_config(argv + ['--train', '--train_agent', A.__name__, '--train_optimizer', O.__name__, '--max_learning_step', '4',
+                                 '--agent_save_dir', str(tmp_path / 'agents') + '/', '--log_dir', str(tmp_path / 'log')])
+        agent, opt = A(cfg), O(cfg)
+        train, test = construct_problem_set(cfg)
+        np.random.seed(3)
+        env = PBO_Env(test[0], opt)
+        with torch.no_grad():
+            info = agent.rollout_episode(env)
+        assert set(info) == {'cost', 'fes', 'return'} and len(info['cost']) <= cfg.n_logpoint + 1 and info['fes'] >= cfg.maxFEs * 0.3
+        assert info['cost'][0] >= info['cost'][-1] and opt.cost == info['cost']
+        if A is not DE_DDQN_Agent:                    # DDQN needs a 1e4-step warm-up before it learns: rollout only
+            torch.set_grad_enabled(True)
+            exceed, tinfo = agent.train_episode(PBO_Env(train[0], opt))
+            assert set(tinfo) == {'normalizer', 'gbest', 'return', 'learn_steps'} and tinfo['learn_steps'] >= 1
+            torch.set_grad_enabled(False)
+        assert os.path.exists(cfg.agent_save_dir + 'checkpoint0.pkl')

@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it writes are data
 (inputs + expected outputs), never reference source.  Re-run: `python tools/gen_golden.py [section ...]`
-with sections in {instances, kat, noise, policy, rlepso, lde, protein, ddqn}.
+with sections in {instances, kat, noise, policy, rlepso, lde, protein, ddqn, harness}.
 
 What is recorded
   instances : per (suite, dim) the problem names, biases, optima, a sha256 over every constructor-made
@@ -456,7 +456,55 @@ def copy_config(config):
     return copy.deepcopy(config)
 
 
-SECTIONS = {'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def gen_harness():
+    """Random_search episodes (the AEI normaliser) and the metric functions of src/logger.py on a synthetic results dict."""
+    import copy
+    import json
+    scratch = tempfile.mkdtemp()
+    from optimizer import Random_search
+    data, cases = {}, []
+    for suite, dim, fids in (('bbob', 10, (1, 16)), ('bbob-noisy', 10, (117,)), ('protein', 12, ('1AVX_1',))):
+        argv = ['--problem', suite] + ([] if suite == 'protein' else ['--dim', str(dim)])
+        config = ref_import.ref_config(argv, scratch)
+        if suite == 'protein':
+            byid = protein_problems()[0]
+        else:
+            tr, te, _ = all_problems(suite, dim)
+            byid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            for seed in (0, 7):
+                opt = Random_search(copy.deepcopy(config))
+                np.random.seed(seed)
+                info = opt.run_episode(byid[fid])
+                key = f'rs/{suite}/{dim}/{fid}/{seed}'
+                cases.append(key)
+                data[f'{key}/cost'] = np.array(info['cost'], dtype=np.float64)
+                data[f'{key}/fes'] = np.float64(info['fes'])
+                print(key, len(info['cost']), info['fes'], info['cost'][-1])
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'random_search.npz'), **data)
+    # ---- metrics: synthetic test.pkl-shaped dicts -> get_random_baseline / aei_metric / cec_metric
+    from logger import Logger, get_random_baseline
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tests'))
+    from helpers import metric_inputs
+    test, rand = metric_inputs()
+    config = ref_import.ref_config(['--problem', 'bbob', '--dim', '10'], scratch)
+    lg = Logger(config)
+    base = get_random_baseline(rand, 20000)
+    mean, std = lg.aei_metric(copy.deepcopy(test), rand, maxFEs=20000)
+    cec = lg.cec_metric(copy.deepcopy(test))
+    config_p = ref_import.ref_config(['--problem', 'protein'], scratch)
+    mean_p, std_p = Logger(config_p).aei_metric(copy.deepcopy(test), rand, maxFEs=1000)
+    out = {'baseline': {k: float(v) for k, v in base.items()},
+           'aei_mean': {k: float(v) for k, v in mean.items()}, 'aei_std': {k: float(v) for k, v in std.items()},
+           'aei_mean_protein': {k: float(v) for k, v in mean_p.items()}, 'aei_std_protein': {k: float(v) for k, v in std_p.items()},
+           'cec': {k: float(v) for k, v in cec.items()}}
+    with open(os.path.join(OUT, 'metrics.json'), 'w') as f:
+        json.dump(out, f)
+    print('metrics:', out['aei_mean'], out['cec'])
+
+
+SECTIONS = {'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
