@@ -106,6 +106,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph-policy', action='store_true', help='replay the policy as one hipGraph instead of launching it op by op')
+    ap.add_argument('--dist-backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
+    ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses cuda:0')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -116,8 +119,13 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.same_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -150,6 +158,21 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     state = env.reset()
+    # The policy forward is two 3-layer MLPs, tanh, Normal sampling and clamp: ~15 tiny kernels.  Launched eagerly they
+    # are asynchronous and hide behind the previous generation kernel; --graph-policy captures them once into a hipGraph
+    # (input = the batch's persistent state tensor, output = a static action tensor) and replays it every generation.
+    # The generation kernel itself is always launched eagerly so that HIP events can bracket it.
+    policy_graph, static_actions = None, None
+    if args.graph_policy:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(3):
+                static_actions = actor.act_batch(state.to(torch.float32))
+        torch.cuda.current_stream().wait_stream(side)
+        policy_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(policy_graph), torch.no_grad():
+            static_actions = actor.act_batch(state.to(torch.float32))
     gen_in_ep, live, base = 0, 0, 0
     t0 = None
     with torch.no_grad():
@@ -166,7 +189,11 @@ def main():
                 gen_in_ep = 0
                 if it <= W:
                     base = 0
-            actions = actor.act_batch(state.to(torch.float32))
+            if policy_graph is not None:
+                policy_graph.replay()
+                actions = static_actions
+            else:
+                actions = actor.act_batch(state.to(torch.float32))
             if it >= W:
                 ev0[it - W].record()
             state, _, _ = env.step(actions)
@@ -178,8 +205,9 @@ def main():
         live += steps_sum() - base
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1))
 
-    tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
+    tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -199,7 +227,8 @@ def main():
             'config': {'workload': f'RLEPSO_Agent + RLEPSO_Optimizer, bbob dim=10 pop=100, {B} lock-step instances per GPU '
                                    f'(24 bbob functions round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
-                       'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}'},
+                       'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}',
+                       'policy_launch': 'hipGraph replay' if args.graph_policy else 'eager (asynchronous, overlapped with the generation kernel)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_rlepso_step',
                          'algorithmic_bytes_per_launch': bytes_per_launch,

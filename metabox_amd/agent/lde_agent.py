@@ -34,7 +34,7 @@ class PolicyNet(nn.Module):
     def act_batch(self, states, h, c):
         """states [B, NP+10] float32, h/c [1, B, 50] -> actions [B, 2NP], h', c'."""
         mu, sigma, h_, c_ = self.forward(states[None], h, c)
-        return torch.clip(torch.normal(mu[0], sigma[0]), 0, 1), h_, c_
+        return torch.clip(mu[0] + sigma[0] * torch.randn_like(mu[0]), 0, 1), h_, c_
 
 
 _REF_KEYS = {'net/_PolicyNet__lstm.': 'lstm.', 'net/_PolicyNet__mu.': 'mu.', 'net/_PolicyNet__sigma.': 'sigma.'}

@@ -47,7 +47,9 @@ class Actor(nn.Module):
     def act_batch(self, states):
         """[B, 1] float32 -> [B, 35] float32 actions for B independent environments."""
         mu, sigma = self.distribution(states)
-        return torch.clamp(torch.normal(mu, sigma), min=0, max=1)
+        # mu + sigma * eps == Normal(mu, sigma).sample(); unlike torch.normal(tensor, tensor) it has no host-side check and
+        # can be captured into a hipGraph
+        return torch.clamp(mu + sigma * torch.randn_like(mu), min=0, max=1)
 
 
 class Critic(nn.Module):

@@ -36,9 +36,9 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP);
-    // PB, X, T: NE each; Z: SC; M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each;
-    // COEF: 6*16; RED: 16; 3 int arrays
-    return 3 * NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
+    // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC; M1T, M2T;
+    // DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each; COEF: 6*16; RED: 16; 2 int arrays
+    return 2 * NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 2 * align2((P + 1) / 2);
 }
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
@@ -47,9 +47,8 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
                   P = align2(NP);
     RlLds L;
     double* p = base;
-    L.PB = p; p += NE;
+    L.PB = p; L.T = p; p += NE;      // T reuses PB's storage (see rl_commit)
     L.X = p; p += NE;
-    L.T = p; p += NE;
     L.Z = p; p += SC;
     L.M1T = p; p += DD;
     L.M2T = p; p += DD;
@@ -69,8 +68,8 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
     L.COEF = p; p += 96;
     L.RED = p; p += 16;
     L.IMPR = (int*)p; p += align2((P + 1) / 2);
-    L.MASK = (int*)p; p += align2((P + 1) / 2);
-    L.DIRTY = (int*)p;
+    L.MASK = (int*)p;
+    L.DIRTY = nullptr;
     return L;
 }
 
@@ -100,14 +99,15 @@ __device__ __forceinline__ void rl_costs(const DevProblem& P, const RlLds& L, in
 // pbest / gbest bookkeeping shared by update() and __reinit() (rlepso_optimizer.py:200-222, 145-168).
 // Candidate positions are in L.X, their costs in L.NC.  `stagnation` additionally updates per_no_improve
 // against the previous c_cost (:225-233), which only update() does.
-__device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool stagnation, double& gbest, int& gbest_idx)
+__device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool stagnation, double& gbest, int& gbest_idx,
+                                          double* __restrict__ gPB)
 {
     const int tid = threadIdx.x;
     for (int i = tid; i < NP; i += kThreads) {
         const double nc = L.NC[i];
         if (stagnation) L.PNI[i] = nc < L.CC[i] ? 0. : L.PNI[i] + 1;
         const int impr = nc < L.PBC[i];
-        if (impr) { L.PBC[i] = nc; L.DIRTY[i] = 1; }
+        if (impr) L.PBC[i] = nc;
         L.IMPR[i] = impr;
         L.CC[i] = nc;
     }
@@ -118,7 +118,7 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
     const int NE = NP * D;
     for (int e = tid; e < NE; e += kThreads) {
         const int i = e / D;
-        if (L.IMPR[i]) L.PB[e] = L.X[e];
+        if (L.IMPR[i]) gPB[e] = L.X[e];                // pbest_position <- new position, straight to HBM
     }
     if (better && tid < D) L.GB[tid] = L.X[cb * D + tid];
     __syncthreads();
@@ -211,12 +211,10 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
 
     // ---- stage: pbest positions/costs, c_cost, stagnation counters, gbest position, linear maps
     const double* gPB = S + MBX_RLEPSO_ST_PBPOS(NP, D);
-    for (int e = tid; e < NE; e += kThreads) L.PB[e] = gPB[e];
     for (int i = tid; i < NP; i += kThreads) {
         L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
         L.CC[i] = S[MBX_RLEPSO_ST_CCOST(NP, D) + i];
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
-        L.DIRTY[i] = 0;
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
     stage_problem(P, L.eval());
@@ -238,20 +236,37 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     __syncthreads();
     const int per_group = NP / G;
     const double pci_den = m_exp(10.) - 1;
+    int* ORDER = L.IMPR;          // both int arrays are free until the first commit
+    int* NLESS = L.MASK;
+    int* RANK = reinterpret_cast<int*>(L.Z);   // evaluator scratch, free until eval
     for (int i = tid; i < NP; i += kThreads) {                    // per-particle quantities
         const int g = i / per_group;
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
         L.PCI[i] = 0.05 + 0.45 * m_exp(10. * i / (NP - 1)) / pci_den;   // learning probability curve (:23-24)
         if (tape) { L.R1[i] = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; L.R2[i] = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i]; }
         else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w); }
+        // position of particle i in the (pbest cost, index) order and the number of strictly better particles
+        const double fi = L.PBC[i];
+        int rank = 0, nless = 0;
+        for (int j = 0; j < NP; ++j) {
+            const double fj = L.PBC[j];
+            nless += fj < fi;
+            rank += (fj < fi) || (fj == fi && j < i);
+        }
+        ORDER[rank] = i; RANK[i] = rank; NLESS[i] = nless; L.NC[rank] = fi;   // NC: pbest costs in ascending order (free until eval)
     }
     __syncthreads();
+    // pbest positions are staged in RANK order (row r = particle ORDER[r]): the FDR scan below then walks LDS linearly
+    for (int e = tid; e < NE; e += kThreads) { const int i = e / D, d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
+    __syncthreads();
 
-    // ---- velocity / position update, one element per thread-iteration (:179-195)
+    // ---- velocity / position update, one element per thread-iteration (:179-195).  Elements are visited in pbest-rank
+    // order so that the lanes of a wave own particles of similar rank (see the FDR scan below).
     double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
     double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
-    for (int e = tid; e < NE; e += kThreads) {
-        const int i = e / D, d = e - i * D;
+    for (int es = tid; es < NE; es += kThreads) {
+        const int rk = es / D, d = es - rk * D;
+        const int i = ORDER[rk], e = i * D + d;
         const double r1 = L.R1[i], r2 = L.R2[i];
         double uc, uf; int t1, t2;
         if (tape) {
@@ -263,29 +278,37 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
             t1 = (int)__umulhi(w.z, (uint32_t)NP); t2 = (int)__umulhi(w.w, (uint32_t)NP);
             w = rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf = u53(w.x, w.y);
         }
-        const double cur = gPos[e], pp = L.PB[e], fi = L.PBC[i];
+        const double cur = gPos[e], pp = L.PB[es], fi = L.PBC[i];
         // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
         const double pci = L.PCI[i];
         const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
-        const double exemplar = uc > pci ? pp : L.PB[tw * D + d];
+        const double exemplar = uc > pci ? pp : L.PB[RANK[tw] * D + d];
         const double v_clpso = uc * (exemplar - cur);
         // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109).
-        // Ratios are compared by cross-multiplication (denominators are >= 1e-5 > 0): a_j/b_j < a*/b*  <=>
-        // a_j b* < a* b_j.  Exactly equal ratios give exactly equal products, so np.argmin's first-index rule is
-        // preserved; only ratios that differ by ~1 ulp could order differently from the rounded quotients.
-        int jb = 0;
-        double ab = L.PBC[0] - fi, bb = fabs(L.PB[d] - pp) + 1e-5;
-#ifdef MBX_ABLATE_FDR
-        for (int j = 1; j < 2; ++j) {
-#else
+        //  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
+        //    among the strictly better particles (negative ratios) if there are any, otherwise it is 0 and np.argmin
+        //    returns the lowest index with pbest_j == pbest_i.  Only the `nless` better particles are scanned, in
+        //    ascending-cost order (ORDER / NC), halving the O(NP^2 D) work on average.
+        //  * ratios are compared by cross-multiplication (denominators >= 1e-5 > 0): a_j/b_j < a*/b* <=> a_j b* < a* b_j.
+        //    Identical candidates (same pbest cost and same coordinate) are adjacent in the (cost, index) order, so the
+        //    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
+        //    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
+        const int nless = NLESS[i];
+        int kb = nless;                                             // rank of the exemplar
+#ifndef MBX_ABLATE_FDR
+        if (nless > 0) {
+            kb = 0;
+            double ab = L.NC[0] - fi, bb = fabs(L.PB[d] - pp) + 1e-5;
+            const double* col = L.PB + d;
 #pragma unroll 4
-        for (int j = 1; j < NP; ++j) {
-#endif
-            const double a = L.PBC[j] - fi;
-            const double b = fabs(L.PB[j * D + d] - pp) + 1e-5;
-            if (a * bb < ab * b) { ab = a; bb = b; jb = j; }
+            for (int k = 1; k < nless; ++k) {
+                const double a = L.NC[k] - fi;
+                const double b = fabs(col[k * D] - pp) + 1e-5;
+                if (a * bb < ab * b) { ab = a; bb = b; kb = k; }
+            }
         }
-        const double v_fdr = uf * (L.PB[jb * D + d] - pp);
+#endif
+        const double v_fdr = uf * (L.PB[kb * D + d] - pp);
         const double v_pbest = r1 * (pp - cur);
         const double v_gbest = r2 * (L.GB[d] - cur);
         const int g = i / per_group;
@@ -304,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
     rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
-    rl_commit(L, NP, D, true, gbest, gbest_idx);
+    rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D));
 
     // ---- re-initialisation (:238-239, 134-168): P(i) = u < c_mutation_i * 0.01 * per_no_improve_i
     int mine = 0;
@@ -334,15 +357,10 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         // the whole population is re-evaluated but only the re-initialised particles are billed (:141-143)
         rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
         fes += n_reinit;
-        rl_commit(L, NP, D, false, gbest, gbest_idx);
+        rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D));
     }
 
     // ---- write back what changed
-    double* gPBw = S + MBX_RLEPSO_ST_PBPOS(NP, D);
-    for (int e = tid; e < NE; e += kThreads) {
-        const int i = e / D;
-        if (L.DIRTY[i]) gPBw[e] = L.PB[e];
-    }
     for (int i = tid; i < NP; i += kThreads) {
         S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = L.PBC[i];
         S[MBX_RLEPSO_ST_CCOST(NP, D) + i] = L.CC[i];
