@@ -26,7 +26,7 @@ constexpr int kDqRec = 820;
 __host__ __device__ inline int64_t dq_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
-    return 2 * NE + SC + 2 * DD + 4 * align2(D) + 2 * P + kDqRec + 100 + 16 + 16 + 2 * align2(D);
+    return NE + eval_t_doubles(NP, D) + SC + 2 * DD + 4 * align2(D) + 2 * P + kDqRec + 100 + 16 + 16 + 2 * align2(D);
 }
 
 __device__ __forceinline__ DqLds dq_carve(double* base, int NP, int D)
@@ -34,7 +34,7 @@ __device__ __forceinline__ DqLds dq_carve(double* base, int NP, int D)
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
     DqLds L;
     double* p = base;
-    L.X = p; p += NE;  L.T = p; p += NE;  L.Z = p; p += SC;  L.M1T = p; p += DD;  L.M2T = p; p += DD;
+    L.X = p; p += NE;  L.T = p; p += eval_t_doubles(NP, D);  L.Z = p; p += SC;  L.M1T = p; p += DD;  L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
     L.NC = p; p += P;  L.COST = p; p += P;  L.REC = p; p += kDqRec;  L.FEAT = p; p += 100;  L.RED = p; p += 16;  L.MISC = p;
     return L;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void dq_features(const DevProblem& P, const DqLds& L,
 __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D;
     const DevProblem P = bp.problems[bp.problem_idx[b]];
     const DqLds L = dq_carve(smem, NP, D);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
                                                       double* __restrict__ reward_out, uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D;
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_DQ_ST_SCALARS(NP, D);

@@ -21,7 +21,7 @@ __host__ __device__ inline int64_t lde_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP), PI = align2((P + 1) / 2);
-    return 3 * NE + SC + 2 * DD + 4 * align2(D) + 6 * P + 16 + 8 + 4 * PI + 8;
+    return 2 * NE + eval_t_doubles(NP, D) + SC + 2 * DD + 4 * align2(D) + 6 * P + 16 + 8 + 4 * PI + 8;
 }
 
 __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
@@ -30,7 +30,7 @@ __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
                   P = align2(NP), PI = align2((P + 1) / 2);
     LdeLds L;
     double* p = base;
-    L.P = p; p += NE;  L.X = p; p += NE;  L.T = p; p += NE;  L.Z = p; p += SC;
+    L.P = p; p += NE;  L.X = p; p += NE;  L.T = p; p += eval_t_doubles(NP, D);  L.Z = p; p += SC;
     L.M1T = p; p += DD;  L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
     L.FIT = p; p += P;  L.NC = p; p += P;  L.SF = p; p += P;  L.CR = p; p += P;  L.ONEM = p; p += P;  L.SORTED = p; p += P;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
 __global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D;
     const DevProblem P = bp.problems[bp.problem_idx[b]];
     const LdeLds L = lde_carve(smem, NP, D);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
                                                        uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D;
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_LDE_ST_SCALARS(NP, D);

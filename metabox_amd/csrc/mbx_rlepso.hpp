@@ -20,6 +20,7 @@ struct BatchParams {
     int64_t state_stride;
     const double* tape;          // nullptr -> Philox
     int64_t tape_stride;
+    const int32_t* order;        // launch order: workgroup w owns instance order[w] (most expensive objectives first)
     int32_t NP, D, max_fes, log_interval, n_logpoint, early_stop, n_group, B;
 };
 
@@ -35,19 +36,19 @@ __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_
 __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
-                  P = align2(NP);
+                  P = align2(NP), TS = eval_t_doubles(NP, D);
     // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC; M1T, M2T;
     // DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each; COEF: 6*16; RED: 16; 2 int arrays
-    return 2 * NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 2 * align2((P + 1) / 2);
+    return TS + NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 2 * align2((P + 1) / 2);
 }
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
-                  P = align2(NP);
+                  P = align2(NP), TS = eval_t_doubles(NP, D);
     RlLds L;
     double* p = base;
-    L.PB = p; L.T = p; p += NE;      // T reuses PB's storage (see rl_commit)
+    L.PB = p; L.T = p; p += TS;      // T reuses PB's storage (see rl_commit)
     L.X = p; p += NE;
     L.Z = p; p += SC;
     L.M1T = p; p += DD;
@@ -130,7 +131,7 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
 __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D;
     const DevProblem P = bp.problems[bp.problem_idx[b]];
     const RlLds L = rl_carve(smem, NP, D);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
                                                           uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D, G = bp.n_group;
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_RLEPSO_ST_SCALARS(NP, D);

@@ -10,7 +10,7 @@ namespace mbx {
 __host__ __device__ inline int64_t rs_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D);
-    return 2 * NE + SC + 2 * DD + 4 * align2(D) + align2(NP) + 16;
+    return NE + eval_t_doubles(NP, D) + SC + 2 * DD + 4 * align2(D) + align2(NP) + 16;
 }
 
 // `first` = 1: the initial population of run_episode's __reset (:24-29); 0: one more population (:45-46)
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_population(BatchParams bp, int 
                                                             double* __restrict__ reward_out, uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D;
     double* sc = bp.state + (int64_t)b * bp.state_stride;
     if (!first && sc[MBX_SC_DONE] != 0.) {
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_population(BatchParams bp, int 
     }
     const DevProblem P = bp.problems[bp.problem_idx[b]];
     const int64_t NEa = align2((int64_t)NE), SC = align2(NEa > 2 * kThreads ? NEa : 2 * kThreads), DD = align2((int64_t)D * D), DV = align2(D);
-    double* X = smem; double* T = X + NEa; double* Z = T + NEa; double* M1T = Z + SC; double* M2T = M1T + DD; double* VEC = M2T + DD;
+    double* X = smem; double* T = X + NEa; double* Z = T + eval_t_doubles(NP, D); double* M1T = Z + SC; double* M2T = M1T + DD; double* VEC = M2T + DD;
     double* NC = VEC + 4 * DV; double* RED = NC + align2(NP);
     const EvalLds L{X, Z, T, M1T, M2T, VEC, VEC + DV, VEC + 2 * DV, VEC + 3 * DV, NC};
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
