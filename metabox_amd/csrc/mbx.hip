@@ -373,9 +373,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
             const int k = s->h_problems[pi].kind;
             switch (k) {
             case MBX_KIND_PROTEIN: return 3000;
-            case 21: return 670; case 16: return 390; case 15: return 320; case 17: case 18: return 317; case 3: return 309;
-            case 22: return 290; case 4: return 284; case 2: case 10: case 11: return 276; case 23: return 267;
-            case 12: return 246; case 14: return 240; case 5: return 188; default: return 225;
+            case 16: case 21: return 390; case 15: return 322; case 17: case 18: return 319; case 3: return 310;
+            case 4: return 285; case 2: case 10: case 11: return 277; case 23: return 268; case 22: return 263;
+            case 12: return 248; case 14: return 241; case 5: return 188; default: return 225;
             }
         };
         std::vector<int32_t> order(n_instances);

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Throughput of the other batched paths (BASELINE.json configs 3 and 4, one GPU's share), policy included.
+   python tools/kbench_algos.py [lde|ddqn|rs] """
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metabox_amd.config import get_config
+from metabox_amd.environment import BatchedPBO_Env
+from metabox_amd.utils import construct_problem_set
+
+def timed(fn, steps):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); fn(steps); torch.cuda.synchronize(); return time.perf_counter() - t0
+
+which = sys.argv[1:] or ['lde', 'ddqn', 'rs']
+if 'lde' in which:
+    from metabox_amd.agent import LDE_Agent
+    from metabox_amd.optimizer import LDE_Optimizer
+    cfg = get_config(['--problem', 'bbob-noisy', '--dim', '30', '--device', 'cuda']); cfg.agent_save_dir = None
+    agent = LDE_Agent(cfg).load_exported_weights(np.load(os.path.join(os.path.dirname(__file__), '..', 'metabox_amd', 'agent_model', 'lde_bbob_easy.npz'))).to('cuda')
+    opt = LDE_Optimizer(cfg)
+    tr, te = construct_problem_set(cfg); ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+    B = 16384
+    env = BatchedPBO_Env(ps, opt, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1)
+    state = env.reset(); h = torch.zeros(1, B, 50, device='cuda'); c = torch.zeros(1, B, 50, device='cuda')
+    def run(n):
+        global state, h, c
+        with torch.no_grad():
+            for _ in range(n):
+                a, h, c = agent.net.act_batch(state.to(torch.float32), h, c)
+                state, _, _ = env.step(a.contiguous())
+    run(5); dt = timed(run, 60)
+    live = int((env.results()['steps'] > 0).sum())
+    print(json.dumps({'path': 'LDE bbob-noisy d=30 NP=50 (reference population), 16384 instances, LSTM policy via PyTorch', 'ms_per_step': dt / 60 * 1e3, 'env_steps_per_s': B * 60 / dt}))
+    env.close()
+if 'ddqn' in which:
+    from metabox_amd.agent import DE_DDQN_Agent
+    from metabox_amd.optimizer import DE_DDQN_Optimizer
+    cfg = get_config(['--problem', 'protein', '--device', 'cuda']); cfg.agent_save_dir = None
+    torch.manual_seed(0)
+    agent = DE_DDQN_Agent(cfg).to('cuda'); opt = DE_DDQN_Optimizer(cfg)
+    tr, te = construct_problem_set(cfg); ps = (tr + te).data[:35]            # one GPU's share of config 4: 35 problems x 64 runs
+    B = 35 * 64
+    env = BatchedPBO_Env(ps, opt, np.repeat(np.arange(35), 64), np.arange(B, dtype=np.uint64) + 1)
+    state = env.reset()
+    def run(n):
+        global state
+        with torch.no_grad():
+            for _ in range(n):
+                a = torch.argmax(agent.q_net(state.to(torch.float32)), dim=1).to(torch.int32)
+                state, _, _ = env.step(a.contiguous())
+    run(5); dt = timed(run, 200)
+    print(json.dumps({'path': 'DE-DDQN protein d=12 NP=100, 2240 instances (35 problems x 64 runs), Q-net via PyTorch', 'ms_per_step': dt / 200 * 1e3, 'env_steps_per_s': B * 200 / dt}))
+    env.close()
+if 'rs' in which:
+    from metabox_amd.optimizer import Random_search
+    from metabox_amd.suite import Suite
+    cfg = get_config(['--problem', 'bbob', '--dim', '10'])
+    tr, te = construct_problem_set(cfg); ps = (tr + te).data
+    s = Suite(ps); B = 24 * 51
+    rs = Random_search(cfg)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); rs.run_batch(s, np.repeat(np.arange(24), 51), np.arange(B)); dt = time.perf_counter() - t0
+    print(json.dumps({'path': 'Random_search baseline epoch: 24 bbob problems x 51 runs, 199 populations each', 'seconds': dt}))
