@@ -107,6 +107,8 @@ def main():
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph-policy', action='store_true', help='replay the policy as one hipGraph instead of launching it op by op')
+    ap.add_argument('--table-policy', action='store_true', help='gather (mu, sigma) from the per-fes table (the actor evaluated once '
+                    'at every reachable state) instead of evaluating the two actor MLPs every generation; NOT the headline setting')
     ap.add_argument('--dist-backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses cuda:0')
     args = ap.parse_args()
@@ -144,6 +146,10 @@ def main():
     seeds = (gid // len(ps)).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
     env = BatchedPBO_Env(ps, optimizer, pidx, seeds, early_stop=True)
     actor = agent.actor
+    table = agent.actor_table(MAXFES, NP_, dev)
+
+    def policy(st):
+        return table.act(st) if args.table_policy else actor.act_batch(st.to(torch.float32))
 
     def steps_sum():
         return int(env.results()['steps'].sum().item())
@@ -168,11 +174,11 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(3):
-                static_actions = actor.act_batch(state.to(torch.float32))
+                static_actions = policy(state)
         torch.cuda.current_stream().wait_stream(side)
         policy_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(policy_graph), torch.no_grad():
-            static_actions = actor.act_batch(state.to(torch.float32))
+            static_actions = policy(state)
     gen_in_ep, live, base = 0, 0, 0
     t0 = None
     with torch.no_grad():
@@ -193,7 +199,7 @@ def main():
                 policy_graph.replay()
                 actions = static_actions
             else:
-                actions = actor.act_batch(state.to(torch.float32))
+                actions = policy(state)
             if it >= W:
                 ev0[it - W].record()
             state, _, _ = env.step(actions)
@@ -228,7 +234,9 @@ def main():
                                    f'(24 bbob functions round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
                        'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}',
-                       'policy_launch': 'hipGraph replay' if args.graph_policy else 'eager (asynchronous, overlapped with the generation kernel)'},
+                       'policy_launch': 'hipGraph replay' if args.graph_policy else 'eager (asynchronous, overlapped with the generation kernel)',
+                       'policy_eval': '(mu, sigma) gathered from a table of the actor evaluated once at every reachable state fes/maxFEs'
+                       if args.table_policy else 'both actor MLPs evaluated every generation over the whole batch (3 batched GEMMs)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_rlepso_step',
                          'algorithmic_bytes_per_launch': bytes_per_launch,

@@ -43,13 +43,59 @@ class Actor(nn.Module):
             return action, log_prob, policy.entropy()
         return action, log_prob
 
+    def _fused_weights(self):
+        """The mu- and sigma-networks share their input and their shapes, so one generation needs 3 (batched) GEMMs instead
+        of 6: layer 1 of both nets is one [1 -> 128] affine map, layers 2 and 3 are 2-batch bmm's."""
+        key = tuple(p.data_ptr() for p in self.parameters()) + (str(next(self.parameters()).device),)
+        if getattr(self, '_fw_key', None) != key:
+            nets = (self.mu_net.net, self.sigma_net.net)
+            lin = [[n._modules[f'layer{i}-linear'] for n in nets] for i in range(3)]
+            self._fw = dict(
+                w1=torch.cat([l.weight[:, 0] for l in lin[0]])[None, :].contiguous(), b1=torch.cat([l.bias for l in lin[0]])[None, :].contiguous(),
+                w2=torch.stack([l.weight.t() for l in lin[1]]).contiguous(), b2=torch.stack([l.bias for l in lin[1]])[:, None, :].contiguous(),
+                w3=torch.stack([l.weight.t() for l in lin[2]]).contiguous(), b3=torch.stack([l.bias for l in lin[2]])[:, None, :].contiguous())
+            self._fw_key = key
+        return self._fw
+
     @torch.no_grad()
     def act_batch(self, states):
-        """[B, 1] float32 -> [B, 35] float32 actions for B independent environments."""
-        mu, sigma = self.distribution(states)
+        """[B, 1] float32 -> [B, 35] float32 actions for B independent environments (both MLPs evaluated every call)."""
+        f = self._fused_weights()
+        B = states.shape[0]
+        h = torch.relu_(torch.addcmul(f['b1'], states, f['w1']))                    # [B, 128]
+        h = h.view(B, 2, -1).transpose(0, 1)                                        # [2, B, 64]
+        h = torch.relu_(torch.baddbmm(f['b2'], h, f['w2']))                         # [2, B, 32]
+        t = torch.tanh_(torch.baddbmm(f['b3'], h, f['w3']))                         # [2, B, 35]
+        mu = (t[0] + 1.) / 2.
+        sigma = (t[1] + 1.) / 2. * (self.max_sigma - self.min_sigma) + self.min_sigma
         # mu + sigma * eps == Normal(mu, sigma).sample(); unlike torch.normal(tensor, tensor) it has no host-side check and
         # can be captured into a hipGraph
-        return torch.clamp(mu + sigma * torch.randn_like(mu), min=0, max=1)
+        return torch.addcmul(mu, sigma, torch.randn_like(mu)).clamp_(0, 1)
+
+
+class ActorTable:
+    """Batched sampling for the RLEPSO actor.
+
+    The optimizer's state is the scalar fes/maxFEs (rlepso_optimizer.py:170-171) and fes is an integer below
+    maxFEs + 2 NP, so (mu, sigma) take at most that many distinct values.  They are evaluated ONCE with one batched
+    forward over every possible state; a generation then costs one row gather and the Normal sampling instead of two
+    3-layer MLPs over the whole instance batch (~23 small kernels -> 5).  Same float32 arithmetic, same weights."""
+
+    def __init__(self, actor, max_fes, np_, device):
+        self.max_fes = int(max_fes)
+        k = torch.arange(0, self.max_fes + 2 * int(np_) + 2, dtype=torch.float64, device=device)
+        with torch.no_grad():
+            mu, sigma = actor.distribution((k / self.max_fes).to(torch.float32)[:, None])
+        self.table = torch.cat([mu, sigma], dim=1).contiguous()        # [K, 2*action_dim]
+        self.adim = mu.shape[1]
+
+    @torch.no_grad()
+    def act(self, state):
+        """state: [B, 1] float64 device tensor (fes/maxFEs) -> [B, action_dim] float32 actions."""
+        idx = torch.round(state[:, 0] * self.max_fes).to(torch.int64).clamp_(0, self.table.shape[0] - 1)
+        ms = self.table.index_select(0, idx)
+        mu, sigma = ms[:, :self.adim], ms[:, self.adim:]
+        return torch.addcmul(mu, sigma, torch.randn_like(mu)).clamp_(0, 1)
 
 
 class Critic(nn.Module):
@@ -103,6 +149,13 @@ class RLEPSO_Agent(Basic_Agent):
     def critic(self):
         return self.__critic
 
+    def actor_table(self, max_fes, np_, device):
+        key = (int(max_fes), int(np_), str(device))
+        cache = self.__dict__.setdefault('_tables', {})
+        if key not in cache:
+            cache[key] = ActorTable(self.__actor, max_fes, np_, device)
+        return cache[key]
+
     def load_exported_weights(self, npz):
         """Load the arrays exported from a reference checkpoint by tools/gen_golden.py (`policy` section)."""
         sd_a, sd_c = {}, {}
@@ -112,6 +165,7 @@ class RLEPSO_Agent(Basic_Agent):
                     (sd_c if pre.startswith('critic') else sd_a)[new + k[len(pre):]] = torch.as_tensor(np.asarray(npz[k]))
         self.__actor.load_state_dict(sd_a)
         self.__critic.load_state_dict(sd_c)
+        self.__dict__['_tables'] = {}
         return self
 
     def to(self, device):
@@ -119,6 +173,7 @@ class RLEPSO_Agent(Basic_Agent):
         self.__config.device = device
         self.__actor.to(device)
         self.__critic.to(device)
+        self.__dict__['_tables'] = {}
         return self
 
     def update_setting(self, config):
@@ -144,18 +199,20 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None):
-        """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.
+    def rollout_batch(self, env, max_steps=None, use_table=True):
+        """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.  ``use_table=False`` evaluates the two actor
+        MLPs every generation instead of gathering (mu, sigma) from the per-fes table (same numbers, more launches).
 
         Every update() bills at least NP evaluations, so after ceil((maxFEs-NP)/NP) generations every instance has
         reached ``fes >= maxFEs``; instances that finish earlier idle inside the kernel.
         """
+        bc = env.batch.cfg                           # the optimizer's own NP / maxFEs (it may differ from the agent's config copy)
         if max_steps is None:
-            bc = env.batch.cfg                       # the optimizer's own NP / maxFEs (it may differ from the agent's config copy)
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
+        table = self.actor_table(bc.max_fes, bc.np, env.batch.device)
         state = env.reset()
         for _ in range(max_steps):
-            actions = self.__actor.act_batch(state.to(torch.float32))
+            actions = table.act(state) if use_table else self.__actor.act_batch(state.to(torch.float32))
             state, _, _ = env.step(actions)
         res = env.results()
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],

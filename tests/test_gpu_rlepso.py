@@ -171,3 +171,38 @@ def test_full_batch_properties(env):
         assert np.array_equal(full[k][half], part[k]), k              # results do not depend on batch position/size
     assert np.all(full['steps'] == 12) or np.all(full['steps'] <= 12)
     assert np.all(full['fes'] >= 100 + 100 * full['steps'])
+
+
+def test_actor_table_equals_mlp_forward():
+    """The per-fes (mu, sigma) table used by rollout_batch reproduces the actor's forward (PyTorch fp32 reference) and
+    the reference's recorded (state -> mu, sigma) pairs."""
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    from metabox_amd.config import get_config
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    pol = load('rlepso_policy.npz')
+    agent = RLEPSO_Agent(cfg).load_exported_weights(pol).to('cuda')
+    with torch.no_grad():
+        mu, sg = agent.actor.distribution(torch.from_numpy(pol['io/state']).cuda())
+    assert np.allclose(mu.cpu().numpy(), pol['io/mu'], atol=2e-6) and np.allclose(sg.cpu().numpy(), pol['io/sigma'], atol=2e-6)
+    tab = agent.actor_table(20000, 100, torch.device('cuda', 0))
+    fes = torch.tensor([100., 200., 4321., 19999., 20000., 20043.], dtype=torch.float64, device='cuda')
+    with torch.no_grad():
+        want_mu, want_sg = agent.actor.distribution((fes / 20000).to(torch.float32)[:, None])
+    got = tab.table.index_select(0, fes.long())
+    assert torch.allclose(got[:, :35], want_mu, atol=2e-6) and torch.allclose(got[:, 35:], want_sg, atol=2e-6)
+    # the fused 3-GEMM forward used per generation == the module-by-module forward
+    st = torch.rand(257, 1, device='cuda')
+    with torch.no_grad():
+        m0, s0 = agent.actor.distribution(st)
+    torch.manual_seed(5); eps = torch.randn_like(m0)
+    torch.manual_seed(5); got_a = agent.actor.act_batch(st)
+    assert torch.allclose(got_a, torch.clamp(m0 + s0 * eps, 0, 1), atol=3e-6)
+    torch.manual_seed(0)
+    a = tab.act((fes / 20000)[:, None])
+    assert a.shape == (6, 35) and a.dtype == torch.float32 and float(a.min()) >= 0 and float(a.max()) <= 1
+    # sampling statistics: mean of many draws approaches clamp-free mu where sigma is small
+    big = tab.act((fes[:1] / 20000).repeat(20000)[:, None])
+    tight = want_sg[0] < 0.05
+    if tight.any():
+        assert torch.allclose(big.mean(0)[tight], want_mu[0][tight].clamp(0, 1), atol=5e-3)
