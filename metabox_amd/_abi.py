@@ -80,6 +80,12 @@ def load_lib():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get('MBX_LIB'):
+        # a fresh checkout (built artefacts are not in git): build in-tree once, exactly like __graft_entry__.build()
+        import shutil
+        import subprocess
+        if shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc'):
+            subprocess.call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s'])
     if not os.path.exists(LIB_PATH):
         raise MbxError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                        f'(hipcc --offload-arch=gfx950). metabox_amd has no CPU fallback.')

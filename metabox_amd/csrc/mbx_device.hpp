@@ -40,6 +40,15 @@ struct DevProblem {
     const double* plogw; // Gallagher: log(w_k), precomputed at upload
 };
 
+// Division of small non-negative integers by a loop-invariant divisor without the ~35-instruction software divide:
+// e / D == umulhi(e, floor((2^32-1)/D) + 1) for e < 2^20, D <= 256 (checked exhaustively on the host).
+struct FastDiv {
+    uint32_t m; int D;
+    __device__ __forceinline__ explicit FastDiv(int D_) : m(0xFFFFFFFFu / (uint32_t)D_ + 1u), D(D_) {}
+    __device__ __forceinline__ int div(int e) const { return (int)__umulhi((uint32_t)e, m); }
+    __device__ __forceinline__ int mod(int e) const { return e - div(e) * D; }
+};
+
 // ------------------------------------------------------------------------------------------------ Philox
 struct U4 { uint32_t x, y, z, w; };
 
@@ -65,7 +74,11 @@ struct Rng {                      // per-instance stream: key = seed, counter = 
     uint32_t k0, k1, gen, episode;
     __device__ __forceinline__ U4 draw(uint32_t idx, uint32_t site) const
     {
+#ifdef MBX_ABLATE_RNG
+        return U4{idx * 2654435761u, site + 0x9E3779B9u * idx, gen ^ (idx << 7), episode + idx};   // timing experiments only
+#else
         return philox4x32_10(idx, site, gen, episode, k0, k1);
+#endif
     }
 };
 
@@ -201,8 +214,9 @@ struct EvalLds {
 __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds& L)
 {
     const int D = P.dim;
+    const FastDiv fd(D);
     for (int t = threadIdx.x; t < D * D; t += kThreads) {
-        const int d = t / D, k = t - d * D;
+        const int d = fd.div(t), k = t - d * D;
         if (P.m1) L.M1T[k * D + d] = P.m1[t];
         if (P.m2) L.M2T[k * D + d] = P.m2[t];
     }
@@ -218,8 +232,9 @@ __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds
 __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, int n, int D, double* Out)
 {
     const int NE = n * D;
+    const FastDiv fd(D);
     for (int e = threadIdx.x; e < NE; e += kThreads) {
-        const int i = e / D, d = e - i * D;
+        const int i = fd.div(e), d = e - i * D;
         const double* row = In + i * D;
         const double* col = MT + d;
         double s = 0.;
@@ -305,13 +320,14 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
     const double* v1 = L.V1;
     const double* v2 = L.V2;
     const double* dsh = L.DSH;
+    const FastDiv fd(D);
 
     // ---- phase A: first linear map  z = M1 (x - dshift)   (Gallagher: M1 x, the peaks are pre-rotated)
     const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
     if (first_map) {
         const bool gall = kind == 21 || kind == 22;
         if (!gall) {
-            for (int e = tid; e < NE; e += kThreads) { const int d = e % D; T[e] = X[e] - dsh[d]; }
+            for (int e = tid; e < NE; e += kThreads) { const int d = fd.mod(e); T[e] = X[e] - dsh[d]; }
             __syncthreads();
         }
         matvec_rows(M1T, gall ? X : T, n, D, Z);
@@ -363,7 +379,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
     } else {
         const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
         for (int e = tid; e < NE; e += kThreads) {
-            const int d = e % D;
+            const int d = fd.mod(e);
             switch (kind) {
             case 2: case 10: { const double o = osc1(Z[e]); T[e] = v0[d] * (o * o); break; }
             case 3: { const double z = v0[d] * asy1(osc1(Z[e]), v1[d]); Z[e] = z; T[e] = m_cos(kTwoPi * z); break; }
@@ -438,7 +454,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         }
     } else if (kind == 17 || kind == 18) {                          // Schaffers, bbob.py:642-643
         for (int e = tid; e < NE; e += kThreads) {
-            const int d = e % D;
+            const int d = fd.mod(e);
             if (d < D - 1) {
                 const double s = sqrt(Z[e] * Z[e] + Z[e + 1] * Z[e + 1]);
                 T[e] = sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1);
@@ -446,7 +462,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         }
     } else if (kind == 19) {                                        // Griewank-Rosenbrock, bbob.py:702-703
         for (int e = tid; e < NE; e += kThreads) {
-            const int d = e % D;
+            const int d = fd.mod(e);
             if (d < D - 1) {
                 const double a = Z[e] * Z[e] - Z[e + 1];
                 const double b = 1. - Z[e];
@@ -456,7 +472,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         }
     } else if (kind == 20) {                                        // Schwefel, bbob.py:754-756
         for (int e = tid; e < NE; e += kThreads) {
-            const int d = e % D;
+            const int d = fd.mod(e);
             double zi = T[e];
             if (d > 0) zi += 0.25 * (T[e - 1] - v1[d - 1]);
             Z[e] = 100. * (v0[d] * (zi - v1[d]) + v1[d]);

@@ -105,8 +105,9 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
     }
     __syncthreads();
     const int NE = NP * D;
+    const FastDiv fd(D);
     for (int e = tid; e < NE; e += kThreads) {
-        const int i = e / D, d = e - i * D;
+        const int i = fd.div(e), d = e - i * D;
         gPop[L.PIDX[i] * D + d] = L.P[e];
     }
     lde_norm_hist(L.SORTED, NP, state_out, L.HIST);
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
     int my_hist = tid < MBX_LDE_BINS ? L.HIST[tid] : 0;
 
     // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
+    const FastDiv fd(D);
     for (int e = tid; e < NE; e += kThreads) {
-        const int i = e / D, d = e - i * D;
+        const int i = fd.div(e), d = e - i * D;
         double u;
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
         else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
         if (surv) L.FIT[i] = L.NC[i];
     }
     __syncthreads();
-    for (int e = tid; e < NE; e += kThreads) if (L.R0[e / D]) L.P[e] = L.X[e];
+    for (int e = tid; e < NE; e += kThreads) if (L.R0[fd.div(e)]) L.P[e] = L.X[e];
     double bsf_next; int bi;
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
     if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }

@@ -27,7 +27,7 @@ struct BatchParams {
 // LDS carve-up (all offsets in doubles; base is 16-byte aligned, every array starts 16-byte aligned)
 struct RlLds {
     double *PB, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *PBC, *CC, *NC, *PNI, *CMUT, *PCI, *R1, *R2, *GB, *COEF, *RED;
-    int *IMPR, *MASK, *DIRTY;
+    int *IMPR, *MASK, *RANK;
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
 
@@ -39,7 +39,7 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
                   P = align2(NP), TS = eval_t_doubles(NP, D);
     // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC; M1T, M2T;
     // DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each; COEF: 6*16; RED: 16; 2 int arrays
-    return TS + NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 2 * align2((P + 1) / 2);
+    return TS + NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
 }
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
@@ -69,8 +69,8 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
     L.COEF = p; p += 96;
     L.RED = p; p += 16;
     L.IMPR = (int*)p; p += align2((P + 1) / 2);
-    L.MASK = (int*)p;
-    L.DIRTY = nullptr;
+    L.MASK = (int*)p; p += align2((P + 1) / 2);
+    L.RANK = (int*)p;
     return L;
 }
 
@@ -117,8 +117,9 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
     const bool better = cbv < gbest;
     if (better) { gbest = cbv; gbest_idx = cb; }
     const int NE = NP * D;
+    const FastDiv fd(D);
     for (int e = tid; e < NE; e += kThreads) {
-        const int i = e / D;
+        const int i = fd.div(e);
         if (L.IMPR[i]) gPB[e] = L.X[e];                // pbest_position <- new position, straight to HBM
     }
     if (better && tid < D) L.GB[tid] = L.X[cb * D + tid];
@@ -212,8 +213,14 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
 
     // ---- stage: pbest positions/costs, c_cost, stagnation counters, gbest position, linear maps
     const double* gPB = S + MBX_RLEPSO_ST_PBPOS(NP, D);
+    double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
+    double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
+    // positions and velocities are parked in X / Z (both free until the new positions / the evaluation need them): every HBM
+    // read of the generation is issued up front, coalesced, and overlaps the ranking below
+    for (int e = tid; e < NE; e += kThreads) { L.X[e] = gPos[e]; L.Z[e] = gVel[e]; }
     for (int i = tid; i < NP; i += kThreads) {
         L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
+        L.IMPR[i] = 0; L.MASK[i] = 0;
         L.CC[i] = S[MBX_RLEPSO_ST_CCOST(NP, D) + i];
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
     }
@@ -236,37 +243,53 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     }
     __syncthreads();
     const int per_group = NP / G;
+    const FastDiv fd(D), fg(per_group);
     const double pci_den = m_exp(10.) - 1;
+    // ---- rank the particles by (pbest cost, index); all 256 threads take part: thread (i, part) counts over a slice of j
     int* ORDER = L.IMPR;          // both int arrays are free until the first commit
     int* NLESS = L.MASK;
-    int* RANK = reinterpret_cast<int*>(L.Z);   // evaluator scratch, free until eval
+    int* RANK = L.RANK;
+    {
+        const int parts = kThreads / NP > 0 ? kThreads / NP : 1;
+        for (int w = tid; w < parts * NP; w += kThreads) {
+            const int part = w / NP, i = w - part * NP;
+            const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
+            const double fi = L.PBC[i];
+            int rank = 0, nless = 0;
+#ifndef MBX_ABLATE_RANK
+#pragma unroll 4
+            for (int j = j0; j < j1; ++j) {
+                const double fj = L.PBC[j];
+                nless += fj < fi;
+                rank += (fj < fi) || (fj == fi && j < i);
+            }
+#else
+            if (part == 0) { rank = i; nless = i; }
+#endif
+            atomicAdd(&ORDER[i], rank); atomicAdd(&NLESS[i], nless);        // ORDER doubles as the rank accumulator
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NP; i += kThreads) RANK[i] = ORDER[i];
+    __syncthreads();
     for (int i = tid; i < NP; i += kThreads) {                    // per-particle quantities
-        const int g = i / per_group;
+        const int g = fg.div(i);
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
         L.PCI[i] = 0.05 + 0.45 * m_exp(10. * i / (NP - 1)) / pci_den;   // learning probability curve (:23-24)
         if (tape) { L.R1[i] = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; L.R2[i] = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i]; }
         else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w); }
-        // position of particle i in the (pbest cost, index) order and the number of strictly better particles
-        const double fi = L.PBC[i];
-        int rank = 0, nless = 0;
-        for (int j = 0; j < NP; ++j) {
-            const double fj = L.PBC[j];
-            nless += fj < fi;
-            rank += (fj < fi) || (fj == fi && j < i);
-        }
-        ORDER[rank] = i; RANK[i] = rank; NLESS[i] = nless; L.NC[rank] = fi;   // NC: pbest costs in ascending order (free until eval)
+        const int rank = RANK[i];
+        ORDER[rank] = i; L.NC[rank] = L.PBC[i];                    // NC: pbest costs in ascending order (free until eval)
     }
     __syncthreads();
     // pbest positions are staged in RANK order (row r = particle ORDER[r]): the FDR scan below then walks LDS linearly
-    for (int e = tid; e < NE; e += kThreads) { const int i = e / D, d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
+    for (int e = tid; e < NE; e += kThreads) { const int i = fd.div(e), d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
     __syncthreads();
 
     // ---- velocity / position update, one element per thread-iteration (:179-195).  Elements are visited in pbest-rank
     // order so that the lanes of a wave own particles of similar rank (see the FDR scan below).
-    double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
-    double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
     for (int es = tid; es < NE; es += kThreads) {
-        const int rk = es / D, d = es - rk * D;
+        const int rk = fd.div(es), d = es - rk * D;
         const int i = ORDER[rk], e = i * D + d;
         const double r1 = L.R1[i], r2 = L.R2[i];
         double uc, uf; int t1, t2;
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
             t1 = (int)__umulhi(w.z, (uint32_t)NP); t2 = (int)__umulhi(w.w, (uint32_t)NP);
             w = rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf = u53(w.x, w.y);
         }
-        const double cur = gPos[e], pp = L.PB[es], fi = L.PBC[i];
+        const double cur = L.X[e], pp = L.PB[es], fi = L.PBC[i];
         // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
         const double pci = L.PCI[i];
         const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
@@ -312,10 +335,10 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         const double v_fdr = uf * (L.PB[kb * D + d] - pp);
         const double v_pbest = r1 * (pp - cur);
         const double v_gbest = r2 * (L.GB[d] - cur);
-        const int g = i / per_group;
+        const int g = fg.div(i);
         double cw = 0., c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
         if (g < G) { const double* c = L.COEF + g * 6; cw = c[1]; c1 = c[2]; c2 = c[3]; c3 = c[4]; c4 = c[5]; }
-        double nv = cw * gVel[e] + c1 * v_clpso + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
+        double nv = cw * L.Z[e] + c1 * v_clpso + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
         nv = fmin(fmax(nv, -vmax), vmax);
         double np_ = cur + nv;
         np_ = fmin(fmax(np_, lb), ub);
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     const int n_reinit = __syncthreads_count(mine);               // NP <= 256: at most one particle per thread
     if (n_reinit > 0) {
         for (int e = tid; e < NE; e += kThreads) {
-            const int i = e / D;
+            const int i = fd.div(e);
             if (L.MASK[i]) {
                 double up, uv;
                 if (tape) { up = tape[MBX_RLEPSO_TAPE_REPOS(NP, D) + e]; uv = tape[MBX_RLEPSO_TAPE_REVEL(NP, D) + e]; }

@@ -206,3 +206,61 @@ def test_actor_table_equals_mlp_forward():
     tight = want_sg[0] < 0.05
     if tight.any():
         assert torch.allclose(big.mean(0)[tight], want_mu[0][tight].clamp(0, 1), atol=5e-3)
+
+
+def test_config5_shape_np128_dim40_mixed_suites():
+    """BASELINE.json config 5 geometry: RLEPSO on bbob (24) + bbob-noisy (30) at D = 40 with NP = 128 (5 groups of 25:
+    particles 125..127 keep zero coefficients under the reference's NP // n_group rule, rlepso_optimizer.py:117-126)."""
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    ps = [problems('bbob', 40)[k] for k in sorted(problems('bbob', 40))] + \
+         [problems('bbob-noisy', 40)[k] for k in sorted(problems('bbob-noisy', 40))]
+    s = Suite(ps)
+    B, G, NPc, Dc = len(ps), 6, 128, 40
+    maxfes, logi = 80000, 1600
+    rs = np.random.RandomState(2)
+    actions = rs.uniform(0, 1, size=(G, B, 35)).astype(np.float32)
+    seeds = np.arange(B, dtype=np.uint64) + 77
+    b = Batch(s, ALGO_RLEPSO, np.arange(B), seeds, NPc, maxfes, logi, 50)
+    b.reset()
+    for g in range(G):
+        b.step(torch.from_numpy(actions[g]).cuda())
+    torch.cuda.synchronize()
+    cfg = oracle.make_cfg(1, NPc, Dc, maxfes, logi, 50)
+    for k in range(B):
+        p = ps[k]
+        o = oracle.RlepsoOracle(p.desc(), p.bias, cfg, seed=int(seeds[k]))
+        o.reset()
+        for g in range(G):
+            o.step(actions[g, k])
+        want = oracle.split_rlepso_state(o.state(), NPc, Dc, 50)
+        got = oracle.split_rlepso_state(b.read_state(k), NPc, Dc, 50)
+        assert close(got['scalars'][0], want['scalars'][0]), (p.func_id, got['scalars'][0], want['scalars'][0])
+        assert got['scalars'][1] == want['scalars'][1]
+        if p.noise[0] == 0:
+            assert np.abs(got['pos'] - want['pos']).max() <= 1e-9, p.func_id
+            assert close(got['pbest'], want['pbest']), p.func_id
+        # particles beyond n_group * (NP // n_group) never move on their own (w = c = 0): velocity exactly 0
+        assert np.all(got['vel'].reshape(NPc, Dc)[125:] == 0) or got['scalars'][oracle.SC_REINIT] > 0
+    b.close()
+
+
+def test_single_instance_batch_and_error_paths():
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd import _abi
+    from metabox_amd._abi import ALGO_RLEPSO
+    ps = [problems('bbob', 10)[1]]
+    s = Suite(ps)
+    b = Batch(s, ALGO_RLEPSO, [0], [5], NP, MAXFES, LOGI, NLOG)
+    st = b.reset()
+    assert st.shape == (1, 1) and float(st[0, 0]) == NP / MAXFES
+    for _ in range(3):
+        st, r, d = b.step(torch.full((1, 35), 0.5, device='cuda'))
+    assert float(st[0, 0]) >= 4 * NP / MAXFES and abs(float(r[0])) == 1.0 and int(d[0]) == 0
+    res = b.results()
+    assert int(res['steps'][0]) == 3 and int(res['cost_len'][0]) == 2 and res['cost'].shape == (1, 51)   # fes 400 >= 1*400: one log point
+    with pytest.raises(_abi.MbxError):
+        Batch(s, ALGO_RLEPSO, [3], [5], NP, MAXFES, LOGI, NLOG)          # problem index out of range
+    with pytest.raises(_abi.MbxError):
+        Batch(s, ALGO_RLEPSO, [0], [5], 1000, MAXFES, LOGI, NLOG)        # population larger than a workgroup
+    b.close()
