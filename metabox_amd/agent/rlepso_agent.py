@@ -218,6 +218,94 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
                 'cost_len': res['cost_len']}
 
+    # ---- batched training -------------------------------------------------------------------------
+    def train_batch(self, env, max_updates=None):
+        """PPO over a lock-step BatchedPBO_Env: the reference's n_step = 10 segments / K_epochs = 3 / clipped surrogate +
+        clipped value loss (rlepso_agent.py:140-276), with every quantity carrying a leading batch axis and the losses
+        averaged over the (step, instance) pairs that were still running.  Semantic difference from the reference, by
+        construction: one optimizer step now consumes B trajectories instead of one, and `learn_steps` counts optimizer
+        steps.  Gradients are averaged across ranks when torch.distributed is initialised.
+        Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'}) with per-batch means."""
+        from ..distributed import average_gradients
+        config = self.__config
+        gamma, n_step, K_epochs, eps_clip = config.gamma, config.n_step, config.K_epochs, config.eps_clip
+        actor, critic = self.__actor, self.__critic
+        params = list(actor.parameters()) + list(critic.parameters())
+        B = env.B
+        state = env.reset().to(torch.float32).clone()                     # [B, 1]
+        alive = torch.ones(B, dtype=torch.bool, device=state.device)
+        ret_sum = torch.zeros(B, dtype=torch.float64, device=state.device)
+        updates, exceed = 0, False
+
+        def evaluate(states, actions):
+            mu, sigma = actor.distribution(states)
+            dist_ = Normal(mu, sigma)
+            return dist_.log_prob(actions).sum(-1), critic.value_head(states).squeeze(-1)
+
+        while bool(alive.any()) and not exceed:
+            S, A, LP, V, R, M = [], [], [], [], [], []
+            for _ in range(n_step):
+                with torch.no_grad():
+                    mu, sigma = actor.distribution(state)
+                    action = torch.clamp(mu + sigma * torch.randn_like(mu), 0, 1)
+                logp, val = evaluate(state, action)
+                S.append(state); A.append(action); LP.append(logp); V.append(val); M.append(alive.clone())
+                nstate, reward, done = env.step(action.contiguous())
+                R.append(reward.to(torch.float32).clone())
+                ret_sum += reward * alive
+                alive = alive & (done == 0)
+                state = nstate.to(torch.float32).clone()
+                if not bool(alive.any()):
+                    break
+            S, A, M = torch.stack(S), torch.stack(A), torch.stack(M).to(torch.float32)      # [T, B, ...]
+            R = torch.stack(R) * M
+            old_logp = torch.stack(LP).detach()
+            n_live = M.sum().clamp_min(1.)
+            old_value = None
+            for k in range(K_epochs):
+                if k == 0:
+                    logp, val = torch.stack(LP), torch.stack(V)
+                else:
+                    logp, val = evaluate(S.reshape(-1, S.shape[-1]), A.reshape(-1, A.shape[-1]))
+                    logp, val = logp.view(M.shape), val.view(M.shape)
+                with torch.no_grad():                                        # n-step bootstrapped returns (:225-237)
+                    Rt = critic.value_head(state).squeeze(-1)
+                    returns = []
+                    for t in reversed(range(R.shape[0])):
+                        Rt = torch.where(M[t] > 0, Rt * gamma + R[t], Rt)
+                        returns.append(Rt)
+                    returns = torch.stack(returns[::-1])
+                ratios = torch.exp(logp - old_logp)
+                adv = returns - val.detach()
+                surr = torch.min(ratios * adv, torch.clamp(ratios, 1 - eps_clip, 1 + eps_clip) * adv)
+                reinforce_loss = -(surr * M).sum() / n_live
+                if old_value is None:
+                    baseline_loss = (((val - returns) ** 2) * M).sum() / n_live
+                    old_value = val.detach()
+                else:
+                    vclip = old_value + torch.clamp(val - old_value, -eps_clip, eps_clip)
+                    baseline_loss = (torch.max((val - returns) ** 2, (vclip - returns) ** 2) * M).sum() / n_live
+                self.__optimizer_actor.zero_grad()
+                self.__optimizer_critic.zero_grad()
+                (baseline_loss + reinforce_loss).backward()
+                average_gradients(params)
+                self.__optimizer_actor.step()
+                self.__optimizer_critic.step()
+                self.__dict__['_tables'] = {}
+                self.__learning_time += 1
+                updates += 1
+                if getattr(config, 'agent_save_dir', None) and self.__learning_time >= config.save_interval * self.__cur_checkpoint:
+                    save_class(config.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
+                    self.__cur_checkpoint += 1
+                if self.__learning_time >= config.max_learning_step or (max_updates is not None and updates >= max_updates):
+                    exceed = True
+                    break
+        res = env.results()
+        return self.__learning_time >= config.max_learning_step, {
+            'normalizer': float(res['cost'][:, 0].mean()), 'gbest': float(res['cost'][:, -1].mean()),
+            'return': float(ret_sum.mean()), 'learn_steps': self.__learning_time,
+            'last_losses': (float(baseline_loss.detach()), float(reinforce_loss.detach()))}
+
     # ---- training (PPO, single environment; reference rlepso_agent.py:113-292) ------------------------
     def train_episode(self, env):
         config = self.__config

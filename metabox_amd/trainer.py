@@ -38,7 +38,40 @@ class Trainer(object):
                 normalizer[name].append(normalizer[name][-1])
             np.save(log_dir + name + '_cost', np.stack((epochs, cost[name], normalizer[name]), 0))
 
+    def train_batched(self, max_epochs=None):
+        """--train_batch_size > 1: every epoch is ONE lock-step batch of (train problem x train_batch_size runs) instances
+        driven by ``agent.train_batch`` (vectorised PPO; the reference accepts the flag but never batches,
+        src/trainer.py:159-161).  Instances are sharded over ranks when torch.distributed is initialised and gradients are
+        averaged, so every rank holds the same policy."""
+        import numpy as np
+        from .distributed import instance_table, philox_seed, shard_range
+        from .environment import BatchedPBO_Env
+        from .suite import Suite
+        from .tester import _world
+        problems = self.train_set.data
+        suite = Suite(problems)
+        rank, world = _world()
+        exceed, epoch, log = False, 0, []
+        while not exceed:
+            pidx, run = instance_table(len(problems), self.config.train_batch_size)
+            lo, hi = shard_range(len(pidx), rank, world)
+            seeds = philox_seed(run, np.arange(len(pidx)), epoch_salt=epoch + 1)
+            env = BatchedPBO_Env(problems, self.optimizer, pidx[lo:hi], seeds[lo:hi], suite=suite)
+            exceed, info = self.agent.train_batch(env)
+            env.close()
+            log.append(info)
+            epoch += 1
+            if max_epochs is not None and epoch >= max_epochs:
+                break
+        if rank == 0:
+            log_dir = self.config.log_dir + f'/train/{self.agent.__class__.__name__}/{self.config.run_time}/log/'
+            os.makedirs(log_dir, exist_ok=True)
+            np.save(log_dir + 'return', np.stack(([i['learn_steps'] for i in log], [i['return'] for i in log]), 0))
+        return {'epochs': epoch, 'learn_steps': [i['learn_steps'] for i in log], 'returns': [i['return'] for i in log]}
+
     def train(self, max_epochs=None):
+        if getattr(self.config, 'train_batch_size', 1) > 1 and hasattr(self.agent, 'train_batch'):
+            return self.train_batched(max_epochs)
         exceed, epoch = False, 0
         cost_record = {str(p): [] for p in self.train_set.data}
         normalizer_record = {str(p): [] for p in self.train_set.data}

@@ -50,3 +50,35 @@ def test_gather_equals_unsharded(n_total):
     want = unpack_rows(pack_rows(_fake_results(0, n_total)))
     for k in want:
         assert np.array_equal(got[k], want[k].numpy()), k
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from metabox_amd.distributed import average_gradients
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Linear(3, 2)
+    x = torch.full((4, 3), float(rank + 1))
+    net(x).sum().backward()
+    average_gradients(list(net.parameters()))
+    if rank == 0:
+        q.put([p.grad.clone().numpy() for p in net.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gw, gb = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # rank r sees x = r+1: d/dW sum(Wx+b) = 4*(r+1) per entry, averaged over ranks 1 and 2 -> 6; bias grad 4
+    assert np.allclose(gw, 6.0) and np.allclose(gb, 4.0)

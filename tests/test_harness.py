@@ -194,3 +194,42 @@ def test_single_env_protocol_and_short_training(tmp_path):
             assert set(tinfo) == {'normalizer', 'gbest', 'return', 'learn_steps'} and tinfo['learn_steps'] >= 1
             torch.set_grad_enabled(False)
         assert os.path.exists(cfg.agent_save_dir + 'checkpoint0.pkl')
+
+
+@pytest.mark.gpu
+def test_batched_ppo_training_updates_the_policy(tmp_path):
+    """N3: vectorised PPO over a lock-step batch — finite losses, parameters move, checkpoints are written, and the
+    masked n-step machinery copes with instances that finish early (Sphere stops at 1e-8 with the trained policy)."""
+    import torch
+    from metabox_amd.agent import RLEPSO_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import RLEPSO_Optimizer
+    from metabox_amd.utils import construct_problem_set
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda', '--train', '--train_agent', 'RLEPSO_Agent',
+                      '--train_optimizer', 'RLEPSO_Optimizer', '--max_learning_step', '12', '--n_checkpoint', '3',
+                      '--agent_save_dir', str(tmp_path / 'agents') + '/'])
+    agent = RLEPSO_Agent(cfg).load_exported_weights(np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'metabox_amd',
+                                                                           'agent_model', 'rlepso_bbob_easy.npz'))).to('cuda')
+    opt = RLEPSO_Optimizer(cfg)
+    train, test = construct_problem_set(cfg)
+    ps = (train + test).data
+    B = 96
+    env = BatchedPBO_Env(ps, opt, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 3)
+    before = [p.detach().clone() for p in agent.actor.parameters()]
+    torch.set_grad_enabled(True)
+    exceed, info = agent.train_batch(env, max_updates=9)
+    assert info['learn_steps'] == 9 and not exceed and all(np.isfinite(v) for v in info['last_losses'])
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.actor.parameters()))
+    assert os.path.exists(cfg.agent_save_dir + 'checkpoint1.pkl') and os.path.exists(cfg.agent_save_dir + 'checkpoint2.pkl')
+    exceed, info = agent.train_batch(env)                                      # runs until max_learning_step = 12
+    assert exceed and info['learn_steps'] == 12 and np.isfinite(info['return'])
+    env.close()
+    # the Trainer entry point in batched mode (--train_batch_size > 1)
+    from metabox_amd.trainer import Trainer
+    tcfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda', '--train', '--train_agent', 'RLEPSO_Agent',
+                       '--train_optimizer', 'RLEPSO_Optimizer', '--max_learning_step', '6', '--n_checkpoint', '2', '--train_batch_size', '2',
+                       '--agent_save_dir', str(tmp_path / 'agents2') + '/', '--log_dir', str(tmp_path / 'log2')])
+    out = Trainer(tcfg).train()
+    torch.set_grad_enabled(False)
+    assert out['learn_steps'][-1] == 6 and os.path.exists(tcfg.agent_save_dir + 'checkpoint2.pkl')
