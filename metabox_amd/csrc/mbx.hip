@@ -55,6 +55,7 @@ struct mbx_batch {
     uint64_t* d_seeds = nullptr;
     double* d_state = nullptr;
     int32_t* d_order = nullptr;
+    double* d_pci = nullptr;
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
     size_t lds_bytes = 0;
@@ -388,7 +389,13 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
                        g.sc_off, n_instances);
     HIP_TRY(hipDeviceSynchronize());
     if (cfg->algo == MBX_ALGO_RLEPSO) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {   // RLEPSO learning-probability curve (rlepso_optimizer.py:23-24): pci_i = 0.05 + 0.45 exp(10 i/(NP-1)) / (e^10 - 1)
+        std::vector<double> pci(cfg->np);
+        for (int i = 0; i < cfg->np; ++i) pci[i] = 0.05 + 0.45 * std::exp(10. * i / (cfg->np - 1)) / (std::exp(10.) - 1);
+        HIP_TRY(hipMalloc(&b->d_pci, cfg->np * sizeof(double)));
+        HIP_TRY(hipMemcpy(b->d_pci, pci.data(), cfg->np * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_LDE) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -406,7 +413,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
 extern "C" int mbx_batch_destroy(mbx_batch* b)
 {
     if (!b) return MBX_OK;
-    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order);
+    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order); (void)hipFree(b->d_pci);
     delete b;
     return MBX_OK;
 }
@@ -423,7 +430,7 @@ static BatchParams make_params(const mbx_batch* b)
     BatchParams p;
     p.problems = b->suite->d_problems; p.problem_idx = b->d_problem_idx; p.seeds = b->d_seeds;
     p.state = b->d_state; p.state_stride = b->state_stride;
-    p.tape = b->d_tape; p.tape_stride = b->tape_stride; p.order = b->d_order;
+    p.tape = b->d_tape; p.tape_stride = b->tape_stride; p.order = b->d_order; p.pci = b->d_pci;
     p.NP = b->cfg.np; p.D = b->cfg.dim; p.max_fes = b->cfg.max_fes; p.log_interval = b->cfg.log_interval;
     p.n_logpoint = b->cfg.n_logpoint; p.early_stop = b->cfg.early_stop; p.n_group = b->cfg.n_group; p.B = b->B;
     return p;

@@ -21,12 +21,13 @@ struct BatchParams {
     const double* tape;          // nullptr -> Philox
     int64_t tape_stride;
     const int32_t* order;        // launch order: workgroup w owns instance order[w] (most expensive objectives first)
+    const double* pci;           // [NP] RLEPSO learning-probability curve pci_i (rlepso_optimizer.py:23-24), computed at batch creation
     int32_t NP, D, max_fes, log_interval, n_logpoint, early_stop, n_group, B;
 };
 
 // LDS carve-up (all offsets in doubles; base is 16-byte aligned, every array starts 16-byte aligned)
 struct RlLds {
-    double *PB, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *PBC, *CC, *NC, *PNI, *CMUT, *PCI, *R1, *R2, *GB, *COEF, *RED;
+    double *PB, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *PBC, *NC, *PNI, *CMUT, *R1, *R2, *GB, *COEF, *RED;
     int *IMPR, *MASK, *RANK;
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
@@ -38,8 +39,9 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP), TS = eval_t_doubles(NP, D);
     // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC; M1T, M2T;
-    // DSH, V0, V1, V2, GB: D each; PBC, CC, NC, PNI, CMUT, PCI, R1, R2: P each; COEF: 6*16; RED: 16; 2 int arrays
-    return TS + NE + SC + 2 * DD + 8 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
+    // DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT, R1, R2: P each; COEF: 6*16; RED: 16; 3 int arrays
+    // (32.4 KB at NP = 100, D = 10: five workgroups per CU)
+    return TS + NE + SC + 2 * DD + 6 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
 }
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
@@ -57,11 +59,9 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
     L.V0 = p; p += align2(D);
     L.V1 = p; p += align2(D);
     L.V2 = p; p += align2(D);
-    L.PCI = p; p += P;
     L.R1 = p; p += P;
     L.R2 = p; p += P;
     L.PBC = p; p += P;
-    L.CC = p; p += P;
     L.NC = p; p += P;
     L.PNI = p; p += P;
     L.CMUT = p; p += P;
@@ -101,16 +101,16 @@ __device__ __forceinline__ void rl_costs(const DevProblem& P, const RlLds& L, in
 // Candidate positions are in L.X, their costs in L.NC.  `stagnation` additionally updates per_no_improve
 // against the previous c_cost (:225-233), which only update() does.
 __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool stagnation, double& gbest, int& gbest_idx,
-                                          double* __restrict__ gPB)
+                                          double* __restrict__ gPB, double* __restrict__ gCC)
 {
     const int tid = threadIdx.x;
     for (int i = tid; i < NP; i += kThreads) {
         const double nc = L.NC[i];
-        if (stagnation) L.PNI[i] = nc < L.CC[i] ? 0. : L.PNI[i] + 1;
+        if (stagnation) L.PNI[i] = nc < gCC[i] ? 0. : L.PNI[i] + 1;   // c_cost lives in HBM only: thread i is its sole reader/writer
         const int impr = nc < L.PBC[i];
         if (impr) L.PBC[i] = nc;
         L.IMPR[i] = impr;
-        L.CC[i] = nc;
+        gCC[i] = nc;
     }
     double cbv; int cb;
     block_argmin(L.NC, NP, L.RED, cbv, cb);         // contains the barriers that publish IMPR / CC
@@ -221,7 +221,6 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     for (int i = tid; i < NP; i += kThreads) {
         L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
         L.IMPR[i] = 0; L.MASK[i] = 0;
-        L.CC[i] = S[MBX_RLEPSO_ST_CCOST(NP, D) + i];
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
@@ -244,7 +243,6 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     __syncthreads();
     const int per_group = NP / G;
     const FastDiv fd(D), fg(per_group);
-    const double pci_den = m_exp(10.) - 1;
     // ---- rank the particles by (pbest cost, index); all 256 threads take part: thread (i, part) counts over a slice of j
     int* ORDER = L.IMPR;          // both int arrays are free until the first commit
     int* NLESS = L.MASK;
@@ -275,7 +273,6 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     for (int i = tid; i < NP; i += kThreads) {                    // per-particle quantities
         const int g = fg.div(i);
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
-        L.PCI[i] = 0.05 + 0.45 * m_exp(10. * i / (NP - 1)) / pci_den;   // learning probability curve (:23-24)
         if (tape) { L.R1[i] = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; L.R2[i] = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i]; }
         else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w); }
         const int rank = RANK[i];
@@ -304,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         }
         const double cur = L.X[e], pp = L.PB[es], fi = L.PBC[i];
         // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
-        const double pci = L.PCI[i];
+        const double pci = bp.pci[i];
         const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
         const double exemplar = uc > pci ? pp : L.PB[RANK[tw] * D + d];
         const double v_clpso = uc * (exemplar - cur);
@@ -351,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
     rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
-    rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D));
+    rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
 
     // ---- re-initialisation (:238-239, 134-168): P(i) = u < c_mutation_i * 0.01 * per_no_improve_i
     int mine = 0;
@@ -381,13 +378,12 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         // the whole population is re-evaluated but only the re-initialised particles are billed (:141-143)
         rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
         fes += n_reinit;
-        rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D));
+        rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
     }
 
     // ---- write back what changed
     for (int i = tid; i < NP; i += kThreads) {
         S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = L.PBC[i];
-        S[MBX_RLEPSO_ST_CCOST(NP, D) + i] = L.CC[i];
         S[MBX_RLEPSO_ST_PNI(NP, D) + i] = L.PNI[i];
     }
     if (gbest < pre_gbest && tid < D) S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid] = L.GB[tid];
