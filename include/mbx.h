@@ -110,9 +110,10 @@ typedef struct mbx_algo_cfg {
 } mbx_algo_cfg;
 
 /* Dimensions of the per-step tensors for a configuration (so callers can size buffers):
- *   RLEPSO : state [1]      (fes/maxFEs, rlepso_optimizer.py:170-171), action [35] float32
- *   LDE    : state [np+10]  (lde_optimizer.py:145-157),               action [2*np] float32
- *   DEDDQN : state [99]     (de_ddqn_optimizer.py:76-129),            action [1] int32      */
+ *   RLEPSO        : state [1]      (fes/maxFEs, rlepso_optimizer.py:170-171), action [35] float32
+ *   LDE           : state [np+10]  (lde_optimizer.py:145-157),               action [2*np] float32
+ *   DEDDQN        : state [99]     (de_ddqn_optimizer.py:76-129),            action [1] int32
+ *   RANDOM_SEARCH : state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step) */
 int mbx_state_dim(const mbx_algo_cfg* cfg);
 int mbx_action_dim(const mbx_algo_cfg* cfg);
 /* number of doubles of external random numbers one instance consumes per step (see mbx_set_tape) */
@@ -139,8 +140,9 @@ int mbx_reset(mbx_batch* b, double* d_state_out, void* stream);
 
 /* PBO_Env.step(action) for every instance that is not done: optimizer.update(action, problem)
  * (basic_environment.py:21-22, rlepso_optimizer.py:173-263).  d_actions is
- * [n_instances, action_dim] (float32; int32 for DEDDQN).  Outputs: next state (float64),
- * reward (float64), done (uint8).  Done instances are left untouched and report reward 0. */
+ * [n_instances, action_dim] (float32; int32 for DEDDQN; NULL for RANDOM_SEARCH).  Outputs: next state (float64),
+ * reward (float64), done (uint8).  Done instances are left untouched and report reward 0 (their state row keeps
+ * its last value).  Workgroups are dispatched most-expensive-objective first. */
 int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out,
              uint8_t* d_done_out, void* stream);
 
