@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it writes are data
 (inputs + expected outputs), never reference source.  Re-run: `python tools/gen_golden.py [section ...]`
-with sections in {instances, kat, noise, policy, rlepso, lde, protein, ddqn, harness}.
+with sections in {instances, kat, noise, policy, rlepso, lde, protein, ddqn, harness, stats}.
 
 What is recorded
   instances : per (suite, dim) the problem names, biases, optima, a sha256 over every constructor-made
@@ -504,7 +504,36 @@ def gen_harness():
     print('metrics:', out['aei_mean'], out['cec'])
 
 
-SECTIONS = {'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def gen_stats():
+    """End-to-end statistics of the reference: final cost / fes / return of the shipped RLEPSO agent over 40 seeded runs of
+    each bbob-easy test problem (np.random.seed(r); torch.manual_seed(r)).  The GPU test compares the Philox-driven batched
+    engine against these distributions."""
+    scratch = tempfile.mkdtemp()
+    from optimizer import RLEPSO_Optimizer
+    from environment import PBO_Env
+    import copy
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/RLEPSO_Agent.pkl'))
+    config = ref_import.ref_config(['--problem', 'bbob', '--dim', '10'], scratch)
+    tr, te, _ = all_problems('bbob', 10)
+    data = {}
+    for p in te:
+        fc, fes, ret = [], [], []
+        for r in range(40):
+            opt = RLEPSO_Optimizer(copy.deepcopy(config))
+            np.random.seed(r)
+            torch.manual_seed(r)
+            p.reset()
+            with torch.no_grad():
+                info = agent.rollout_episode(PBO_Env(p, opt))
+            fc.append(info['cost'][-1]); fes.append(info['fes']); ret.append(info['return'])
+        data[f'{fid_of(p)}/final_cost'] = np.array(fc, dtype=np.float64)
+        data[f'{fid_of(p)}/fes'] = np.array(fes, dtype=np.float64)
+        data[f'{fid_of(p)}/return'] = np.array(ret, dtype=np.float64)
+        print(fid_of(p), str(p), np.mean(fc), np.std(fc), np.mean(fes))
+    np.savez_compressed(os.path.join(OUT, 'rlepso_stats.npz'), **data)
+
+
+SECTIONS = {'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
