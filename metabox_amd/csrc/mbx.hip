@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -97,6 +98,9 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
     }
     return g;
 }
+
+extern "C" int mbx_suite_destroy(mbx_suite* s);
+extern "C" int mbx_batch_destroy(mbx_batch* b);
 
 // ------------------------------------------------------------------------------------------------ kernels
 // Stand-alone evaluation: each block stages the problem's linear maps and evaluates up to `rows` rows.
@@ -257,7 +261,8 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
             o.o[9] = push(ry.data(), NA * D);
         }
     }
-    mbx_suite* s = new mbx_suite();
+    std::unique_ptr<mbx_suite, int (*)(mbx_suite*)> guard(new mbx_suite(), mbx_suite_destroy);   // freed on every error return
+    mbx_suite* s = guard.get();
     s->n = n_problems; s->dim = D;
     HIP_TRY(hipMalloc(&s->d_pool, pool.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(s->d_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -285,7 +290,7 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
         for (int i = 0; i < n_problems; ++i) s->h_problems[i].optimum = s->optimum[i];
         (void)hipFree(d_x); (void)hipFree(d_f);
     }
-    *out = s;
+    *out = guard.release();
     return MBX_OK;
 }
 
@@ -358,7 +363,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     const size_t lds = (size_t)g.lds_doubles * sizeof(double);
     if (lds > (size_t)max_lds_bytes())
         return fail(MBX_E_UNSUPPORTED, "np=%d dim=%d needs %zu B of LDS per workgroup (> %d)", cfg->np, cfg->dim, lds, max_lds_bytes());
-    mbx_batch* b = new mbx_batch();
+    std::unique_ptr<mbx_batch, int (*)(mbx_batch*)> guard(new mbx_batch(), mbx_batch_destroy);   // freed on every error return
+    mbx_batch* b = guard.get();
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
     b->state_stride = (g.state_doubles + 1) & ~(int64_t)1;
     b->sc_off = g.sc_off; b->tape_stride = g.tape_stride; b->state_dim = g.state_dim; b->action_dim = g.action_dim;
@@ -406,7 +412,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     } else {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rs_population, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    *out = b;
+    *out = guard.release();
     return MBX_OK;
 }
 
