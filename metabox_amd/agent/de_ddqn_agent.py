@@ -1,9 +1,10 @@
-"""DE-DDQN agent: double deep Q-network choosing one of four DE mutation operators per trial vector
-(reference: src/agent/de_ddqn_agent.py).  Q-network = MLP 99 -> 100 x4 (ReLU) -> 4; rollout is greedy,
-training is epsilon-greedy with a 1e5 replay buffer, 1e4 warm-up, batch 64, target sync every 1000 updates.
+"""DE-DDQN agent: a double deep Q-network picks one of four DE mutation operators for every trial vector
+(reference: src/agent/de_ddqn_agent.py).
 
-``rollout_batch`` evaluates the Q-network once per step over the whole instance batch (PyTorch-ROCm GEMMs) and
-feeds the argmax actions to the fused DE-DDQN step kernel.
+Q-network: MLP 99 -> 100 -> 100 -> 100 -> 100 -> 4 with ReLU.  Rollout is greedy (argmax Q); training is epsilon-greedy
+(eps = 0.1) with a 1e5-transition replay buffer, a 1e4-transition warm-up, mini-batches of 64, gamma = 0.99, AdamW
+(lr 1e-4) and a target network refreshed every 1000 updates.  ``rollout_batch`` evaluates the Q-network once per step
+over the whole instance batch (PyTorch-ROCm GEMMs) and feeds the argmax to the fused DE-DDQN step kernel.
 """
 import copy
 
@@ -14,42 +15,38 @@ from .basic_agent import Basic_Agent
 from .networks import MLP
 from .utils import ReplayBuffer, save_class
 
+_HYPER = dict(state_size=99, n_act=4, lr=1e-4, batch_size=64, epsilon=0.1, gamma=0.99, update_target_steps=1000,
+              memory_size=100000, warm_up_size=10000)
+
+
+def _q_layers(n_in, n_out, width=100, depth=4):
+    dims = [n_in] + [width] * depth
+    layers = [{'in': a, 'out': b, 'drop_out': 0, 'activation': 'ReLU'} for a, b in zip(dims[:-1], dims[1:])]
+    return layers + [{'in': width, 'out': n_out, 'drop_out': 0, 'activation': 'None'}]
+
 
 class DE_DDQN_Agent(Basic_Agent):
     def __init__(self, config):
         super().__init__(config)
-        config.state_size = 99
-        config.n_act = 4
-        config.lr = 1e-4
-        config.batch_size = 64
-        config.epsilon = 0.1
-        config.gamma = 0.99
-        config.update_target_steps = 1000
-        config.memory_size = 100000
-        config.warm_up_size = 10000
-        config.net_config = [{'in': config.state_size, 'out': 100, 'drop_out': 0, 'activation': 'ReLU'},
-                             {'in': 100, 'out': 100, 'drop_out': 0, 'activation': 'ReLU'},
-                             {'in': 100, 'out': 100, 'drop_out': 0, 'activation': 'ReLU'},
-                             {'in': 100, 'out': 100, 'drop_out': 0, 'activation': 'ReLU'},
-                             {'in': 100, 'out': config.n_act, 'drop_out': 0, 'activation': 'None'}]
+        for key, value in _HYPER.items():               # the agent publishes its hyper-parameters on the shared config
+            setattr(config, key, value)
+        config.net_config = _q_layers(config.state_size, config.n_act)
         self.__config = config
         self.__device = config.device
         self.__pred_func = MLP(config.net_config).to(self.__device)
         self.__target_func = copy.deepcopy(self.__pred_func).to(self.__device)
         self.__optimizer = torch.optim.AdamW(self.__pred_func.parameters(), lr=config.lr)
         self.__criterion = torch.nn.MSELoss()
-        self.__n_act = config.n_act
-        self.__epsilon = config.epsilon
-        self.__gamma = config.gamma
-        self.__update_target_steps = config.update_target_steps
-        self.__batch_size = config.batch_size
         self.__replay_buffer = ReplayBuffer(config.memory_size)
-        self.__warm_up_size = config.warm_up_size
         self.__max_learning_step = config.max_learning_step
         self.__global_ls = 0
         self.__cur_checkpoint = 0
-        if getattr(config, 'agent_save_dir', None):
-            save_class(config.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
+        self.__checkpoint()
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------
+    def __checkpoint(self):
+        if getattr(self.__config, 'agent_save_dir', None):
+            save_class(self.__config.agent_save_dir, f'checkpoint{self.__cur_checkpoint}', self)
         self.__cur_checkpoint += 1
 
     @property
@@ -57,14 +54,14 @@ class DE_DDQN_Agent(Basic_Agent):
         return self.__pred_func
 
     def load_exported_weights(self, npz):
-        sd = {k[len('net/'):]: torch.as_tensor(np.asarray(npz[k])) for k in npz.files if k.startswith('net/')}
-        self.__pred_func.load_state_dict(sd)
+        prefix = 'net/'
+        self.__pred_func.load_state_dict({k[len(prefix):]: torch.as_tensor(np.asarray(npz[k]))
+                                          for k in npz.files if k.startswith(prefix)})
         self.__target_func = copy.deepcopy(self.__pred_func)
         return self
 
     def to(self, device):
-        self.__device = device
-        self.__config.device = device
+        self.__device = self.__config.device = device
         self.__pred_func.to(device)
         self.__target_func.to(device)
         return self
@@ -72,30 +69,25 @@ class DE_DDQN_Agent(Basic_Agent):
     def update_setting(self, config):
         self.__max_learning_step = config.max_learning_step
         self.__config.agent_save_dir = config.agent_save_dir
-        self.__global_ls = 0
-        save_class(self.__config.agent_save_dir, 'checkpoint0', self)
         self.__config.save_interval = config.save_interval
-        self.__cur_checkpoint = 1
+        self.__global_ls = 0
+        self.__cur_checkpoint = 0
+        self.__checkpoint()
 
-    def __get_action(self, state, options=None):
-        state = torch.Tensor(state).to(self.__device)
-        action = None
+    # ---- acting ---------------------------------------------------------------------------------------
+    def __act(self, state, explore):
         with torch.no_grad():
-            Q_list = self.__pred_func(state)
-        if options['epsilon_greedy'] and np.random.rand() < self.__epsilon:
-            action = np.random.randint(low=0, high=self.__n_act)
-        if action is None:
-            action = int(torch.argmax(Q_list).detach().cpu().numpy())
-        return action, Q_list[action].detach().cpu().numpy()
+            q = self.__pred_func(torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.__device))
+        if explore and np.random.rand() < self.__config.epsilon:
+            return int(np.random.randint(low=0, high=self.__config.n_act))
+        return int(torch.argmax(q))
 
     def rollout_episode(self, env):
-        state = env.reset()
-        done, R = False, 0
+        state, done, total = env.reset(), False, 0
         while not done:
-            action, _ = self.__get_action(state, {'epsilon_greedy': False})
-            state, reward, done = env.step(action)
-            R += reward
-        return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
+            state, reward, done = env.step(self.__act(state, explore=False))
+            total += reward
+        return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': total}
 
     @torch.no_grad()
     def rollout_batch(self, env, max_steps=None):
@@ -104,40 +96,41 @@ class DE_DDQN_Agent(Basic_Agent):
             max_steps = bc.max_fes - bc.np                # one evaluation per step
         state = env.reset()
         for _ in range(max_steps):
-            actions = torch.argmax(self.__pred_func(state.to(torch.float32)), dim=1).to(torch.int32)
-            state, _, _ = env.step(actions.contiguous())
+            greedy = self.__pred_func(state.to(torch.float32)).argmax(dim=1).to(torch.int32)
+            state, _, _ = env.step(greedy.contiguous())
         res = env.results()
-        return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}
+        return {k: res[k] for k in ('cost', 'fes', 'return', 'steps', 'cost_len')}
+
+    # ---- learning -------------------------------------------------------------------------------------
+    def __learn_from_replay(self):
+        cfg = self.__config
+        obs, act, rew, nxt, dn = (t.to(self.__device) for t in self.__replay_buffer.sample(cfg.batch_size))
+        q_taken = self.__pred_func(obs).gather(1, act.view(-1, 1).long()).squeeze(1)
+        with torch.no_grad():
+            target = rew + (1 - dn) * cfg.gamma * self.__target_func(nxt).max(1)[0]
+        self.__optimizer.zero_grad()
+        self.__criterion(q_taken, target).backward()
+        self.__optimizer.step()
+        self.__global_ls += 1
+        if self.__global_ls >= cfg.save_interval * self.__cur_checkpoint:
+            self.__checkpoint()
 
     def train_episode(self, env):
-        """Reference training loop (de_ddqn_agent.py:70-106)."""
-        state = env.reset()
-        done, R = False, 0
+        """One episode of epsilon-greedy interaction with a replay update after every step once the buffer holds
+        warm_up_size transitions (reference loop: de_ddqn_agent.py:70-106)."""
+        cfg = self.__config
+        state, done, total = env.reset(), False, 0
         while not done:
-            action, _ = self.__get_action(state, {'epsilon_greedy': True})
-            next_state, reward, done = env.step(action)
-            R += reward
-            self.__replay_buffer.append((state, action, reward, next_state, done))
-            if len(self.__replay_buffer) >= self.__warm_up_size:
-                obs, act, rew, nxt, dn = self.__replay_buffer.sample(self.__batch_size)
-                pred_Vs = self.__pred_func(obs.to(self.__device))
-                onehot = torch.nn.functional.one_hot(act.to(self.__device), self.__n_act)
-                predict_Q = (pred_Vs * onehot).sum(1)
-                target_Q = rew.to(self.__device) + (1 - dn.to(self.__device)) * self.__gamma * \
-                    self.__target_func(nxt.to(self.__device)).max(1)[0]
-                self.__optimizer.zero_grad()
-                loss = self.__criterion(predict_Q, target_Q.detach())
-                loss.backward()
-                self.__optimizer.step()
-                self.__global_ls += 1
-                if self.__global_ls >= (self.__config.save_interval * self.__cur_checkpoint):
-                    save_class(self.__config.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
-                    self.__cur_checkpoint += 1
+            action = self.__act(state, explore=True)
+            nxt, reward, done = env.step(action)
+            total += reward
+            self.__replay_buffer.append((state, action, reward, nxt, done))
+            if len(self.__replay_buffer) >= cfg.warm_up_size:
+                self.__learn_from_replay()
                 if self.__global_ls >= self.__max_learning_step:
                     break
-            if self.__global_ls % self.__update_target_steps == 0:
-                for tp, pp in zip(self.__target_func.parameters(), self.__pred_func.parameters()):
-                    tp.data.copy_(pp.data)
-            state = next_state
+            if self.__global_ls % cfg.update_target_steps == 0:
+                self.__target_func.load_state_dict(self.__pred_func.state_dict())
+            state = nxt
         return self.__global_ls >= self.__max_learning_step, {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1],
-                                                              'return': R, 'learn_steps': self.__global_ls}
+                                                              'return': total, 'learn_steps': self.__global_ls}

@@ -126,60 +126,106 @@ class LDE_Agent(Basic_Agent):
         res = env.results()
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}
 
-    def __discounted_norm_rewards(self, r):
+    def __discounted(self, rewards, n_traj):
+        """Per-trajectory discounted returns (gamma = 0.99) over `n_traj` equally long segments of `rewards`."""
+        gamma = self.__config.gamma
+        out = np.array(rewards, dtype=np.float64, copy=True).reshape(n_traj, -1)
+        for t in range(out.shape[1] - 2, -1, -1):
+            out[:, t] += gamma * out[:, t + 1]
+        return out.reshape(-1)
+
+    def __reinforce_step(self, inputs, hs, cs, actions, returns):
+        """One REINFORCE update: loss = -mean(log pi(a + 1e-8 | s, h, c) * discounted return)  (lde_agent.py:124-133)."""
         c = self.__config
-        out = []
-        length = r.shape[0] // c.TRAJECTORY_NUM
-        for ep in range(c.TRAJECTORY_NUM * self.__BATCH_SIZE):
-            single = r[ep * length: ep * length + length]
-            disc = np.zeros_like(single)
-            run = 0.
-            for t in reversed(range(length)):
-                run = run * c.gamma + single[t]
-                disc[t] = run
-            out.append(disc)
-        return np.hstack(out)
+        mean, std, _, _ = self.__net.forward(inputs[None], hs[None], cs[None])
+        log_prob = torch.distributions.Normal(mean[0], std[0]).log_prob(actions + 1e-8).sum(1)
+        loss = -(log_prob * returns).mean()
+        loss.backward()
+        return loss
+
+    def __after_update(self):
+        c = self.__config
+        self.__learn_steps += 1
+        if getattr(c, 'agent_save_dir', None) and self.__learn_steps >= c.save_interval * self.__cur_checkpoint:
+            save_class(c.agent_save_dir, f'checkpoint{self.__cur_checkpoint}', self)
+            self.__cur_checkpoint += 1
 
     def train_episode(self, env):
-        """REINFORCE over 20 trajectories x 50 steps, each trajectory restarting the environment (lde_agent.py:85-145)."""
+        """REINFORCE over TRAJECTORY_NUM = 20 trajectories of at most TRAJECTORY_LENGTH = 50 steps, every trajectory
+        restarting the environment with a zero LSTM state (reference: lde_agent.py:85-145)."""
         c = self.__config
+        dev = c.device
         self.__optimizer.zero_grad()
-        inputs_b, action_b, hs_b, cs_b, rewards_b = [], [], [], [], []
-        R = 0
+        feats, acts, hs, cs, rews = [], [], [], [], []
+        total = 0
         for _ in range(c.TRAJECTORY_NUM):
-            input_net = env.reset()
-            h0, c0 = self.__zeros()
-            for _t in range(c.TRAJECTORY_LENGTH):
-                input_net = input_net.reshape(self.__feature_shape)
+            obs = env.reset()
+            h, cell = self.__zeros()
+            for _step in range(c.TRAJECTORY_LENGTH):
+                obs = obs.reshape(self.__feature_shape)
                 with torch.no_grad():
-                    action, h_, c_ = self.__net.sampler(torch.FloatTensor(input_net[None, :]).to(c.device), h0, c0)
-                action = np.squeeze(action.reshape(1, self.__BATCH_SIZE, -1).cpu().numpy(), axis=0)
-                inputs_b.append(input_net)
-                action_b.append(action)
-                next_input, reward, is_done = env.step(action)
-                hs_b.append(torch.squeeze(h0, axis=0))
-                cs_b.append(torch.squeeze(c0, axis=0))
-                rewards_b.append(np.asarray(reward).reshape(self.__BATCH_SIZE))
-                R += np.mean(reward)
-                h0, c0 = h_, c_
-                input_net = next_input.copy()
-                if is_done:
+                    a, h_next, c_next = self.__net.sampler(torch.FloatTensor(obs[None, :]).to(dev), h, cell)
+                a = np.squeeze(a.reshape(1, self.__BATCH_SIZE, -1).cpu().numpy(), axis=0)
+                nxt, reward, done = env.step(a)
+                feats.append(obs[0]); acts.append(a[0]); hs.append(h[0, 0]); cs.append(cell[0, 0])
+                rews.append(float(np.mean(reward)))
+                total += np.mean(reward)
+                h, cell, obs = h_next, c_next, nxt.copy()
+                if done:
                     break
-        inputs = np.stack(inputs_b, axis=0).transpose((1, 0, 2)).reshape(-1, c.node_dim)
-        actions = np.stack(action_b, axis=0).transpose((1, 0, 2)).reshape(-1, c.output_dim_actor)
-        hs = torch.stack(hs_b, axis=0).permute(1, 0, 2).reshape(-1, c.CELL_SIZE)
-        cs = torch.stack(cs_b, axis=0).permute(1, 0, 2).reshape(-1, c.CELL_SIZE)
-        rewards = np.stack(rewards_b, axis=0).transpose((1, 0)).flatten()
-        mean, std, _, _ = self.__net.forward(torch.FloatTensor(inputs[None, :]).to(c.device), hs[None, :], cs[None, :])
-        actions = torch.FloatTensor(actions).to(c.device)
-        normal = torch.distributions.Normal(torch.squeeze(mean, 0), torch.squeeze(std, 0))
-        log_prob = torch.sum(normal.log_prob(actions + 1e-8), 1)
-        loss = -torch.mean(log_prob * torch.FloatTensor(self.__discounted_norm_rewards(rewards)).to(c.device))
-        loss.backward()
+        returns = torch.FloatTensor(self.__discounted(rews, c.TRAJECTORY_NUM)).to(dev)
+        self.__reinforce_step(torch.FloatTensor(np.stack(feats)).to(dev), torch.stack(hs), torch.stack(cs),
+                              torch.FloatTensor(np.stack(acts)).to(dev), returns)
         self.__optimizer.step()
-        self.__learn_steps += 1
-        if self.__learn_steps >= (c.save_interval * self.__cur_checkpoint):
-            save_class(c.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
-            self.__cur_checkpoint += 1
+        self.__after_update()
         return self.__learn_steps >= c.max_learning_step, {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1],
-                                                          'return': R, 'learn_steps': self.__learn_steps}
+                                                          'return': total, 'learn_steps': self.__learn_steps}
+
+    def train_batch(self, env, max_updates=None):
+        """Batched REINFORCE: the B instances of a lock-step BatchedPBO_Env are the trajectories (the
+        reference collects 20 of them one after the other); TRAJECTORY_LENGTH = 50 steps each, then one update, repeated
+        until every instance is done.  Finished instances are masked out; gradients are averaged over ranks."""
+        from ..distributed import average_gradients
+        c = self.__config
+        dev = env.batch.device
+        state = env.reset().to(torch.float32).clone()
+        B = env.B
+        h, cell = self.__zeros(B)
+        alive = torch.ones(B, dtype=torch.bool, device=dev)
+        ret_sum = torch.zeros(B, dtype=torch.float64, device=dev)
+        updates, exceed, loss = 0, False, torch.zeros(())
+        while bool(alive.any()) and not exceed:
+            S, H, C_, A, R, M = [], [], [], [], [], []
+            for _ in range(c.TRAJECTORY_LENGTH):
+                with torch.no_grad():
+                    a, h2, c2 = self.__net.act_batch(state, h, cell)
+                S.append(state); H.append(h[0]); C_.append(cell[0]); A.append(a); M.append(alive.clone())
+                nstate, reward, done = env.step(a.contiguous())
+                r = torch.nan_to_num(reward.to(torch.float32), nan=0.0, posinf=0.0, neginf=0.0) * alive
+                R.append(r)
+                ret_sum += r.to(torch.float64)
+                alive = alive & (done == 0)
+                h, cell, state = h2, c2, nstate.to(torch.float32).clone()
+                if not bool(alive.any()):
+                    break
+            M = torch.stack(M).to(torch.float32)
+            G = torch.stack(R)
+            for t in range(G.shape[0] - 2, -1, -1):
+                G[t] += c.gamma * G[t + 1]
+            T = G.shape[0]
+            self.__optimizer.zero_grad()
+            mean, std, _, _ = self.__net.forward(torch.stack(S).view(1, T * B, -1), torch.stack(H).view(1, T * B, -1),
+                                                 torch.stack(C_).view(1, T * B, -1))
+            logp = torch.distributions.Normal(mean[0], std[0]).log_prob(torch.stack(A).view(T * B, -1) + 1e-8).sum(1).view(T, B)
+            loss = -(logp * G * M).sum() / M.sum().clamp_min(1.)
+            loss.backward()
+            average_gradients(list(self.__net.parameters()))
+            self.__optimizer.step()
+            self.__after_update()
+            updates += 1
+            if self.__learn_steps >= c.max_learning_step or (max_updates is not None and updates >= max_updates):
+                exceed = True
+        res = env.results()
+        return self.__learn_steps >= c.max_learning_step, {
+            'normalizer': float(res['cost'][:, 0].mean()), 'gbest': float(res['cost'][:, -1].mean()),
+            'return': float(ret_sum.mean()), 'learn_steps': self.__learn_steps, 'last_losses': (float(loss.detach()),)}

@@ -1,39 +1,47 @@
-"""Agent utilities (reference: src/agent/utils.py:9-48)."""
-import collections
-import os
+"""Small training utilities shared by the agents (reference: src/agent/utils.py:9-48): the PPO rollout memory, the
+DQN replay buffer, and the whole-object pickle checkpoints (``checkpoint0.pkl`` .. ``checkpoint20.pkl``)."""
+import pathlib
 import pickle
 import random
+from collections import deque
 
 import numpy as np
 import torch
 
 
 class Memory:
+    """Per-segment storage of (state, action, log-prob, reward) lists."""
+    FIELDS = ('actions', 'states', 'logprobs', 'rewards')
+
     def __init__(self):
-        self.actions, self.states, self.logprobs, self.rewards = [], [], [], []
+        for f in self.FIELDS:
+            setattr(self, f, [])
 
     def clear_memory(self):
-        del self.actions[:], self.states[:], self.logprobs[:], self.rewards[:]
+        for f in self.FIELDS:
+            getattr(self, f).clear()
 
 
 class ReplayBuffer:
+    """Uniform-sampling FIFO of (obs, action, reward, next_obs, done) transitions."""
+
     def __init__(self, max_size):
-        self.buffer = collections.deque(maxlen=max_size)
+        self.buffer = deque(maxlen=max_size)
+
+    def __len__(self):
+        return len(self.buffer)
 
     def append(self, exp):
         self.buffer.append(exp)
 
     def sample(self, batch_size):
-        obs, act, rew, nxt, done = zip(*random.sample(self.buffer, batch_size))
-        return (torch.FloatTensor(np.array(obs)), torch.tensor(act), torch.FloatTensor(rew),
-                torch.FloatTensor(np.array(nxt)), torch.FloatTensor(done))
-
-    def __len__(self):
-        return len(self.buffer)
+        cols = list(zip(*random.sample(self.buffer, batch_size)))
+        obs, nxt = (torch.FloatTensor(np.array(cols[k])) for k in (0, 3))
+        return obs, torch.tensor(cols[1]), torch.FloatTensor(cols[2]), nxt, torch.FloatTensor(cols[4])
 
 
 def save_class(dir, file_name, saving_class):
-    """Whole-object pickle checkpoint ``<dir><file_name>.pkl`` (21 files checkpoint0..20 per training run)."""
-    os.makedirs(dir, exist_ok=True)
-    with open(dir + file_name + '.pkl', 'wb') as f:
-        pickle.dump(saving_class, f, -1)
+    """Pickle `saving_class` to ``<dir><file_name>.pkl`` (dir is used as a string prefix, like the reference does)."""
+    pathlib.Path(dir).mkdir(parents=True, exist_ok=True)
+    with open(f'{dir}{file_name}.pkl', 'wb') as fh:
+        pickle.dump(saving_class, fh, protocol=-1)

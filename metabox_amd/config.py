@@ -1,92 +1,97 @@
-"""Command-line configuration — same flags and derived fields as the reference's ``get_config``
-(src/config.py:5-109), plus the batch-engine options ``--n_instances`` / ``--runs`` / ``--fixed_horizon``.
+"""Run configuration: the reference's command-line surface (src/config.py:5-109) rebuilt from a flag table.
 
-Derived: maxFEs = 2000*dim (protein: dim 12, maxFEs 1000, n_logpoint 5), log_interval = maxFEs // n_logpoint,
-save_interval = max_learning_step // n_checkpoint, run-stamped log / checkpoint directories, and the two
-always-present comparison baselines DEAP_CMAES and Random_search.
+Every option name, type and default of MetaBox's ``get_config`` is kept so existing command lines keep working; the
+derived fields (maxFEs, n_logpoint, log_interval, save_interval, run-stamped directories, the two comparison baselines
+that are always appended) follow the same rules.  Engine-specific additions: --n_instances, --test_runs,
+--rollout_runs, --fixed_horizon.
 """
 import argparse
 import time
 
-_SUITES = ['bbob', 'bbob-noisy', 'bbob-torch', 'bbob-noisy-torch', 'protein', 'protein-torch']
-_MODES = ('train', 'test', 'rollout', 'run_experiment', 'mgd_test', 'mte_test')
+SUITES = ('bbob', 'bbob-noisy', 'bbob-torch', 'bbob-noisy-torch', 'protein', 'protein-torch')
+MODES = ('train', 'test', 'rollout', 'run_experiment', 'mgd_test', 'mte_test')
+LEVELS = ('easy', 'difficult')
+
+# (flag, kwargs) — grouped as in the reference's parser
+_FLAGS = [
+    # problem / device
+    ('problem', dict(default='bbob', choices=SUITES)),
+    ('dim', dict(type=int, default=10)),
+    ('upperbound', dict(type=float, default=5)),
+    ('difficulty', dict(default='easy', choices=LEVELS)),
+    ('device', dict(default='cpu')),
+    # training
+    ('max_learning_step', dict(type=int, default=1500000)),
+    ('train_batch_size', dict(type=int, default=1)),
+    ('train_agent', dict(default=None)),
+    ('train_optimizer', dict(default=None)),
+    ('agent_save_dir', dict(type=str, default='agent_model/train/')),
+    ('log_dir', dict(type=str, default='output/')),
+    ('draw_interval', dict(type=int, default=3)),
+    ('agent_for_plot_training', dict(type=str, nargs='+', default=['RL_HPSDE_Agent'])),
+    ('n_checkpoint', dict(type=int, default=20)),
+    ('resume_dir', dict(type=str)),
+    # testing
+    ('agent', dict(default=None)),
+    ('agent_load_dir', dict(type=str)),
+    ('optimizer', dict(default=None)),
+    ('agent_for_cp', dict(type=str, nargs='+', default=[])),
+    ('l_optimizer_for_cp', dict(type=str, nargs='+', default=[])),
+    ('t_optimizer_for_cp', dict(type=str, nargs='+', default=[])),
+    ('test_batch_size', dict(type=int, default=1)),
+    # rollout
+    ('agent_for_rollout', dict(type=str, nargs='+')),
+    ('optimizer_for_rollout', dict(type=str, nargs='+')),
+    ('plot_smooth', dict(type=float, default=0.8)),
+    # zero-shot (MGD) / transfer (MTE)
+    ('problem_from', dict(choices=SUITES)),
+    ('problem_to', dict(choices=SUITES)),
+    ('difficulty_from', dict(default='easy', choices=LEVELS)),
+    ('difficulty_to', dict(default='easy', choices=LEVELS)),
+    ('model_from', dict(type=str)),
+    ('model_to', dict(type=str)),
+    ('pre_train_rollout', dict(type=str)),
+    ('scratch_rollout', dict(type=str)),
+    # batch engine
+    ('n_instances', dict(type=int, default=0)),      # cap on instances per kernel launch (0: the whole problem x run table)
+    ('test_runs', dict(type=int, default=51)),       # tester.py:196
+    ('rollout_runs', dict(type=int, default=5)),     # tester.py:321
+]
+ALWAYS_COMPARED = ('DEAP_CMAES', 'Random_search')   # config.py:104-107
 
 
 def build_parser():
-    p = argparse.ArgumentParser()
-    a = p.add_argument
-    # common
-    a('--problem', default='bbob', choices=_SUITES, help='specify the problem suite')
-    a('--dim', type=int, default=10, help='dimension of search space')
-    a('--upperbound', type=float, default=5, help='upperbound of search space')
-    a('--difficulty', default='easy', choices=['easy', 'difficult'], help='difficulty level')
-    a('--device', default='cpu', help='device of the policy networks')
-    for m in _MODES:
-        a('--' + m, default=None, action='store_true', help=f'switch to {m} mode')
-    # training
-    a('--max_learning_step', type=int, default=1500000, help='the maximum learning step for training')
-    a('--train_batch_size', type=int, default=1, help='batch size of train set')
-    a('--train_agent', default=None, help='agent for training')
-    a('--train_optimizer', default=None, help='optimizer for training')
-    a('--agent_save_dir', type=str, default='agent_model/train/', help='save your own trained agent model')
-    a('--log_dir', type=str, default='output/', help='logging testing output')
-    a('--draw_interval', type=int, default=3, help='interval epochs in drawing figures')
-    a('--agent_for_plot_training', type=str, nargs='+', default=['RL_HPSDE_Agent'], help='learnable optimizer to compare')
-    a('--n_checkpoint', type=int, default=20, help='number of training checkpoints')
-    a('--resume_dir', type=str, help='directory to load previous checkpoint model')
-    # testing
-    a('--agent', default=None, help='None: traditional optimizer, else Learnable optimizer')
-    a('--agent_load_dir', type=str, help='load your own agent model')
-    a('--optimizer', default=None, help='your own learnable or traditional optimizer')
-    a('--agent_for_cp', type=str, nargs='+', default=[], help='learnable optimizer to compare')
-    a('--l_optimizer_for_cp', type=str, nargs='+', default=[], help='learnable optimizer to compare')
-    a('--t_optimizer_for_cp', type=str, nargs='+', default=[], help='traditional optimizer to compare')
-    a('--test_batch_size', type=int, default=1, help='batch size of test set')
-    # rollout
-    a('--agent_for_rollout', type=str, nargs='+', help='learnable agent for rollout')
-    a('--optimizer_for_rollout', type=str, nargs='+', help='learnabel optimizer for rollout')
-    a('--plot_smooth', type=float, default=0.8, help='smoothness of figure curves in [0, 1]')
-    # zero-shot / transfer
-    a('--problem_from', choices=_SUITES, help='source problem set in zero-shot and transfer learning')
-    a('--problem_to', choices=_SUITES, help='target problem set in zero-shot and transfer learning')
-    a('--difficulty_from', default='easy', choices=['easy', 'difficult'])
-    a('--difficulty_to', default='easy', choices=['easy', 'difficult'])
-    a('--model_from', type=str, help='the model trained on source problem set')
-    a('--model_to', type=str, help='the model trained on target problem set')
-    a('--pre_train_rollout', type=str, help='path of pre-train models rollout result .pkl file')
-    a('--scratch_rollout', type=str, help='path of scratch models rollout result .pkl file')
-    # batch engine (new)
-    a('--n_instances', type=int, default=0, help='cap on instances stepped per kernel launch (0 = all problem x run pairs)')
-    a('--test_runs', type=int, default=51, help='independent runs per problem in --test (reference: 51)')
-    a('--rollout_runs', type=int, default=5, help='independent runs per problem and checkpoint in --rollout (reference: 5)')
-    a('--fixed_horizon', default=False, action='store_true', help='disable the gbest<=1e-8 early stop')
-    return p
+    parser = argparse.ArgumentParser(description='MetaBBO rollout engine (MetaBox-compatible options)')
+    for name, kw in _FLAGS:
+        parser.add_argument('--' + name, **kw)
+    for mode in MODES:
+        parser.add_argument('--' + mode, default=None, action='store_true')
+    parser.add_argument('--fixed_horizon', default=False, action='store_true')   # no gbest <= 1e-8 early stop
+    return parser
+
+
+def _derive(cfg):
+    protein = cfg.problem in ('protein', 'protein-torch')
+    cfg.maxFEs = 1000 if protein else 2000 * cfg.dim
+    cfg.bo_maxFEs = 10 if protein else 10 * cfg.dim
+    cfg.n_logpoint = 5 if protein else 50
+    if protein:
+        cfg.dim = 12
+    cfg.log_interval = cfg.maxFEs // cfg.n_logpoint
+    cfg.save_interval = cfg.max_learning_step // cfg.n_checkpoint
+    cfg.run_time = time.strftime('%Y%m%dT%H%M%S') + f'_{cfg.problem}_{cfg.difficulty}_{cfg.dim}D'
+    for kind in ('test', 'rollout', 'mgd_test', 'mte_test'):
+        setattr(cfg, kind + '_log_dir', f'{cfg.log_dir}/{kind}/{cfg.run_time}/')
+    if cfg.train or cfg.run_experiment:
+        cfg.agent_save_dir = f'{cfg.agent_save_dir}{cfg.train_agent}/{cfg.run_time}/'
+    cfg.t_optimizer_for_cp += [b for b in ALWAYS_COMPARED if b not in cfg.t_optimizer_for_cp]
+    return cfg
 
 
 def get_config(args=None):
-    config = build_parser().parse_args(args)
-    config.maxFEs = 2000 * config.dim
-    config.bo_maxFEs = 10 * config.dim           # Bayesian optimisation gets a much smaller budget
-    config.n_logpoint = 50
-    if config.run_experiment and len(config.agent_for_cp) >= 1:
-        assert config.agent_load_dir is not None, \
-            "Option --agent_load_dir must be given since you specified option --agent_for_cp."
-    if config.mgd_test or config.mte_test:
-        config.problem = config.problem_to
-        config.difficulty = config.difficulty_to
-    if config.problem in ['protein', 'protein-torch']:
-        config.dim = 12
-        config.maxFEs = 1000
-        config.bo_maxFEs = 10
-        config.n_logpoint = 5
-    config.run_time = f'{time.strftime("%Y%m%dT%H%M%S")}_{config.problem}_{config.difficulty}_{config.dim}D'
-    for mode in ('test', 'rollout', 'mgd_test', 'mte_test'):
-        setattr(config, f'{mode}_log_dir', f'{config.log_dir}/{mode}/{config.run_time}/')
-    if config.train or config.run_experiment:
-        config.agent_save_dir = config.agent_save_dir + config.train_agent + '/' + config.run_time + '/'
-    config.save_interval = config.max_learning_step // config.n_checkpoint
-    config.log_interval = config.maxFEs // config.n_logpoint
-    for always in ('DEAP_CMAES', 'Random_search'):
-        if always not in config.t_optimizer_for_cp:
-            config.t_optimizer_for_cp.append(always)
-    return config
+    cfg = build_parser().parse_args(args)
+    if cfg.run_experiment and cfg.agent_for_cp:
+        assert cfg.agent_load_dir is not None, 'Option --agent_load_dir must be given since you specified option --agent_for_cp.'
+    if cfg.mgd_test or cfg.mte_test:                 # zero-shot / transfer runs evaluate on the target suite
+        cfg.problem, cfg.difficulty = cfg.problem_to, cfg.difficulty_to
+    return _derive(cfg)

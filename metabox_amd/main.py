@@ -1,60 +1,73 @@
-"""Command-line entry point (reference: src/main.py:10-89): exactly one of --train / --rollout / --test /
---run_experiment.  `python -m metabox_amd.main --test --problem bbob --agent_load_dir ... --agent_for_cp RLEPSO_Agent
---l_optimizer_for_cp RLEPSO_Optimizer`.  --mgd_test / --mte_test are post-processing of result pickles and are not part
-of this build."""
+"""Command-line entry point with MetaBox's modes (reference: src/main.py:10-89).
+
+    python -m metabox_amd.main --test --problem bbob --agent_load_dir models/ --agent_for_cp RLEPSO_Agent \\
+                               --l_optimizer_for_cp RLEPSO_Optimizer --device cuda
+
+Exactly one of --train / --rollout / --test / --run_experiment may be given.  --mgd_test / --mte_test only post-process
+result pickles (src/tester.py:421-608) and are not part of this build.
+"""
 import os
 import shutil
 
 import torch
 
-from .config import get_config
+from .config import MODES, get_config
 from .tester import Tester, rollout
 from .trainer import Trainer
 
 
+def _train(config):
+    with torch.enable_grad():
+        return Trainer(config).train()
+
+
+def _rollout(config):
+    with torch.no_grad():
+        return rollout(config)
+
+
+def _test(config):
+    with torch.no_grad():
+        return Tester(config).test()
+
+
+def _experiment(config):
+    """train -> rollout of the 21 checkpoints -> test of the final checkpoint (main.py:40-80)."""
+    _train(config)
+    save_dir = config.agent_save_dir
+    staged = os.path.join(save_dir, config.train_agent) + '/'          # rollout() expects <load_dir>/<agent>/checkpointK.pkl
+    os.makedirs(staged, exist_ok=True)
+    for entry in os.scandir(save_dir):
+        if entry.is_file():
+            shutil.copy(entry.path, staged)
+    user_load_dir = config.agent_load_dir
+    config.agent_load_dir = save_dir
+    config.agent_for_rollout, config.optimizer_for_rollout = [config.train_agent], [config.train_optimizer]
+    _rollout(config)
+    shutil.rmtree(staged)
+    if user_load_dir is not None:
+        config.agent_load_dir = user_load_dir
+    final_model = os.path.join(config.agent_load_dir, config.train_agent + '.pkl')
+    shutil.copy(os.path.join(save_dir, f'checkpoint{config.n_checkpoint}.pkl'), final_model)
+    if config.train_agent != config.agent and config.train_agent not in config.agent_for_cp:
+        config.agent_for_cp.append(config.train_agent)
+    if config.train_optimizer != config.optimizer and config.train_optimizer not in config.l_optimizer_for_cp:
+        config.l_optimizer_for_cp.append(config.train_optimizer)
+    _test(config)
+    if user_load_dir is None:
+        os.remove(final_model)
+
+
+_DISPATCH = {'train': _train, 'rollout': _rollout, 'test': _test, 'run_experiment': _experiment}
+
+
 def main(argv=None):
     config = get_config(argv)
-    modes = [config.train, config.rollout, config.test, config.run_experiment, config.mgd_test, config.mte_test]
-    assert sum(m is not None for m in modes) == 1, \
-        'Among train, rollout, test, run_experiment, mgd_test & mte_test, only one mode can be given at one time.'
-    if config.mgd_test or config.mte_test:
-        raise NotImplementedError('mgd_test / mte_test post-process result pickles (src/tester.py:421-608); out of scope here.')
-    if config.train:
-        torch.set_grad_enabled(True)
-        Trainer(config).train()
-    if config.rollout:
-        torch.set_grad_enabled(False)
-        rollout(config)
-    if config.test:
-        torch.set_grad_enabled(False)
-        Tester(config).test()
-    if config.run_experiment:                      # train -> rollout -> test (main.py:40-80)
-        torch.set_grad_enabled(True)
-        Trainer(config).train()
-        agent_save_dir = config.agent_save_dir
-        rollout_save_dir = os.path.join(agent_save_dir, config.train_agent) + '/'
-        os.makedirs(rollout_save_dir, exist_ok=True)
-        for fn in os.listdir(agent_save_dir):
-            if os.path.isfile(os.path.join(agent_save_dir, fn)):
-                shutil.copy(os.path.join(agent_save_dir, fn), rollout_save_dir)
-        test_agent_load_dir = config.agent_load_dir
-        config.agent_load_dir = agent_save_dir
-        config.agent_for_rollout = [config.train_agent]
-        config.optimizer_for_rollout = [config.train_optimizer]
-        torch.set_grad_enabled(False)
-        rollout(config)
-        shutil.rmtree(rollout_save_dir)
-        if test_agent_load_dir is not None:
-            config.agent_load_dir = test_agent_load_dir
-        test_model_file = os.path.join(config.agent_load_dir, f'{config.train_agent}.pkl')
-        shutil.copy(os.path.join(agent_save_dir, f'checkpoint{config.n_checkpoint}.pkl'), test_model_file)
-        if config.train_agent != config.agent and config.train_agent not in config.agent_for_cp:
-            config.agent_for_cp.append(config.train_agent)
-        if config.train_optimizer != config.optimizer and config.train_optimizer not in config.l_optimizer_for_cp:
-            config.l_optimizer_for_cp.append(config.train_optimizer)
-        Tester(config).test()
-        if test_agent_load_dir is None:
-            os.remove(test_model_file)
+    chosen = [m for m in MODES if getattr(config, m) is not None]
+    assert len(chosen) == 1, 'Among train, rollout, test, run_experiment, mgd_test & mte_test, only one mode can be given at one time.'
+    if chosen[0] not in _DISPATCH:
+        raise NotImplementedError(f'--{chosen[0]} post-processes result pickles and is out of scope of this build')
+    return _DISPATCH[chosen[0]](config)
 
 
 if __name__ == '__main__':

@@ -1,5 +1,5 @@
-"""Base class of classic (non-learnable) optimizers (reference: src/optimizer/basic_optimizer.py:10-15):
-``run_episode(problem) -> {'cost': [...], 'fes': int}``."""
+"""Classic (non-learnable) optimizers implement ``run_episode(problem) -> {'cost': [...], 'fes': int}``
+(reference protocol: src/optimizer/basic_optimizer.py:10-15)."""
 
 
 class Basic_Optimizer:
@@ -7,4 +7,4 @@ class Basic_Optimizer:
         self.__config = config
 
     def run_episode(self, problem):
-        raise NotImplementedError
+        raise NotImplementedError('run_episode(problem) must be provided by the optimizer')

@@ -233,3 +233,30 @@ def test_batched_ppo_training_updates_the_policy(tmp_path):
     out = Trainer(tcfg).train()
     torch.set_grad_enabled(False)
     assert out['learn_steps'][-1] == 6 and os.path.exists(tcfg.agent_save_dir + 'checkpoint2.pkl')
+
+
+@pytest.mark.gpu
+def test_batched_reinforce_training_for_lde(tmp_path):
+    import torch
+    from metabox_amd.agent import LDE_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import LDE_Optimizer
+    from metabox_amd.utils import construct_problem_set
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda', '--train', '--train_agent', 'LDE_Agent',
+                      '--train_optimizer', 'LDE_Optimizer', '--max_learning_step', '100', '--n_checkpoint', '50',
+                      '--agent_save_dir', str(tmp_path / 'lde') + '/'])
+    agent = LDE_Agent(cfg).load_exported_weights(np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'metabox_amd',
+                                                                        'agent_model', 'lde_bbob_easy.npz'))).to('cuda')
+    opt = LDE_Optimizer(cfg)
+    train, test = construct_problem_set(cfg)
+    ps = (train + test).data
+    env = BatchedPBO_Env(ps, opt, np.arange(48) % len(ps), np.arange(48, dtype=np.uint64) + 9)
+    before = [p.detach().clone() for p in agent.net.parameters()]
+    torch.set_grad_enabled(True)
+    exceed, info = agent.train_batch(env, max_updates=3)
+    torch.set_grad_enabled(False)
+    assert info['learn_steps'] == 3 and not exceed and np.isfinite(info['last_losses'][0]) and np.isfinite(info['return'])
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.net.parameters()))
+    assert os.path.exists(cfg.agent_save_dir + 'checkpoint1.pkl')
+    env.close()
