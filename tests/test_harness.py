@@ -260,3 +260,31 @@ def test_batched_reinforce_training_for_lde(tmp_path):
     assert any(not torch.equal(a, b) for a, b in zip(before, agent.net.parameters()))
     assert os.path.exists(cfg.agent_save_dir + 'checkpoint1.pkl')
     env.close()
+
+
+@pytest.mark.gpu
+def test_cli_entry_point_test_mode(tmp_path):
+    """`python -m metabox_amd.main --test ...` end to end with LDE and DE-DDQN agents on protein-docking problems."""
+    from metabox_amd.agent import DE_DDQN_Agent, LDE_Agent
+    from metabox_amd.agent.utils import save_class
+    from metabox_amd.config import get_config
+    from metabox_amd.main import main
+    load_dir = str(tmp_path / 'models') + '/'
+    base = get_config(['--problem', 'protein', '--device', 'cuda'])
+    base.agent_save_dir = None
+    save_class(load_dir, 'LDE_Agent', LDE_Agent(copy.deepcopy(base)).load_exported_weights(
+        np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'metabox_amd', 'agent_model', 'lde_bbob_easy.npz'))))
+    save_class(load_dir, 'DE_DDQN_Agent', DE_DDQN_Agent(copy.deepcopy(base)).load_exported_weights(load('ddqn_policy.npz')))
+    res = main(['--test', '--problem', 'protein', '--difficulty', 'difficult', '--device', 'cuda', '--agent_load_dir', load_dir,
+                '--log_dir', str(tmp_path / 'out'), '--test_runs', '2', '--n_instances', '256',
+                '--agent_for_cp', 'LDE_Agent', 'DE_DDQN_Agent', '--l_optimizer_for_cp', 'LDE_Optimizer', 'DE_DDQN_Optimizer'])
+    assert len(res['cost']) == 210                                       # protein-difficult test split: 21 complexes x 10 models
+    one = res['cost'][next(iter(res['cost']))]
+    assert set(one) == {'LDE_Agent', 'DE_DDQN_Agent', 'Random_search'}
+    for rows in one.values():
+        assert len(rows) == 2 and all(len(r) == 51 and r[0] >= r[5] and r[5] == r[50] for r in rows)   # 6 log points, padded to 51
+    assert all(v == 1000 for v in res['fes'][next(iter(res['fes']))]['DE_DDQN_Agent'])
+    with pytest.raises(AssertionError):
+        main(['--test', '--train'])
+    with pytest.raises(NotImplementedError):
+        main(['--mgd_test', '--problem_to', 'bbob'])
