@@ -533,7 +533,36 @@ def gen_stats():
     np.savez_compressed(os.path.join(OUT, 'rlepso_stats.npz'), **data)
 
 
-SECTIONS = {'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def gen_lde_stats():
+    """Reference LDE (shipped bbob_easy weights) on three bbob problems, 30 seeded runs each: final cost / fes / return."""
+    scratch = tempfile.mkdtemp()
+    from optimizer import LDE_Optimizer
+    from environment import PBO_Env
+    import copy
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/LDE_Agent.pkl'))
+    config = ref_import.ref_config(['--problem', 'bbob', '--dim', '10'], scratch)
+    tr, te, _ = all_problems('bbob', 10)
+    byid = {fid_of(p): p for p in tr + te}
+    data = {}
+    for fid in (1, 15, 20):
+        p = byid[fid]
+        fc, fes, ret = [], [], []
+        for r in range(30):
+            opt = LDE_Optimizer(copy.deepcopy(config))
+            np.random.seed(r)
+            torch.manual_seed(r)
+            p.reset()
+            with torch.no_grad():
+                info = agent.rollout_episode(PBO_Env(p, opt))
+            fc.append(info['cost'][-1]); fes.append(info['fes']); ret.append(info['return'])
+        data[f'{fid}/final_cost'] = np.array(fc, dtype=np.float64)
+        data[f'{fid}/fes'] = np.array(fes, dtype=np.float64)
+        data[f'{fid}/return'] = np.array(ret, dtype=np.float64)
+        print(fid, str(p), np.mean(fc), np.std(fc), np.mean(fes), np.mean(ret))
+    np.savez_compressed(os.path.join(OUT, 'lde_stats.npz'), **data)
+
+
+SECTIONS = {'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
