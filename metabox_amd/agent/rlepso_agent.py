@@ -54,6 +54,12 @@ class Actor(nn.Module):
                 w1=torch.cat([l.weight[:, 0] for l in lin[0]])[None, :].contiguous(), b1=torch.cat([l.bias for l in lin[0]])[None, :].contiguous(),
                 w2=torch.stack([l.weight.t() for l in lin[1]]).contiguous(), b2=torch.stack([l.bias for l in lin[1]])[:, None, :].contiguous(),
                 w3=torch.stack([l.weight.t() for l in lin[2]]).contiguous(), b3=torch.stack([l.bias for l in lin[2]])[:, None, :].contiguous())
+            # (tanh + 1)/2 and (tanh + 1)/2 * (max_sigma - min_sigma) + min_sigma as ONE affine map of the stacked tanh output:
+            # row 0 (mu) = 0.5 t + 0.5 (bit-identical to (t + 1)/2), row 1 (sigma) = s t + (s + min_sigma), s = (max - min)/2
+            half = 0.5 * (self.max_sigma - self.min_sigma)
+            dev = self._fw['w1'].device
+            self._fw['scale'] = torch.tensor([0.5, half], dtype=torch.float32, device=dev).view(2, 1, 1)
+            self._fw['shift'] = torch.tensor([0.5, half + self.min_sigma], dtype=torch.float32, device=dev).view(2, 1, 1)
             self._fw_key = key
         return self._fw
 
@@ -66,11 +72,10 @@ class Actor(nn.Module):
         h = h.view(B, 2, -1).transpose(0, 1)                                        # [2, B, 64]
         h = torch.relu_(torch.baddbmm(f['b2'], h, f['w2']))                         # [2, B, 32]
         t = torch.tanh_(torch.baddbmm(f['b3'], h, f['w3']))                         # [2, B, 35]
-        mu = (t[0] + 1.) / 2.
-        sigma = (t[1] + 1.) / 2. * (self.max_sigma - self.min_sigma) + self.min_sigma
+        ms = torch.addcmul(f['shift'], t, f['scale'])                               # [mu ; sigma]
         # mu + sigma * eps == Normal(mu, sigma).sample(); unlike torch.normal(tensor, tensor) it has no host-side check and
         # can be captured into a hipGraph
-        return torch.addcmul(mu, sigma, torch.randn_like(mu)).clamp_(0, 1)
+        return torch.addcmul(ms[0], ms[1], torch.randn_like(ms[0])).clamp_(0, 1)
 
 
 class ActorTable:
