@@ -150,6 +150,7 @@ __device__ __forceinline__ void block_argmin(const double* a, int n, double* red
             if (x < v) { v = x; idx = j; }
         }
         wave_argmin(v, idx);
+        if (idx >= n) { idx = 0; v = a[0]; }          // every entry +inf (or NaN): np.argmin answers 0; never hand back an out-of-range index
         if (tid == 0) { red[0] = v; red[1] = (double)idx; }
     }
     __syncthreads();
