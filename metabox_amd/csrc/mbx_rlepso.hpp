@@ -126,6 +126,90 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
     __syncthreads();
 }
 
+// Everything the velocity phase needs, bundled so that the per-item routine can be a template on the item width.
+struct MoveCtx {
+    const RlLds& L; const BatchParams& bp; const double* tape; const Rng& rng; double* gPos; double* gVel;
+    const int* ORDER; const int* NLESS; const int* RANK; int NP, D, G; double lb, ub, vmax; const FastDiv& fg;
+};
+
+// Move W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk (rlepso_optimizer.py:179-195).
+template <int W>
+__device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
+{
+    const RlLds& L = c.L;
+    const int NP = c.NP, D = c.D;
+    const int i = c.ORDER[rk], e0 = i * D + d0, es0 = rk * D + d0;
+    const double r1 = L.R1[i], r2 = L.R2[i], fi = L.PBC[i], pci = c.bp.pci[i];
+    double uc[W], uf[W], cur[W], pp[W], v_clpso[W];
+    int t1[W], t2[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const int e = e0 + q;
+        if (c.tape) {
+            uc[q] = c.tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
+            t1[q] = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2[q] = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1];
+            uf[q] = c.tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e];
+        } else {
+            U4 w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc[q] = u53(w.x, w.y);
+            t1[q] = (int)__umulhi(w.z, (uint32_t)NP); t2[q] = (int)__umulhi(w.w, (uint32_t)NP);
+            w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf[q] = u53(w.x, w.y);
+        }
+        cur[q] = L.X[e]; pp[q] = L.PB[es0 + q];
+        // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
+        const int tw = L.PBC[t2[q]] < L.PBC[t1[q]] ? t2[q] : t1[q];
+        const double exemplar = uc[q] > pci ? pp[q] : L.PB[c.RANK[tw] * D + d0 + q];
+        v_clpso[q] = uc[q] * (exemplar - cur[q]);
+    }
+    // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109).
+    //  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
+    //    among the strictly better particles (negative ratios) if there are any, otherwise it is 0 and np.argmin
+    //    returns the lowest index with pbest_j == pbest_i.  Only the `nless` better particles are scanned, in
+    //    ascending-cost order (ORDER / NC), halving the O(NP^2 D) work on average.
+    //  * ratios are compared by cross-multiplication (denominators >= 1e-5 > 0): a_j/b_j < a*/b* <=> a_j b* < a* b_j.
+    //    Identical candidates (same pbest cost and same coordinate) are adjacent in the (cost, index) order, so the
+    //    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
+    //    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
+    const int nless = c.NLESS[i];
+    int kb[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) kb[q] = nless;                   // rank of the exemplar
+#ifndef MBX_ABLATE_FDR
+    if (nless > 0) {
+        double ab[W], bb[W];
+        const double a0 = L.NC[0] - fi;
+#pragma unroll
+        for (int q = 0; q < W; ++q) { kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
+        const double* col = L.PB + d0;
+#pragma unroll 4
+        for (int k = 1; k < nless; ++k) {
+            const double a = L.NC[k] - fi;                        // shared by the W coordinates
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
+                if (a * bb[q] < ab[q] * b) { ab[q] = a; bb[q] = b; kb[q] = k; }
+            }
+        }
+    }
+#endif
+    const int g = c.fg.div(i);
+    double cw = 0., c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
+    if (g < c.G) { const double* k = L.COEF + g * 6; cw = k[1]; c1 = k[2]; c2 = k[3]; c3 = k[4]; c4 = k[5]; }
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const int e = e0 + q, d = d0 + q;
+        const double v_fdr = uf[q] * (L.PB[kb[q] * D + d] - pp[q]);
+        const double v_pbest = r1 * (pp[q] - cur[q]);
+        const double v_gbest = r2 * (L.GB[d] - cur[q]);
+        double nv = cw * L.Z[e] + c1 * v_clpso[q] + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
+        nv = fmin(fmax(nv, -c.vmax), c.vmax);
+        double np_ = cur[q] + nv;
+        np_ = fmin(fmax(np_, c.lb), c.ub);
+        L.X[e] = np_;
+        c.gPos[e] = np_;
+        c.gVel[e] = nv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PBO_Env.reset(): init_population (rlepso_optimizer.py:39-65)
 // ------------------------------------------------------------------------------------------------
@@ -283,65 +367,17 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     for (int e = tid; e < NE; e += kThreads) { const int i = fd.div(e), d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
     __syncthreads();
 
-    // ---- velocity / position update, one element per thread-iteration (:179-195).  Elements are visited in pbest-rank
-    // order so that the lanes of a wave own particles of similar rank (see the FDR scan below).
-    for (int es = tid; es < NE; es += kThreads) {
-        const int rk = fd.div(es), d = es - rk * D;
-        const int i = ORDER[rk], e = i * D + d;
-        const double r1 = L.R1[i], r2 = L.R2[i];
-        double uc, uf; int t1, t2;
-        if (tape) {
-            uc = tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
-            t1 = (int)tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2 = (int)tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1];
-            uf = tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e];
-        } else {
-            U4 w = rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc = u53(w.x, w.y);
-            t1 = (int)__umulhi(w.z, (uint32_t)NP); t2 = (int)__umulhi(w.w, (uint32_t)NP);
-            w = rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf = u53(w.x, w.y);
-        }
-        const double cur = L.X[e], pp = L.PB[es], fi = L.PBC[i];
-        // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
-        const double pci = bp.pci[i];
-        const int tw = L.PBC[t2] < L.PBC[t1] ? t2 : t1;
-        const double exemplar = uc > pci ? pp : L.PB[RANK[tw] * D + d];
-        const double v_clpso = uc * (exemplar - cur);
-        // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109).
-        //  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
-        //    among the strictly better particles (negative ratios) if there are any, otherwise it is 0 and np.argmin
-        //    returns the lowest index with pbest_j == pbest_i.  Only the `nless` better particles are scanned, in
-        //    ascending-cost order (ORDER / NC), halving the O(NP^2 D) work on average.
-        //  * ratios are compared by cross-multiplication (denominators >= 1e-5 > 0): a_j/b_j < a*/b* <=> a_j b* < a* b_j.
-        //    Identical candidates (same pbest cost and same coordinate) are adjacent in the (cost, index) order, so the
-        //    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
-        //    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
-        const int nless = NLESS[i];
-        int kb = nless;                                             // rank of the exemplar
-#ifndef MBX_ABLATE_FDR
-        if (nless > 0) {
-            kb = 0;
-            double ab = L.NC[0] - fi, bb = fabs(L.PB[d] - pp) + 1e-5;
-            const double* col = L.PB + d;
-#pragma unroll 4
-            for (int k = 1; k < nless; ++k) {
-                const double a = L.NC[k] - fi;
-                const double b = fabs(col[k * D] - pp) + 1e-5;
-                if (a * bb < ab * b) { ab = a; bb = b; kb = k; }
-            }
-        }
-#endif
-        const double v_fdr = uf * (L.PB[kb * D + d] - pp);
-        const double v_pbest = r1 * (pp - cur);
-        const double v_gbest = r2 * (L.GB[d] - cur);
-        const int g = fg.div(i);
-        double cw = 0., c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
-        if (g < G) { const double* c = L.COEF + g * 6; cw = c[1]; c1 = c[2]; c2 = c[3]; c3 = c[4]; c4 = c[5]; }
-        double nv = cw * L.Z[e] + c1 * v_clpso + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
-        nv = fmin(fmax(nv, -vmax), vmax);
-        double np_ = cur + nv;
-        np_ = fmin(fmax(np_, lb), ub);
-        L.X[e] = np_;
-        gPos[e] = np_;
-        gVel[e] = nv;
+    // ---- velocity / position update (:179-195).  A work item is W adjacent dimensions of one particle (W = 2 when D is
+    // even: the pbest-cost difference of the FDR scan is then shared by both dimensions and their coordinates come from
+    // one 16-byte LDS read).  Items are visited in pbest-rank order so that the lanes of a wave own particles of similar
+    // rank, i.e. similar FDR trip counts.
+    const MoveCtx mc{L, bp, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
+    if ((D & 1) == 0) {
+        const int HD = D >> 1;
+        const FastDiv fh(HD);
+        for (int ps = tid; ps < NP * HD; ps += kThreads) { const int rk = fh.div(ps); rl_move<2>(mc, rk, 2 * (ps - rk * HD)); }
+    } else {
+        for (int es = tid; es < NE; es += kThreads) { const int rk = fd.div(es); rl_move<1>(mc, rk, es - rk * D); }
     }
     __syncthreads();
 
