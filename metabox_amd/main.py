@@ -3,8 +3,7 @@
     python -m metabox_amd.main --test --problem bbob --agent_load_dir models/ --agent_for_cp RLEPSO_Agent \\
                                --l_optimizer_for_cp RLEPSO_Optimizer --device cuda
 
-Exactly one of --train / --rollout / --test / --run_experiment may be given.  --mgd_test / --mte_test only post-process
-result pickles (src/tester.py:421-608) and are not part of this build.
+Exactly one of --train / --rollout / --test / --run_experiment / --mgd_test / --mte_test may be given.
 """
 import os
 import shutil
@@ -12,7 +11,7 @@ import shutil
 import torch
 
 from .config import MODES, get_config
-from .tester import Tester, rollout
+from .tester import Tester, mgd_test, mte_test, rollout
 from .trainer import Trainer
 
 
@@ -58,15 +57,19 @@ def _experiment(config):
         os.remove(final_model)
 
 
-_DISPATCH = {'train': _train, 'rollout': _rollout, 'test': _test, 'run_experiment': _experiment}
+def _mgd(config):
+    with torch.no_grad():
+        return mgd_test(config)
+
+
+_DISPATCH = {'train': _train, 'rollout': _rollout, 'test': _test, 'run_experiment': _experiment, 'mgd_test': _mgd,
+             'mte_test': mte_test}
 
 
 def main(argv=None):
     config = get_config(argv)
     chosen = [m for m in MODES if getattr(config, m) is not None]
     assert len(chosen) == 1, 'Among train, rollout, test, run_experiment, mgd_test & mte_test, only one mode can be given at one time.'
-    if chosen[0] not in _DISPATCH:
-        raise NotImplementedError(f'--{chosen[0]} post-processes result pickles and is out of scope of this build')
     return _DISPATCH[chosen[0]](config)
 
 

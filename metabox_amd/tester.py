@@ -3,6 +3,8 @@
 ``Tester(config).test()``   51 seeded runs x test problems x (agent, optimizer) pairs  (tester.py:180-263)
 ``rollout(config)``         21 checkpoints x train problems x 5 runs                   (tester.py:266-352)
 ``test_for_random_search``  Random_search over train+test problems, 51 runs            (tester.py:355-407)
+``mgd_test(config)``        zero-shot gap of two saved agents on the target suite      (tester.py:421-497)
+``mte_test(config)``        transfer efficiency from two rollout.pkl files (host only)  (tester.py:500-608)
 
 Where the reference runs one (problem, run) episode at a time, here the whole (problem x run) table of a pair is ONE
 lock-step batch on the GPU (sharded over ranks when torch.distributed is initialised; rows are all-gathered at the end
@@ -249,3 +251,104 @@ def name_translate(problem):
     if problem in ['protein', 'protein-torch']:
         return 'Protein-Docking'
     raise ValueError(problem + ' is not defined!')
+
+
+def mgd_test(config):
+    """Meta-generalisation gap MGD = 100 (1 - AEI_from / AEI_to) of one agent class trained on two suites and tested on
+    the target suite (tester.py:421-497).  Both agents share the learnable optimizer named by --optimizer; each
+    (problem x 51 runs) table is one lock-step batch.  Returns {'aei', 'aei_std', 'mgd'} and writes the reference's
+    two pickles."""
+    from .logger import Logger
+    _, test_set = construct_problem_set(config)
+    problems = test_set.data
+    agents = []
+    for path in (config.model_from, config.model_to):
+        with open(path, 'rb') as f:
+            agents.append(pickle.load(f))
+    optimizer = _lookup(_optimizers, config.optimizer)(copy.deepcopy(config))
+    names = [f'{config.agent}_from', f'{config.agent}_to']
+    results = {'cost': {str(p): {n: [] for n in names} for p in problems},
+               'fes': {str(p): {n: [] for n in names} for p in problems},
+               'T0': cal_t0(config.dim, config.maxFEs), 'T1': {n: 0. for n in names}, 'T2': {n: 0. for n in names}}
+    runs = getattr(config, 'test_runs', 51)
+    cap = getattr(config, 'n_instances', 0)
+    cache = {}
+    for name, agent in zip(names, agents):
+        if hasattr(agent, 'to'):
+            agent.to(config.device)
+        cost, fes, _, wall = run_pairs(problems, _learnable_runner(agent, optimizer, cache), runs, cap)
+        _fill(results, problems, name, runs, cost, fes)
+        results['T2'][name] = wall / len(cost)
+    baseline = test_for_random_search(config)
+    rank, _ = _world()
+    if rank == 0:
+        os.makedirs(config.mgd_test_log_dir, exist_ok=True)
+        with open(config.mgd_test_log_dir + 'test.pkl', 'wb') as f:
+            pickle.dump(results, f, -1)
+        with open(config.mgd_test_log_dir + 'random_search_baseline.pkl', 'wb') as f:
+            pickle.dump(baseline, f, -1)
+    aei, aei_std = Logger(config).aei_metric(results, baseline, config.maxFEs)
+    mgd = 100 * (1 - aei[names[0]] / aei[names[1]])
+    if rank == 0:
+        print(f'AEI: {aei}')
+        print(f'AEI STD: {aei_std}')
+        print(f'MGD({name_translate(config.problem_from)}_{config.difficulty_from}, '
+              f'{name_translate(config.problem_to)}_{config.difficulty_to}) of {config.agent}: {mgd}%')
+    return {'aei': aei, 'aei_std': aei_std, 'mgd': mgd}
+
+
+def _checkpoint_returns(path, agent):
+    """rollout.pkl -> [checkpoint, problem * run] matrix of returns (problems side by side, tester.py:508-521)."""
+    with open(path, 'rb') as f:
+        returns = pickle.load(f)['return']
+    return np.concatenate([np.asarray(returns[p][agent], dtype=np.float64) for p in returns], axis=1)
+
+
+def _running_mean(curve):
+    """The reference's smoothing loop with smooth = 1 (tester.py:553-571) is the prefix mean of the curve."""
+    return np.cumsum(curve) / np.arange(1, len(curve) + 1)
+
+
+def transfer_efficiency(pretrain, scratch):
+    """MTE = 1 - t/T (tester.py:577-590).  T: fraction of training at which the from-scratch curve peaks; t: fraction at
+    which the pre-trained curve first reaches that peak (linear interpolation between checkpoints; 1 if it never does,
+    0 if it starts above)."""
+    n = len(scratch)
+    top = int(np.argmax(scratch))
+    peak = scratch[top]
+    t = 0
+    if pretrain[0] < peak:
+        for i in range(1, n):
+            if pretrain[i - 1] < peak <= pretrain[i]:
+                t = ((peak - pretrain[i - 1]) / (pretrain[i] - pretrain[i - 1]) + i - 1) / n
+                break
+    if pretrain[-1] < peak:
+        t = 1
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return float(1 - np.float64(t) / np.float64(top / n))
+
+
+def mte_test(config):
+    """Meta-transfer efficiency of fine-tuning vs training from scratch, from the two rollout.pkl files named by
+    --pre_train_rollout / --scratch_rollout (tester.py:500-608).  Pure host post-processing: checkpoint-mean returns,
+    Savitzky-Golay (13, 5), prefix mean, then `transfer_efficiency`.  The reference's figure is replaced by the curves
+    it would draw, saved as MTE_<agent>.npz."""
+    from scipy.signal import savgol_filter
+    agent = config.agent
+    pre = _checkpoint_returns(config.pre_train_rollout, agent)
+    scr = _checkpoint_returns(config.scratch_rollout, agent)
+    runs = getattr(config, 'rollout_runs', 5)
+    n_problem = pre.shape[1] // runs
+
+    def band(m):            # mean over problems of the per-problem run std, as standard error
+        return m.reshape(m.shape[0], n_problem, runs).std(-1).mean(-1) / np.sqrt(runs)
+
+    curve_pre = _running_mean(savgol_filter(pre.mean(-1), 13, 5))
+    curve_scr = _running_mean(savgol_filter(scr.mean(-1), 13, 5))
+    mte = transfer_efficiency(curve_pre, curve_scr)
+    print(f'MTE({name_translate(config.problem_from)}_{config.difficulty_from}, '
+          f'{name_translate(config.problem_to)}_{config.difficulty_to}) of {config.agent}: {mte}')
+    os.makedirs(config.mte_test_log_dir, exist_ok=True)
+    np.savez(os.path.join(config.mte_test_log_dir, f'MTE_{agent}.npz'), pretrain=curve_pre, scratch=curve_scr,
+             pretrain_band=band(pre), scratch_band=band(scr[:, :pre.shape[1]]), mte=mte)
+    return mte

@@ -56,3 +56,16 @@ def metric_inputs():
     test = fake_results(rs, METRIC_AGENTS, METRIC_PROBLEMS)
     rand = fake_results(rs, ['Random_search'], METRIC_PROBLEMS + ['Ellipsoidal'])
     return test, rand
+
+
+def fake_rollout(seed, agent='RLEPSO_Agent', n_problems=18, n_cp=21, runs=5, trend=1.0):
+    """Synthetic rollout.pkl-shaped dict (schema of src/tester.py:282-310): returns improve with the checkpoint index."""
+    rs = np.random.RandomState(seed)
+    out = {'cost': {}, 'fes': {}, 'return': {}}
+    for p in range(n_problems):
+        name = f'problem_{p}'
+        base = rs.uniform(-50, 50)
+        out['return'][name] = {agent: [[float(base + trend * 4 * c + rs.normal(0, 3)) for _ in range(runs)] for c in range(n_cp)]}
+        out['cost'][name] = {agent: [[[1.0] * 51 for _ in range(runs)] for _ in range(n_cp)]}
+        out['fes'][name] = {agent: [[20000.0] * runs for _ in range(n_cp)]}
+    return out

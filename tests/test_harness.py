@@ -8,7 +8,7 @@ import pickle
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, close, load, metric_inputs, problems
+from helpers import GOLDEN, close, fake_rollout, load, metric_inputs, problems
 from oracle import oracle
 
 RS = load('random_search.npz')
@@ -286,5 +286,43 @@ def test_cli_entry_point_test_mode(tmp_path):
     assert all(v == 1000 for v in res['fes'][next(iter(res['fes']))]['DE_DDQN_Agent'])
     with pytest.raises(AssertionError):
         main(['--test', '--train'])
-    with pytest.raises(NotImplementedError):
-        main(['--mgd_test', '--problem_to', 'bbob'])
+    with pytest.raises(AssertionError):
+        main(['--mgd_test', '--mte_test', '--problem_from', 'bbob', '--problem_to', 'bbob'])
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_mte_matches_reference(tag, tmp_path, capsys):
+    """mte_test on two seeded synthetic rollout.pkl files vs the value the reference printed (tools/gen_golden.py mte)."""
+    from metabox_amd.main import main
+    with open(os.path.join(GOLDEN, 'mte.json')) as f:
+        gold = json.load(f)[tag]
+    s_pre, t_pre, s_scr, t_scr = gold['seeds']
+    pre, scr = str(tmp_path / 'pre.pkl'), str(tmp_path / 'scr.pkl')
+    with open(pre, 'wb') as f:
+        pickle.dump(fake_rollout(s_pre, trend=t_pre), f)
+    with open(scr, 'wb') as f:
+        pickle.dump(fake_rollout(s_scr, trend=t_scr), f)
+    mte = main(['--mte_test', '--problem_from', 'bbob', '--problem_to', 'bbob-noisy', '--agent', 'RLEPSO_Agent', '--device', 'cpu',
+                '--pre_train_rollout', pre, '--scratch_rollout', scr, '--log_dir', str(tmp_path / 'out')])
+    assert abs(mte - gold['mte']) <= 1e-12
+    assert capsys.readouterr().out.strip().splitlines()[-1].split(': ')[0] == gold['line'].split(': ')[0]
+
+
+@pytest.mark.gpu
+def test_mgd_between_two_saved_agents(tmp_path):
+    """--mgd_test: the same weights saved twice give AEI_from == AEI_to and MGD == 0 (runs are keyed by (problem, run))."""
+    from metabox_amd.agent import RLEPSO_Agent
+    from metabox_amd.agent.utils import save_class
+    from metabox_amd.config import get_config
+    from metabox_amd.main import main
+    cfg = get_config(['--problem', 'bbob', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    weights = np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'metabox_amd', 'agent_model', 'rlepso_bbob_easy.npz'))
+    agent = RLEPSO_Agent(cfg).load_exported_weights(weights)
+    save_class(str(tmp_path) + '/', 'from', agent)
+    save_class(str(tmp_path) + '/', 'to', agent)
+    out = main(['--mgd_test', '--problem_from', 'bbob', '--problem_to', 'bbob-noisy', '--agent', 'RLEPSO_Agent',
+                '--optimizer', 'RLEPSO_Optimizer', '--model_from', str(tmp_path / 'from.pkl'), '--model_to', str(tmp_path / 'to.pkl'),
+                '--device', 'cuda', '--test_runs', '3', '--log_dir', str(tmp_path / 'out')])
+    assert set(out['aei']) == {'RLEPSO_Agent_from', 'RLEPSO_Agent_to'}
+    assert out['aei']['RLEPSO_Agent_from'] > 0 and out['mgd'] == 0.0

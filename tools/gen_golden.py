@@ -562,7 +562,40 @@ def gen_lde_stats():
     np.savez_compressed(os.path.join(OUT, 'lde_stats.npz'), **data)
 
 
-SECTIONS = {'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+def gen_mte():
+    """MTE of the reference (src/tester.py:500-608) on two seeded synthetic rollout.pkl files; the value is parsed from the
+    line the reference prints (the function only prints and plots)."""
+    import contextlib
+    import io
+    import json
+    import pickle
+    os.environ['MPLBACKEND'] = 'Agg'
+    import matplotlib
+    matplotlib.use('Agg')
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tests'))
+    from helpers import fake_rollout
+    import tester as ref_tester
+    scratch = tempfile.mkdtemp()
+    out = {}
+    for tag, (s_pre, t_pre, s_scr, t_scr) in {'a': (1, 1.0, 2, 0.6), 'b': (3, 0.3, 4, 1.0), 'c': (5, 1.5, 6, 0.2)}.items():
+        pre, scr = os.path.join(scratch, f'pre_{tag}.pkl'), os.path.join(scratch, f'scr_{tag}.pkl')
+        with open(pre, 'wb') as f:
+            pickle.dump(fake_rollout(s_pre, trend=t_pre), f)
+        with open(scr, 'wb') as f:
+            pickle.dump(fake_rollout(s_scr, trend=t_scr), f)
+        config = ref_import.ref_config(['--mte_test', '--problem_from', 'bbob', '--problem_to', 'bbob-noisy', '--agent', 'RLEPSO_Agent',
+                                        '--pre_train_rollout', pre, '--scratch_rollout', scr], scratch)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ref_tester.mte_test(config)
+        line = [l for l in buf.getvalue().splitlines() if l.startswith('MTE(')][-1]
+        out[tag] = {'seeds': [s_pre, t_pre, s_scr, t_scr], 'mte': float(line.rsplit(':', 1)[1]), 'line': line}
+        print(tag, line)
+    with open(os.path.join(OUT, 'mte.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+
+
+SECTIONS = {'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
