@@ -106,7 +106,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph-policy', action='store_true', help='replay the policy as one hipGraph instead of launching it op by op')
+    ap.add_argument('--torch-policy', action='store_true', help='evaluate the actor with PyTorch ops (two batched MLPs, torch generator) '
+                                                               'instead of the one-launch mbx_rlepso_policy kernel')
+    ap.add_argument('--graph-policy', action='store_true', help='with --torch-policy / --table-policy: replay the policy as one hipGraph')
     ap.add_argument('--table-policy', action='store_true', help='gather (mu, sigma) from the per-fes table (the actor evaluated once '
                     'at every reachable state) instead of evaluating the two actor MLPs every generation; NOT the headline setting')
     ap.add_argument('--dist-backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
@@ -148,7 +150,14 @@ def main():
     actor = agent.actor
     table = agent.actor_table(MAXFES, NP_, dev)
 
+    h1, h2 = actor.hidden_sizes()
+    hip_policy = not (args.torch_policy or args.table_policy)
+    if hip_policy and args.graph_policy:
+        raise SystemExit('--graph-policy applies to --torch-policy / --table-policy')
+
     def policy(st):
+        if hip_policy:            # reads the batch's own state tensor (st is that tensor)
+            return env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
         return table.act(st) if args.table_policy else actor.act_batch(st.to(torch.float32))
 
     def steps_sum():
@@ -234,9 +243,12 @@ def main():
                                    f'(24 bbob functions round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
                        'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}',
-                       'policy_launch': 'hipGraph replay' if args.graph_policy else 'eager (asynchronous, overlapped with the generation kernel)',
-                       'policy_eval': '(mu, sigma) gathered from a table of the actor evaluated once at every reachable state fes/maxFEs'
-                       if args.table_policy else 'both actor MLPs evaluated every generation over the whole batch (3 batched GEMMs)'},
+                       'policy_launch': 'one k_gauss_mlp_policy launch per generation' if hip_policy else
+                                        ('hipGraph replay' if args.graph_policy else 'eager PyTorch ops'),
+                       'policy_eval': 'both actor MLPs evaluated every generation over the whole batch (mbx_rlepso_policy: weights in LDS, '
+                                      'Philox Normal draws)' if hip_policy else
+                                      ('(mu, sigma) gathered from a table of the actor evaluated once at every reachable state fes/maxFEs'
+                                       if args.table_policy else 'both actor MLPs evaluated every generation over the whole batch (3 batched GEMMs)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_rlepso_step',
                          'algorithmic_bytes_per_launch': bytes_per_launch,

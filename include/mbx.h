@@ -159,6 +159,25 @@ int mbx_results(mbx_batch* b, double* d_cost_curves /* [B, n_logpoint+1] */, dou
 int64_t mbx_instance_state_doubles(const mbx_batch* b);
 int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out);
 
+/* The RLEPSO actor as ONE kernel launch per generation (src/agent/rlepso_agent.py:9-47, Actor.forward without
+ * fixed_action): two MLPs in_dim -> h1 -> h2 -> out_dim (ReLU, ReLU, none) sharing their input,
+ *   mu = (tanh(mu_net(x)) + 1)/2,  sigma = (tanh(sigma_net(x)) + 1)/2 * (max_sigma - min_sigma) + min_sigma,
+ *   action = clamp(Normal(mu, sigma).sample(), 0, 1).
+ * float32 arithmetic like the reference's torch modules.  d_weights holds, for the mu net and then for the sigma net:
+ *   W1^T [in_dim][h1] | b1 [h1] | W2^T [h1][h2] | b2 [h2] | W3^T [h2][out_dim] | b3 [out_dim]
+ * (W^T = torch's nn.Linear.weight transposed, row-major).  The Normal draws replace torch's global generator by the
+ * instance's Philox stream: counter (j, MBX_SITE_POLICY, next generation, episode). */
+typedef struct mbx_gauss_mlp {
+    const float* d_weights;
+    int32_t in_dim, h1, h2, out_dim;
+    float min_sigma, max_sigma;
+} mbx_gauss_mlp;
+
+/* d_state [n_instances, in_dim] float64 (what mbx_reset / mbx_step wrote) -> d_actions [n_instances, out_dim] float32,
+ * ready for mbx_step.  d_mu_sigma, if not NULL, receives [n_instances, 2, out_dim] float32 (mu row, sigma row). */
+int mbx_rlepso_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
+                      void* stream);
+
 const char* mbx_last_error(void);
 const char* mbx_version(void);
 

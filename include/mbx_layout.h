@@ -166,6 +166,8 @@
 #define MBX_DQ_X_PREVIEW  8
 #define MBX_SITE_DQ_R      13u
 #define MBX_SITE_DQ_JRAND  14u
+/* mbx_rlepso_policy: index j = action component, u53(w0,w1), u53(w2,w3) -> Box-Muller, first normal used */
+#define MBX_SITE_POLICY    15u
 
 /* ---------------------------------------------------------------- 6. Random_search (random_search.py) layouts
  * tape per step / reset: pos_u[NP*D] | noise[3*NP];  state block: scalars[16] cost_curve[nlog+1].

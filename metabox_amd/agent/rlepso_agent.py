@@ -63,6 +63,25 @@ class Actor(nn.Module):
             self._fw_key = key
         return self._fw
 
+    def packed_weights(self):
+        """float32 CUDA tensor in the layout ``mbx_gauss_mlp`` documents (include/mbx.h): per net W1^T | b1 | W2^T | b2 | W3^T | b3.
+        Re-packed whenever a parameter has been modified in place (optimizer step, load)."""
+        ps = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_pw_key', None) != key:
+            parts = []
+            for n in (self.mu_net.net, self.sigma_net.net):
+                for i in range(3):
+                    lin = n._modules[f'layer{i}-linear']
+                    parts += [lin.weight.detach().t().reshape(-1), lin.bias.detach().reshape(-1)]
+            self._pw = torch.cat(parts).to(torch.float32).contiguous()
+            self._pw_key = key
+        return self._pw
+
+    def hidden_sizes(self):
+        n = self.mu_net.net
+        return n._modules['layer0-linear'].out_features, n._modules['layer1-linear'].out_features
+
     @torch.no_grad()
     def act_batch(self, states):
         """[B, 1] float32 -> [B, 35] float32 actions for B independent environments (both MLPs evaluated every call)."""
@@ -204,9 +223,12 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, use_table=True):
-        """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.  ``use_table=False`` evaluates the two actor
-        MLPs every generation instead of gathering (mu, sigma) from the per-fes table (same numbers, more launches).
+    def rollout_batch(self, env, max_steps=None, policy='hip'):
+        """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.  ``policy`` selects how the actor runs:
+        'hip'   one ``mbx_rlepso_policy`` launch per generation (weights in LDS, Philox Normal draws) -- the default;
+        'torch' the two MLPs as batched PyTorch GEMMs (``Actor.act_batch``, torch's generator);
+        'table' (mu, sigma) gathered from the per-fes table of the actor evaluated once (``ActorTable``).
+        All three sample the same distribution; only the random stream differs.
 
         Every update() bills at least NP evaluations, so after ceil((maxFEs-NP)/NP) generations every instance has
         reached ``fes >= maxFEs``; instances that finish earlier idle inside the kernel.
@@ -214,11 +236,22 @@ class RLEPSO_Agent(Basic_Agent):
         bc = env.batch.cfg                           # the optimizer's own NP / maxFEs (it may differ from the agent's config copy)
         if max_steps is None:
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
-        table = self.actor_table(bc.max_fes, bc.np, env.batch.device)
+        actor = self.__actor
+        if policy == 'hip':
+            h1, h2 = actor.hidden_sizes()
+
+            def act(_state):
+                return env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+        elif policy == 'table':
+            act = self.actor_table(bc.max_fes, bc.np, env.batch.device).act
+        elif policy == 'torch':
+            def act(state):
+                return actor.act_batch(state.to(torch.float32))
+        else:
+            raise ValueError(f"policy must be 'hip', 'torch' or 'table', not {policy!r}")
         state = env.reset()
         for _ in range(max_steps):
-            actions = table.act(state) if use_table else self.__actor.act_batch(state.to(torch.float32))
-            state, _, _ = env.step(actions)
+            state, _, _ = env.step(act(state))
         res = env.results()
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
                 'cost_len': res['cost_len']}

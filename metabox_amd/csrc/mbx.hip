@@ -16,6 +16,7 @@
 #include "mbx_lde.hpp"
 #include "mbx_ddqn.hpp"
 #include "mbx_rs.hpp"
+#include "mbx_policy.hpp"
 
 using namespace mbx;
 
@@ -484,6 +485,25 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     return MBX_OK;
 }
 
+extern "C" int mbx_rlepso_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
+                                 void* stream)
+{
+    if (!b || !net || !net->d_weights || !d_state || !d_actions) return fail(MBX_E_ARG, "mbx_rlepso_policy: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_policy: the batch is not an RLEPSO batch");
+    if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->h1 < 1 || net->h2 < 1)
+        return fail(MBX_E_ARG, "mbx_rlepso_policy: network dimensions do not match the batch (state_dim -> h1 -> h2 -> action_dim)");
+    const size_t lds = gauss_mlp_lds_bytes(net->in_dim, net->h1, net->h2, net->out_dim);
+    if (lds > 64 * 1024) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_policy: the weights do not fit the 64 KB LDS budget of this kernel");
+    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma};
+    // every wave owns an instance; two instances per wave amortise the weight staging without leaving CUs idle at B = 4096
+    int blocks = (b->B + 2 * kPolicyWaves - 1) / (2 * kPolicyWaves);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g, d_state,
+                       d_actions, d_mu_sigma);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
 extern "C" int mbx_results(mbx_batch* b, double* d_cost_curves, double* d_fes, double* d_return, int32_t* d_steps,
                            int32_t* d_cost_len, void* stream)
 {
@@ -516,3 +536,19 @@ extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out
 
 extern "C" const char* mbx_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mbx_version(void) { return "metabox_amd libmbx 0.1 (gfx950)"; }
+
+#ifdef MBX_PHASE_TIMING
+// Instrumented builds only (not declared in include/mbx.h): cumulative per-phase cycles of k_rlepso_step (thread 0 of every
+// block), summed over blocks.
+extern "C" int mbx_debug_phase_cycles(unsigned long long* out, int n, int reset)
+{
+    std::vector<unsigned long long> h(8192 * 16);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(mbx::g_phase_cycles), h.size() * 8) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 16; ++i) { out[i] = 0; for (int b = 0; b < 8192; ++b) out[i] += h[b * 16 + i]; }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0ull);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mbx::g_phase_cycles), h.data(), h.size() * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -1,0 +1,89 @@
+// mbx_policy.hpp — the RLEPSO actor as one kernel launch per generation.
+//
+// Reference: src/agent/rlepso_agent.py:9-47 (Actor).  Two MLPs in -> H1 -> H2 -> A with ReLU share their input;
+// mu = (tanh(.) + 1)/2, sigma = (tanh(.) + 1)/2 * (max_sigma - min_sigma) + min_sigma, action = clamp(N(mu, sigma), 0, 1).
+// At H1 = 64, H2 = 32, A = 35 one instance is 6.5 kMAC: far too small for MFMA tiles and, launched as ~15 library kernels,
+// pure launch latency (50 us per generation next to a 230 us generation kernel).  Here a wave owns an instance, the
+// 27 KB of float32 weights sit in LDS (transposed, so that lanes read consecutive addresses) and the three layers, the
+// squashing and the Normal draw (Philox, keyed like every other draw of the instance) happen in registers / LDS.
+#pragma once
+#include "mbx_rlepso.hpp"
+
+namespace mbx {
+
+struct GaussMlp {
+    const float* w;              // packed weights, see mbx_gauss_mlp in include/mbx.h
+    int32_t in_dim, h1, h2, out_dim;
+    float min_sigma, max_sigma;
+};
+
+__host__ __device__ inline int gauss_mlp_net_floats(int in, int h1, int h2, int A) { return in * h1 + h1 + h1 * h2 + h2 + h2 * A + A; }
+
+constexpr int kPolicyWaves = kThreads / 64;
+
+__host__ __device__ inline size_t gauss_mlp_lds_bytes(int in, int h1, int h2, int A)
+{
+    return sizeof(float) * (size_t)(2 * gauss_mlp_net_floats(in, h1, h2, A) + kPolicyWaves * 2 * (h1 + h2));
+}
+
+__global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, GaussMlp net, const double* __restrict__ state,
+                                                               float* __restrict__ actions, float* __restrict__ mu_sigma)
+{
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int IN = net.in_dim, H1 = net.h1, H2 = net.h2, A = net.out_dim;
+    const int NW = gauss_mlp_net_floats(IN, H1, H2, A);
+    for (int k = tid; k < 2 * NW; k += kThreads) psm[k] = net.w[k];
+    float* h1v = psm + 2 * NW + wave * 2 * (H1 + H2);        // [2][H1] hidden activations of this wave's instance
+    float* h2v = h1v + 2 * H1;                                // [2][H2]
+    const int o_b1 = IN * H1, o_w2 = o_b1 + H1, o_b2 = o_w2 + H1 * H2, o_w3 = o_b2 + H2, o_b3 = o_w3 + H2 * A;
+    __syncthreads();
+    for (int base = blockIdx.x * kPolicyWaves; base < bp.B; base += gridDim.x * kPolicyWaves) {   // block-uniform trip count
+        const int b = base + wave;
+        const bool live = b < bp.B;
+        if (live)
+            for (int j = lane; j < 2 * H1; j += 64) {
+                const int n = j >= H1, o = j - n * H1;
+                const float* W = psm + n * NW;
+                float acc = W[o_b1 + o];
+                for (int k = 0; k < IN; ++k) acc += (float)state[(int64_t)b * IN + k] * W[k * H1 + o];
+                h1v[j] = fmaxf(acc, 0.f);
+            }
+        __syncthreads();
+        if (live)
+            for (int j = lane; j < 2 * H2; j += 64) {
+                const int n = j >= H2, o = j - n * H2;
+                const float* W = psm + n * NW;
+                const float* h = h1v + n * H1;
+                float acc = W[o_b2 + o];
+#pragma unroll 8
+                for (int k = 0; k < H1; ++k) acc += h[k] * W[o_w2 + k * H2 + o];
+                h2v[j] = fmaxf(acc, 0.f);
+            }
+        __syncthreads();
+        if (live) {
+            const double* sc = bp.state + (int64_t)b * bp.state_stride + MBX_RLEPSO_ST_SCALARS(bp.NP, bp.D);
+            const uint64_t seed = bp.seeds[b];
+            // the action drawn here drives generation gen + 1 of the current episode
+            const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)((int)sc[MBX_SC_GEN] + 1), (uint32_t)(int)sc[MBX_SC_EPISODE]};
+            for (int j = lane; j < A; j += 64) {
+                const float* Wm = psm;
+                const float* Ws = psm + NW;
+                float am = Wm[o_b3 + j], as = Ws[o_b3 + j];
+#pragma unroll 8
+                for (int k = 0; k < H2; ++k) { am += h2v[k] * Wm[o_w3 + k * A + j]; as += h2v[H2 + k] * Ws[o_w3 + k * A + j]; }
+                const float mu = (tanhf(am) + 1.f) / 2.f;
+                const float sigma = (tanhf(as) + 1.f) / 2.f * (net.max_sigma - net.min_sigma) + net.min_sigma;
+                const U4 w = rng.draw((uint32_t)j, MBX_SITE_POLICY);
+                double n0, n1;
+                box_muller(u53(w.x, w.y), u53(w.z, w.w), n0, n1);
+                const float a = mu + sigma * (float)n0;
+                actions[(int64_t)b * A + j] = fminf(fmaxf(a, 0.f), 1.f);
+                if (mu_sigma) { mu_sigma[((int64_t)b * 2) * A + j] = mu; mu_sigma[((int64_t)b * 2 + 1) * A + j] = sigma; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mbx

@@ -132,6 +132,20 @@ struct MoveCtx {
     const int* ORDER; const int* NLESS; const int* RANK; int NP, D, G; double lb, ub, vmax; const FastDiv& fg;
 };
 
+// Per-phase wall-cycle accounting of k_rlepso_step (instrumented builds only: -DMBX_PHASE_TIMING; tools/kbench.py --phases).
+#ifdef MBX_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[8192 * 16];         // [block][phase], no atomics: plain accumulation by the owning block
+#define MBX_PHASE_BEGIN unsigned long long ph_t = clock64();
+#define MBX_PHASE(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_phase_cycles[(blockIdx.x & 8191) * 16 + (k)] += t_ - ph_t; ph_t = t_; } } while (0)
+#else
+#define MBX_PHASE_BEGIN
+#define MBX_PHASE(k)
+#endif
+
+#ifndef MBX_FDR_UNROLL
+#define MBX_FDR_UNROLL 4
+#endif
+
 // Move W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk (rlepso_optimizer.py:179-195).
 template <int W>
 __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
@@ -180,7 +194,7 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
 #pragma unroll
         for (int q = 0; q < W; ++q) { kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
         const double* col = L.PB + d0;
-#pragma unroll 4
+#pragma unroll MBX_FDR_UNROLL
         for (int k = 1; k < nless; ++k) {
             const double a = L.NC[k] - fi;                        // shared by the W coordinates
 #pragma unroll
@@ -281,6 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         }
         return;
     }
+    MBX_PHASE_BEGIN
     const DevProblem P = bp.problems[bp.problem_idx[b]];
     const RlLds L = rl_carve(smem, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
@@ -325,6 +340,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         c[4] = (double)(scale * a[5]); c[5] = (double)(scale * a[6]);
     }
     __syncthreads();
+    MBX_PHASE(0);                                                 // HBM -> LDS staging
     const int per_group = NP / G;
     const FastDiv fd(D), fg(per_group);
     // ---- rank the particles by (pbest cost, index); all 256 threads take part: thread (i, part) counts over a slice of j
@@ -363,28 +379,43 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         ORDER[rank] = i; L.NC[rank] = L.PBC[i];                    // NC: pbest costs in ascending order (free until eval)
     }
     __syncthreads();
+    MBX_PHASE(1);                                                 // ranking + per-particle draws
     // pbest positions are staged in RANK order (row r = particle ORDER[r]): the FDR scan below then walks LDS linearly
     for (int e = tid; e < NE; e += kThreads) { const int i = fd.div(e), d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
     __syncthreads();
+    MBX_PHASE(2);                                                 // pbest rows -> LDS in rank order
 
     // ---- velocity / position update (:179-195).  A work item is W adjacent dimensions of one particle (W = 2 when D is
     // even: the pbest-cost difference of the FDR scan is then shared by both dimensions and their coordinates come from
     // one 16-byte LDS read).  Items are visited in pbest-rank order so that the lanes of a wave own particles of similar
     // rank, i.e. similar FDR trip counts.
     const MoveCtx mc{L, bp, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
+    // The FDR trip count grows with the rank, and wave w of every resident workgroup shares one SIMD: odd passes run
+    // backwards (boustrophedon) so that each wave pairs a cheap slice of ranks with an expensive one.
     if ((D & 1) == 0) {
-        const int HD = D >> 1;
+        const int HD = D >> 1, NI = NP * HD;
         const FastDiv fh(HD);
-        for (int ps = tid; ps < NP * HD; ps += kThreads) { const int rk = fh.div(ps); rl_move<2>(mc, rk, 2 * (ps - rk * HD)); }
+        for (int base = 0, pass = 0; base < NI; base += kThreads, ++pass) {
+            const int lim = base + kThreads < NI ? base + kThreads : NI;
+            const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
+            if (ps >= base && ps < lim) { const int rk = fh.div(ps); rl_move<2>(mc, rk, 2 * (ps - rk * HD)); }
+        }
     } else {
-        for (int es = tid; es < NE; es += kThreads) { const int rk = fd.div(es); rl_move<1>(mc, rk, es - rk * D); }
+        for (int base = 0, pass = 0; base < NE; base += kThreads, ++pass) {
+            const int lim = base + kThreads < NE ? base + kThreads : NE;
+            const int es = (pass & 1) ? lim - 1 - tid : base + tid;
+            if (es >= base && es < lim) { const int rk = fd.div(es); rl_move<1>(mc, rk, es - rk * D); }
+        }
     }
     __syncthreads();
+    MBX_PHASE(3);                                                 // move (draws, exemplars, FDR scan, velocity)
 
     // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
     rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    MBX_PHASE(4);                                                 // evaluation
     fes += NP;
     rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
+    MBX_PHASE(5);                                                 // commit
 
     // ---- re-initialisation (:238-239, 134-168): P(i) = u < c_mutation_i * 0.01 * per_no_improve_i
     int mine = 0;
@@ -397,6 +428,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         mine += m;
     }
     const int n_reinit = __syncthreads_count(mine);               // NP <= 256: at most one particle per thread
+    MBX_PHASE(6);                                                 // re-init draw
     if (n_reinit > 0) {
         for (int e = tid; e < NE; e += kThreads) {
             const int i = fd.div(e);
@@ -417,6 +449,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
     }
 
+    MBX_PHASE(7);                                                 // re-init (move, evaluation, commit)
     // ---- write back what changed
     for (int i = tid; i < NP; i += kThreads) {
         S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = L.PBC[i];
@@ -443,6 +476,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         if (reward_out) reward_out[b] = reward;
         if (done_out) done_out[b] = done ? 1 : 0;
     }
+    MBX_PHASE(8);                                                 // write-back, logging
 }
 
 }  // namespace mbx

@@ -146,6 +146,18 @@ class Batch:
         _abi.check(self.lib.mbx_step(self._h, _ptr(actions), _ptr(self.state), _ptr(self.reward), _ptr(self.done), _stream()))
         return self.state, self.reward, self.done
 
+    def gauss_policy(self, weights, h1, h2, min_sigma, max_sigma, want_mu_sigma=False):
+        """RLEPSO actor over the batch's current state in one launch (``mbx_rlepso_policy``).  weights: packed float32 CUDA
+        tensor (``Actor.packed_weights``).  Returns the [B, action_dim] float32 action tensor (overwritten by the next
+        call), plus [B, 2, action_dim] (mu, sigma) if asked."""
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        if getattr(self, '_actions', None) is None:
+            self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
+        ms = torch.empty(self.B, 2, self.action_dim, dtype=torch.float32, device=self.device) if want_mu_sigma else None
+        net = _abi.GaussMlp(weights.data_ptr(), self.state_dim, int(h1), int(h2), self.action_dim, float(min_sigma), float(max_sigma))
+        _abi.check(self.lib.mbx_rlepso_policy(self._h, C.byref(net), _ptr(self.state), _ptr(self._actions), _ptr(ms), _stream()))
+        return (self._actions, ms) if want_mu_sigma else self._actions
+
     def results(self):
         """-> dict of device tensors: cost [B, n_logpoint+1], fes [B], return [B], steps [B], cost_len [B]."""
         n = self.cfg.n_logpoint + 1

@@ -208,6 +208,58 @@ def test_actor_table_equals_mlp_forward():
         assert torch.allclose(big.mean(0)[tight], want_mu[0][tight].clamp(0, 1), atol=5e-3)
 
 
+def test_policy_kernel_equals_actor_forward():
+    """mbx_rlepso_policy (one launch: both MLPs, squashing, Philox Normal draw, clamp) vs the PyTorch fp32 modules and the
+    reference's recorded (state -> mu, sigma) pairs; the draws are N(0, 1), reproducible and keyed by (seed, generation)."""
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import RLEPSO_Optimizer
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    pol = load('rlepso_policy.npz')
+    agent = RLEPSO_Agent(cfg).load_exported_weights(pol).to('cuda')
+    actor = agent.actor
+    h1, h2 = actor.hidden_sizes()
+    assert (h1, h2) == (64, 32) and actor.packed_weights().numel() == 2 * (64 + 64 + 64 * 32 + 32 + 32 * 35 + 35)
+    ps = [problems('bbob', 10)[f] for f in (1, 8)]
+    B = 3001                                                     # not a multiple of the 4 waves of a block
+    env = BatchedPBO_Env(ps, RLEPSO_Optimizer(cfg), np.arange(B) % 2, np.arange(B, dtype=np.uint64) + 99)
+    state = env.reset()
+    io_state = torch.from_numpy(pol['io/state']).cuda().to(torch.float64)
+    n_io = io_state.shape[0]
+    state[:n_io] = io_state                                      # recorded states of the reference in the first rows
+    state[n_io:, 0] = torch.rand(B - n_io, dtype=torch.float64, device='cuda')
+    act, ms = env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma, want_mu_sigma=True)
+    act, ms = act.clone(), ms.clone()
+    with torch.no_grad():
+        mu, sg = actor.distribution(state.to(torch.float32))
+    assert torch.allclose(ms[:, 0], mu, atol=2e-6) and torch.allclose(ms[:, 1], sg, atol=2e-6)
+    assert np.allclose(ms[:n_io, 0].cpu().numpy(), pol['io/mu'], atol=2e-6)
+    assert np.allclose(ms[:n_io, 1].cpu().numpy(), pol['io/sigma'], atol=2e-6)
+    assert float(act.min()) >= 0 and float(act.max()) <= 1
+    inner = (act > 0) & (act < 1) & (ms[:, 1] > 0.05)
+    z = ((act - ms[:, 0]) / ms[:, 1])[inner].double()            # un-clamped draws: a truncated standard normal sample
+    free = (ms[:, 0] > 0.3) & (ms[:, 0] < 0.7) & (ms[:, 1] < 0.1) & inner      # >= 3 sigma from both clamps: untruncated
+    zf = ((act - ms[:, 0]) / ms[:, 1])[free].double()
+    assert zf.numel() > 2000 and abs(float(zf.mean())) < 5 / zf.numel() ** 0.5 and abs(float(zf.var()) - 1) < 0.1
+    assert z.numel() > 10000 and float(z.abs().max()) < 7
+    again = env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma).clone()
+    assert torch.equal(again, act)                               # same (seed, generation) -> same draws
+    env.step(act)
+    env.batch.state.copy_(state)
+    nxt = env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+    assert not torch.equal(nxt, act) and float((nxt - act).abs().max()) > 0.1      # next generation: new draws, same (mu, sigma)
+    # weights are re-packed after an in-place update
+    with torch.no_grad():
+        next(actor.parameters()).mul_(1.5)
+    _, ms2 = env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma, want_mu_sigma=True)
+    with torch.no_grad():
+        mu2, _ = actor.distribution(state.to(torch.float32))
+    assert torch.allclose(ms2[:, 0], mu2, atol=2e-6) and not torch.allclose(mu2, mu, atol=1e-4)
+    env.close()
+
+
 def test_config5_shape_np128_dim40_mixed_suites():
     """BASELINE.json config 5 geometry: RLEPSO on bbob (24) + bbob-noisy (30) at D = 40 with NP = 128 (5 groups of 25:
     particles 125..127 keep zero coefficients under the reference's NP // n_group rule, rlepso_optimizer.py:117-126)."""
@@ -285,9 +337,9 @@ def test_end_to_end_statistics_match_the_reference():
     runs = 256
     pidx = np.repeat(np.arange(len(fids)), runs)
     torch.manual_seed(123)
-    for use_table in (True, False):
-        env = BatchedPBO_Env(ps, opt, pidx, np.arange(len(pidx), dtype=np.uint64) * 2654435761 + (11 if use_table else 12))
-        out = agent.rollout_batch(env, use_table=use_table)
+    for salt, policy in enumerate(('hip', 'table', 'torch')):
+        env = BatchedPBO_Env(ps, opt, pidx, np.arange(len(pidx), dtype=np.uint64) * 2654435761 + 11 + salt)
+        out = agent.rollout_batch(env, policy=policy)
         cost = out['cost'][:, -1].cpu().numpy().reshape(len(fids), runs)
         fes = out['fes'].cpu().numpy().reshape(len(fids), runs)
         env.close()

@@ -10,7 +10,7 @@ from metabox_amd._abi import ALGO_RLEPSO
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--fids', default='all'); ap.add_argument('--B', type=int, default=4096); ap.add_argument('--steps', type=int, default=40)
-ap.add_argument('--suite', default='bbob'); ap.add_argument('--dim', type=int, default=10); ap.add_argument('--each', action='store_true')
+ap.add_argument('--suite', default='bbob'); ap.add_argument('--dim', type=int, default=10); ap.add_argument('--each', action='store_true'); ap.add_argument('--phases', action='store_true')
 a = ap.parse_args()
 tr, te = BBOB_Dataset.get_datasets(a.suite, a.dim, 5.0)
 ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
@@ -26,9 +26,15 @@ for grp in groups:
     for _ in range(3): b.step(act)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.phases:
+        import ctypes as C
+        ph = (C.c_ulonglong * 16)(); b.lib.mbx_debug_phase_cycles(ph, 16, 1)
     e0.record()
     for _ in range(a.steps): b.step(act)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.steps * 1e3
     print(json.dumps({'lib': os.path.basename(os.environ.get('MBX_LIB', 'libmbx.so')), 'fids': grp if len(grp) < 5 else 'all', 'B': a.B, 'us_per_step': round(us, 1), 'env_steps_per_s': round(a.B / us * 1e6)}))
+    if a.phases:
+        b.lib.mbx_debug_phase_cycles(ph, 16, 1); v = np.array(list(ph), dtype=np.float64)
+        print(json.dumps({'phase_kcycles_per_block': [round(x / a.steps / a.B / 1e3, 2) for x in v[:12]], 'share': [round(x / v.sum(), 3) for x in v[:12]]}))
     b.close()
