@@ -106,11 +106,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--torch-policy', action='store_true', help='evaluate the actor with PyTorch ops (two batched MLPs, torch generator) '
-                                                               'instead of the one-launch mbx_rlepso_policy kernel')
-    ap.add_argument('--graph-policy', action='store_true', help='with --torch-policy / --table-policy: replay the policy as one hipGraph')
-    ap.add_argument('--table-policy', action='store_true', help='gather (mu, sigma) from the per-fes table (the actor evaluated once '
-                    'at every reachable state) instead of evaluating the two actor MLPs every generation; NOT the headline setting')
+    ap.add_argument('--policy', choices=['fused', 'hip', 'torch', 'table'], default='fused',
+                    help='fused: the generation kernel draws its own action from the actor table (mbx_rlepso_act_step, default); '
+                         'hip: mbx_rlepso_policy + mbx_step; torch: the two MLPs as batched PyTorch ops; table: (mu, sigma) gathered '
+                         'from the per-fes table with PyTorch ops')
+    ap.add_argument('--graph-policy', action='store_true', help='with --policy torch / table: replay the policy as one hipGraph')
+    ap.add_argument('--event-stride', type=int, default=8, help='bracket every n-th generation kernel with HIP events (1 = all)')
     ap.add_argument('--dist-backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses cuda:0')
     args = ap.parse_args()
@@ -151,14 +152,15 @@ def main():
     table = agent.actor_table(MAXFES, NP_, dev)
 
     h1, h2 = actor.hidden_sizes()
-    hip_policy = not (args.torch_policy or args.table_policy)
-    if hip_policy and args.graph_policy:
-        raise SystemExit('--graph-policy applies to --torch-policy / --table-policy')
+    if args.policy in ('fused', 'hip') and args.graph_policy:
+        raise SystemExit('--graph-policy applies to --policy torch / table')
+    # fused: the actor evaluated at every reachable state, once (rebuilt whenever the weights change; they do not during a rollout)
+    fused_table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma) if args.policy == 'fused' else None
 
     def policy(st):
-        if hip_policy:            # reads the batch's own state tensor (st is that tensor)
+        if args.policy == 'hip':            # reads the batch's own state tensor (st is that tensor)
             return env.batch.gauss_policy(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
-        return table.act(st) if args.table_policy else actor.act_batch(st.to(torch.float32))
+        return table.act(st) if args.policy == 'table' else actor.act_batch(st.to(torch.float32))
 
     def steps_sum():
         return int(env.results()['steps'].sum().item())
@@ -204,21 +206,28 @@ def main():
                 gen_in_ep = 0
                 if it <= W:
                     base = 0
-            if policy_graph is not None:
+            if fused_table is not None:
+                actions = None
+            elif policy_graph is not None:
                 policy_graph.replay()
                 actions = static_actions
             else:
                 actions = policy(state)
-            if it >= W:
+            timed = it >= W and (it - W) % args.event_stride == 0
+            if timed:
                 ev0[it - W].record()
-            state, _, _ = env.step(actions)
-            if it >= W:
+            if fused_table is not None:
+                state, _, _ = env.batch.act_step(fused_table)
+            else:
+                state, _, _ = env.step(actions)
+            if timed:
                 ev1[it - W].record()
             gen_in_ep += 1
         barrier()
         elapsed = time.perf_counter() - t0
         live += steps_sum() - base
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1))
+    n_timed = len(range(0, K, args.event_stride))
+    kern_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(0, K, args.event_stride)) * K / n_timed
 
     red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
     tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=red_dev)
@@ -243,12 +252,13 @@ def main():
                                    f'(24 bbob functions round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
                        'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}',
-                       'policy_launch': 'one k_gauss_mlp_policy launch per generation' if hip_policy else
-                                        ('hipGraph replay' if args.graph_policy else 'eager PyTorch ops'),
-                       'policy_eval': 'both actor MLPs evaluated every generation over the whole batch (mbx_rlepso_policy: weights in LDS, '
-                                      'Philox Normal draws)' if hip_policy else
-                                      ('(mu, sigma) gathered from a table of the actor evaluated once at every reachable state fes/maxFEs'
-                                       if args.table_policy else 'both actor MLPs evaluated every generation over the whole batch (3 batched GEMMs)')},
+                       'policy': {'fused': 'act + step in one launch (mbx_rlepso_act_step): the generation kernel draws its action from the '
+                                           'actor (mu, sigma) table built by mbx_rlepso_policy_table (actor evaluated at every reachable '
+                                           'state fes/maxFEs)',
+                                  'hip': 'mbx_rlepso_policy (both MLPs over the whole batch, one launch) + mbx_step per generation',
+                                  'torch': 'both actor MLPs as batched PyTorch ops every generation' + (', hipGraph replay' if args.graph_policy else ''),
+                                  'table': '(mu, sigma) gathered from the per-fes table with PyTorch ops' + (', hipGraph replay' if args.graph_policy else '')}[args.policy],
+                       'kernel_timing': f'HIP events around every {args.event_stride}-th generation kernel'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_rlepso_step',
                          'algorithmic_bytes_per_launch': bytes_per_launch,

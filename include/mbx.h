@@ -178,6 +178,20 @@ typedef struct mbx_gauss_mlp {
 int mbx_rlepso_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
                       void* stream);
 
+/* The agent's act() and the environment's step() in ONE launch (the loop body of RLEPSO_Agent.rollout_episode,
+ * src/agent/rlepso_agent.py:294-303: `action = actor(state); state, reward, done = env.step(action)`).
+ * RLEPSO's state is the scalar fes/maxFEs (rlepso_optimizer.py:170-171) and fes is an integer, so the actor's (mu, sigma)
+ * take at most mbx_rlepso_policy_table_rows() distinct values.  mbx_rlepso_policy_table evaluates the actor once at all
+ * of them (row k <- state k/maxFEs; same kernel and float32 arithmetic as mbx_rlepso_policy) into
+ * d_table [rows, 2, out_dim] float32; it has to be rebuilt whenever the weights change.  mbx_rlepso_act_step then draws
+ * each instance's action from row `fes` with exactly the Philox draws of mbx_rlepso_policy and performs mbx_step with
+ * it: mbx_rlepso_policy + mbx_step and mbx_rlepso_act_step give bit-identical trajectories.  d_actions_out, if not
+ * NULL, receives the sampled actions [n_instances, out_dim] (e.g. for log-probabilities). */
+int mbx_rlepso_policy_table_rows(const mbx_batch* b);
+int mbx_rlepso_policy_table(mbx_batch* b, const mbx_gauss_mlp* net, float* d_table, void* stream);
+int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out, double* d_state_out,
+                        double* d_reward_out, uint8_t* d_done_out, void* stream);
+
 const char* mbx_last_error(void);
 const char* mbx_version(void);
 

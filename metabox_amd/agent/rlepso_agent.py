@@ -223,12 +223,14 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, policy='hip'):
+    def rollout_batch(self, env, max_steps=None, policy='fused'):
         """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.  ``policy`` selects how the actor runs:
-        'hip'   one ``mbx_rlepso_policy`` launch per generation (weights in LDS, Philox Normal draws) -- the default;
+        'fused' act + step in ONE launch per generation (``mbx_rlepso_act_step``): the actor is evaluated once per rollout at
+                every reachable state (``mbx_rlepso_policy_table``) and the generation kernel draws its own action -- the default;
+        'hip'   one ``mbx_rlepso_policy`` launch per generation (weights in LDS), then ``mbx_step``; bit-identical to 'fused';
         'torch' the two MLPs as batched PyTorch GEMMs (``Actor.act_batch``, torch's generator);
         'table' (mu, sigma) gathered from the per-fes table of the actor evaluated once (``ActorTable``).
-        All three sample the same distribution; only the random stream differs.
+        All of them sample the same distribution; 'torch' and 'table' use torch's generator instead of the instance's Philox stream.
 
         Every update() bills at least NP evaluations, so after ceil((maxFEs-NP)/NP) generations every instance has
         reached ``fes >= maxFEs``; instances that finish earlier idle inside the kernel.
@@ -237,6 +239,15 @@ class RLEPSO_Agent(Basic_Agent):
         if max_steps is None:
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         actor = self.__actor
+        if policy == 'fused':
+            h1, h2 = actor.hidden_sizes()
+            table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+            env.reset()
+            for _ in range(max_steps):
+                env.batch.act_step(table)
+            res = env.results()
+            return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
+                    'cost_len': res['cost_len']}
         if policy == 'hip':
             h1, h2 = actor.hidden_sizes()
 
@@ -248,7 +259,7 @@ class RLEPSO_Agent(Basic_Agent):
             def act(state):
                 return actor.act_batch(state.to(torch.float32))
         else:
-            raise ValueError(f"policy must be 'hip', 'torch' or 'table', not {policy!r}")
+            raise ValueError(f"policy must be 'fused', 'hip', 'torch' or 'table', not {policy!r}")
         state = env.reset()
         for _ in range(max_steps):
             state, _, _ = env.step(act(state))

@@ -367,6 +367,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     std::unique_ptr<mbx_batch, int (*)(mbx_batch*)> guard(new mbx_batch(), mbx_batch_destroy);   // freed on every error return
     mbx_batch* b = guard.get();
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
+#ifdef MBX_LDS_PAD_EXPERIMENT
+    if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
+#endif
     b->state_stride = (g.state_doubles + 1) & ~(int64_t)1;
     b->sc_off = g.sc_off; b->tape_stride = g.tape_stride; b->state_dim = g.state_dim; b->action_dim = g.action_dim;
     HIP_TRY(hipMalloc(&b->d_problem_idx, n_instances * sizeof(int32_t)));
@@ -471,7 +474,7 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
                            d_reward_out, d_done_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE)
@@ -485,21 +488,65 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     return MBX_OK;
 }
 
+static int check_gauss_mlp(const mbx_batch* b, const mbx_gauss_mlp* net, const char* who, size_t* lds)
+{
+    if (!b || !net || !net->d_weights) return fail(MBX_E_ARG, "%s: bad arguments", who);
+    if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "%s: the batch is not an RLEPSO batch", who);
+    if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->h1 < 1 || net->h2 < 1)
+        return fail(MBX_E_ARG, "%s: network dimensions do not match the batch (state_dim -> h1 -> h2 -> action_dim)", who);
+    *lds = gauss_mlp_lds_bytes(net->in_dim, net->h1, net->h2, net->out_dim);
+    if (*lds > 64 * 1024) return fail(MBX_E_UNSUPPORTED, "%s: the weights do not fit the 64 KB LDS budget of this kernel", who);
+    return MBX_OK;
+}
+
+static int policy_blocks(int rows)
+{
+    // every wave owns a row; two rows per wave amortise the weight staging without leaving CUs idle at 4096 rows
+    const int blocks = (rows + 2 * kPolicyWaves - 1) / (2 * kPolicyWaves);
+    return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+}
+
 extern "C" int mbx_rlepso_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
                                  void* stream)
 {
-    if (!b || !net || !net->d_weights || !d_state || !d_actions) return fail(MBX_E_ARG, "mbx_rlepso_policy: bad arguments");
-    if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_policy: the batch is not an RLEPSO batch");
-    if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->h1 < 1 || net->h2 < 1)
-        return fail(MBX_E_ARG, "mbx_rlepso_policy: network dimensions do not match the batch (state_dim -> h1 -> h2 -> action_dim)");
-    const size_t lds = gauss_mlp_lds_bytes(net->in_dim, net->h1, net->h2, net->out_dim);
-    if (lds > 64 * 1024) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_policy: the weights do not fit the 64 KB LDS budget of this kernel");
+    size_t lds = 0;
+    if (const int rc = check_gauss_mlp(b, net, "mbx_rlepso_policy", &lds)) return rc;
+    if (!d_state || !d_actions) return fail(MBX_E_ARG, "mbx_rlepso_policy: bad arguments");
     const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma};
-    // every wave owns an instance; two instances per wave amortise the weight staging without leaving CUs idle at B = 4096
-    int blocks = (b->B + 2 * kPolicyWaves - 1) / (2 * kPolicyWaves);
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g, d_state,
-                       d_actions, d_mu_sigma);
+    hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(policy_blocks(b->B)), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
+                       d_state, d_actions, d_mu_sigma, 0);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_rlepso_policy_table_rows(const mbx_batch* b)
+{
+    if (!b || b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_ARG, "mbx_rlepso_policy_table_rows: not an RLEPSO batch");
+    return b->cfg.max_fes + 2 * b->cfg.np + 1;       // fes < maxFEs before the last update, which bills at most 2 NP evaluations
+}
+
+extern "C" int mbx_rlepso_policy_table(mbx_batch* b, const mbx_gauss_mlp* net, float* d_table, void* stream)
+{
+    size_t lds = 0;
+    if (const int rc = check_gauss_mlp(b, net, "mbx_rlepso_policy_table", &lds)) return rc;
+    if (!d_table || net->in_dim != 1) return fail(MBX_E_ARG, "mbx_rlepso_policy_table: bad arguments");
+    const int rows = mbx_rlepso_policy_table_rows(b);
+    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma};
+    hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(policy_blocks(rows)), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
+                       (const double*)nullptr, (float*)nullptr, d_table, rows);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out, double* d_state_out,
+                                   double* d_reward_out, uint8_t* d_done_out, void* stream)
+{
+    if (!b || !d_table) return fail(MBX_E_ARG, "mbx_rlepso_act_step: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_act_step: the batch is not an RLEPSO batch");
+    if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_act_step: a replay tape carries no policy draws; use mbx_step with recorded actions");
+    hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                       (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b),
+                       d_actions_out);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

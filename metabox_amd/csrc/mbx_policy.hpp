@@ -26,8 +26,12 @@ __host__ __device__ inline size_t gauss_mlp_lds_bytes(int in, int h1, int h2, in
     return sizeof(float) * (size_t)(2 * gauss_mlp_net_floats(in, h1, h2, A) + kPolicyWaves * 2 * (h1 + h2));
 }
 
+// table_rows == 0: one action per instance from `state` [B, in_dim].
+// table_rows  > 0: no sampling; row k of mu_sigma receives the actor's (mu, sigma) at the state k / max_fes, i.e. at every value
+//                  RLEPSO's scalar state fes/maxFEs can take (rlepso_optimizer.py:170-171) -- the table k_rlepso_step samples from
+//                  when the policy is fused into the generation kernel.
 __global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, GaussMlp net, const double* __restrict__ state,
-                                                               float* __restrict__ actions, float* __restrict__ mu_sigma)
+                                                               float* __restrict__ actions, float* __restrict__ mu_sigma, int table_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,15 +42,19 @@ __global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, G
     float* h2v = h1v + 2 * H1;                                // [2][H2]
     const int o_b1 = IN * H1, o_w2 = o_b1 + H1, o_b2 = o_w2 + H1 * H2, o_w3 = o_b2 + H2, o_b3 = o_w3 + H2 * A;
     __syncthreads();
-    for (int base = blockIdx.x * kPolicyWaves; base < bp.B; base += gridDim.x * kPolicyWaves) {   // block-uniform trip count
+    const int rows = table_rows > 0 ? table_rows : bp.B;
+    for (int base = blockIdx.x * kPolicyWaves; base < rows; base += gridDim.x * kPolicyWaves) {   // block-uniform trip count
         const int b = base + wave;
-        const bool live = b < bp.B;
+        const bool live = b < rows;
         if (live)
             for (int j = lane; j < 2 * H1; j += 64) {
                 const int n = j >= H1, o = j - n * H1;
                 const float* W = psm + n * NW;
                 float acc = W[o_b1 + o];
-                for (int k = 0; k < IN; ++k) acc += (float)state[(int64_t)b * IN + k] * W[k * H1 + o];
+                for (int k = 0; k < IN; ++k) {
+                    const double x = table_rows > 0 ? (double)b / (double)bp.max_fes : state[(int64_t)b * IN + k];
+                    acc += (float)x * W[k * H1 + o];
+                }
                 h1v[j] = fmaxf(acc, 0.f);
             }
         __syncthreads();
@@ -62,10 +70,13 @@ __global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, G
             }
         __syncthreads();
         if (live) {
-            const double* sc = bp.state + (int64_t)b * bp.state_stride + MBX_RLEPSO_ST_SCALARS(bp.NP, bp.D);
-            const uint64_t seed = bp.seeds[b];
-            // the action drawn here drives generation gen + 1 of the current episode
-            const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)((int)sc[MBX_SC_GEN] + 1), (uint32_t)(int)sc[MBX_SC_EPISODE]};
+            Rng rng{0u, 0u, 0u, 0u};
+            if (table_rows == 0) {
+                const double* sc = bp.state + (int64_t)b * bp.state_stride + MBX_RLEPSO_ST_SCALARS(bp.NP, bp.D);
+                const uint64_t seed = bp.seeds[b];
+                // the action drawn here drives generation gen + 1 of the current episode
+                rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)((int)sc[MBX_SC_GEN] + 1), (uint32_t)(int)sc[MBX_SC_EPISODE]};
+            }
             for (int j = lane; j < A; j += 64) {
                 const float* Wm = psm;
                 const float* Ws = psm + NW;
@@ -74,11 +85,7 @@ __global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, G
                 for (int k = 0; k < H2; ++k) { am += h2v[k] * Wm[o_w3 + k * A + j]; as += h2v[H2 + k] * Ws[o_w3 + k * A + j]; }
                 const float mu = (tanhf(am) + 1.f) / 2.f;
                 const float sigma = (tanhf(as) + 1.f) / 2.f * (net.max_sigma - net.min_sigma) + net.min_sigma;
-                const U4 w = rng.draw((uint32_t)j, MBX_SITE_POLICY);
-                double n0, n1;
-                box_muller(u53(w.x, w.y), u53(w.z, w.w), n0, n1);
-                const float a = mu + sigma * (float)n0;
-                actions[(int64_t)b * A + j] = fminf(fmaxf(a, 0.f), 1.f);
+                if (table_rows == 0) actions[(int64_t)b * A + j] = sample_action(rng, j, mu, sigma);
                 if (mu_sigma) { mu_sigma[((int64_t)b * 2) * A + j] = mu; mu_sigma[((int64_t)b * 2 + 1) * A + j] = sigma; }
             }
         }

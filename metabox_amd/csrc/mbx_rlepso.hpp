@@ -132,6 +132,19 @@ struct MoveCtx {
     const int* ORDER; const int* NLESS; const int* RANK; int NP, D, G; double lb, ub, vmax; const FastDiv& fg;
 };
 
+// action_j = clamp(Normal(mu, sigma).sample(), 0, 1) (rlepso_agent.py:27-32) with the instance's Philox stream.  The policy is
+// float32 and its noise has no counterpart in the reference (torch's global generator), so Box-Muller runs on the hardware
+// float32 transcendentals: v_log_f32 (log2) and v_cos_f32 (argument in revolutions, i.e. cos(2 pi u) directly).
+__device__ __forceinline__ float sample_action(const Rng& rng, int j, float mu, float sigma)
+{
+    const U4 w = rng.draw((uint32_t)j, MBX_SITE_POLICY);
+    const float u1 = (float)((w.x >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
+    const float u2 = (float)(w.y >> 8) * 5.9604644775390625e-8f;             // [0, 1)
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));     // sqrt(-2 ln u1)
+    const float n = r * __builtin_amdgcn_cosf(u2);
+    return fminf(fmaxf(mu + sigma * n, 0.f), 1.f);
+}
+
 // Per-phase wall-cycle accounting of k_rlepso_step (instrumented builds only: -DMBX_PHASE_TIMING; tools/kbench.py --phases).
 #ifdef MBX_PHASE_TIMING
 __device__ unsigned long long g_phase_cycles[8192 * 16];         // [block][phase], no atomics: plain accumulation by the owning block
@@ -277,9 +290,13 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
 // ------------------------------------------------------------------------------------------------
 // PBO_Env.step(action): RLEPSO_Optimizer.update (rlepso_optimizer.py:173-263)
 // ------------------------------------------------------------------------------------------------
+// Actions come either from `actions` [B, 7G] (PBO_Env.step(action)) or, when `policy_table` is given, are drawn here from
+// the actor's (mu, sigma) at the instance's current state (agent.act + env.step in one launch, mbx_rlepso_act_step): row
+// fes of the table built by k_gauss_mlp_policy, same Philox draws as mbx_rlepso_policy, optionally echoed to actions_out.
 __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
                                                           double* __restrict__ state_out, double* __restrict__ reward_out,
-                                                          uint8_t* __restrict__ done_out)
+                                                          uint8_t* __restrict__ done_out, const float* __restrict__ policy_table,
+                                                          int table_rows, float* __restrict__ actions_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
@@ -314,20 +331,30 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     const double* gPB = S + MBX_RLEPSO_ST_PBPOS(NP, D);
     double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
     double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
+    float* ACT = (float*)L.R1;                                    // sampled action; R1 is not written before the ranking barrier
+    if (policy_table && tid < 7 * G) {
+        const int A = 7 * G;
+        int row = (int)fes;
+        row = row < table_rows ? row : table_rows - 1;
+        const float* ms = policy_table + (int64_t)row * 2 * A;
+        const float a = sample_action(rng, tid, ms[tid], ms[A + tid]);
+        ACT[tid] = a;
+        if (actions_out) actions_out[(int64_t)b * A + tid] = a;
+    }
     // positions and velocities are parked in X / Z (both free until the new positions / the evaluation need them): every HBM
     // read of the generation is issued up front, coalesced, and overlaps the ranking below
     for (int e = tid; e < NE; e += kThreads) { L.X[e] = gPos[e]; L.Z[e] = gVel[e]; }
     for (int i = tid; i < NP; i += kThreads) {
         L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
-        L.IMPR[i] = 0; L.MASK[i] = 0;
+        L.RANK[i] = 0; L.MASK[i] = 0;
+        L.IMPR[i] = i;                                             // ORDER stays a valid index table even if a NaN cost breaks the ranking
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
     stage_problem(P, L.eval());
     // __get_coe (:112-132): float32 arithmetic (numpy >= 2 keeps float32 for scalar*python-float), group g
     // reads actions[g*n_group : g*n_group+7]
-    if (tid < G) {
-        const float* a = act + tid * G;
+    auto get_coe = [&](const float* a) {
         const float cm = a[0] * 0.01f;
         const float wv = a[1] * 0.8f + 0.1f;
         float den = a[3] + a[4];
@@ -338,45 +365,53 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         c[0] = (double)cm; c[1] = (double)wv;
         c[2] = (double)(scale * a[3]); c[3] = (double)(scale * a[4]);
         c[4] = (double)(scale * a[5]); c[5] = (double)(scale * a[6]);
-    }
+    };
+    if (!policy_table && tid < G) get_coe(act + tid * G);
     __syncthreads();
+    // fused policy: the sampled action became visible with the barrier above; the coefficients are published by the ranking
+    // barrier below, before their first use
+    if (policy_table && tid < G) get_coe(ACT + tid * G);
     MBX_PHASE(0);                                                 // HBM -> LDS staging
     const int per_group = NP / G;
     const FastDiv fd(D), fg(per_group);
-    // ---- rank the particles by (pbest cost, index); all 256 threads take part: thread (i, part) counts over a slice of j
-    int* ORDER = L.IMPR;          // both int arrays are free until the first commit
+    // ---- rank the particles by (pbest cost, index); all 256 threads take part: thread (i, part) counts, over a slice of j,
+    // the particles that are strictly better (nless) and those that are not worse (nle).  rank = nless unless another
+    // particle has exactly the same pbest cost (nle - nless > 1: rare), in which case the equal ones are ordered by index.
+    int* ORDER = L.IMPR;          // free until the first commit
     int* NLESS = L.MASK;
-    int* RANK = L.RANK;
+    int* RANK = L.RANK;           // doubles as the nle accumulator
     {
         const int parts = kThreads / NP > 0 ? kThreads / NP : 1;
         for (int w = tid; w < parts * NP; w += kThreads) {
             const int part = w / NP, i = w - part * NP;
             const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
             const double fi = L.PBC[i];
-            int rank = 0, nless = 0;
+            int nle = 0, nless = 0;
 #ifndef MBX_ABLATE_RANK
 #pragma unroll 4
             for (int j = j0; j < j1; ++j) {
                 const double fj = L.PBC[j];
                 nless += fj < fi;
-                rank += (fj < fi) || (fj == fi && j < i);
+                nle += fj <= fi;
             }
 #else
-            if (part == 0) { rank = i; nless = i; }
+            if (part == 0) { nle = i + 1; nless = i; }
 #endif
-            atomicAdd(&ORDER[i], rank); atomicAdd(&NLESS[i], nless);        // ORDER doubles as the rank accumulator
+            atomicAdd(&RANK[i], nle); atomicAdd(&NLESS[i], nless);
         }
     }
-    __syncthreads();
-    for (int i = tid; i < NP; i += kThreads) RANK[i] = ORDER[i];
     __syncthreads();
     for (int i = tid; i < NP; i += kThreads) {                    // per-particle quantities
         const int g = fg.div(i);
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
         if (tape) { L.R1[i] = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; L.R2[i] = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i]; }
         else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w); }
-        const int rank = RANK[i];
-        ORDER[rank] = i; L.NC[rank] = L.PBC[i];                    // NC: pbest costs in ascending order (free until eval)
+        const double fi = L.PBC[i];
+        int rank = NLESS[i];
+        if (RANK[i] - rank > 1)
+            for (int j = 0; j < i; ++j) rank += L.PBC[j] == fi;
+        RANK[i] = rank;                                            // thread i is the only reader / writer of entry i here
+        ORDER[rank] = i; L.NC[rank] = fi;                          // NC: pbest costs in ascending order (free until eval)
     }
     __syncthreads();
     MBX_PHASE(1);                                                 // ranking + per-particle draws

@@ -158,6 +158,27 @@ class Batch:
         _abi.check(self.lib.mbx_rlepso_policy(self._h, C.byref(net), _ptr(self.state), _ptr(self._actions), _ptr(ms), _stream()))
         return (self._actions, ms) if want_mu_sigma else self._actions
 
+    def policy_table(self, weights, h1, h2, min_sigma, max_sigma):
+        """(mu, sigma) of the actor at every reachable state fes/maxFEs -> [rows, 2, action_dim] float32 (``mbx_rlepso_policy_table``)."""
+        rows = int(self.lib.mbx_rlepso_policy_table_rows(self._h))
+        table = torch.empty(rows, 2, self.action_dim, dtype=torch.float32, device=self.device)
+        net = _abi.GaussMlp(weights.data_ptr(), self.state_dim, int(h1), int(h2), self.action_dim, float(min_sigma), float(max_sigma))
+        _abi.check(self.lib.mbx_rlepso_policy_table(self._h, C.byref(net), _ptr(table), _stream()))
+        return table
+
+    def act_step(self, table, want_actions=False):
+        """agent.act + env.step in one launch (``mbx_rlepso_act_step``): the action of every instance is drawn inside the generation
+        kernel from row fes of `table`.  Returns (state, reward, done[, actions])."""
+        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        acts = None
+        if want_actions:
+            if getattr(self, '_actions', None) is None:
+                self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
+            acts = self._actions
+        _abi.check(self.lib.mbx_rlepso_act_step(self._h, _ptr(table), _ptr(acts), _ptr(self.state), _ptr(self.reward), _ptr(self.done),
+                                                _stream()))
+        return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
+
     def results(self):
         """-> dict of device tensors: cost [B, n_logpoint+1], fes [B], return [B], steps [B], cost_len [B]."""
         n = self.cfg.n_logpoint + 1
