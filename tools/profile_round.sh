@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round profile on the GPU box:  bash tools/profile_round.sh r01c
+# Writes gpurun_out/<tag>/: bench.json, kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_hbm_traffic.json (three separate
+# --pmc passes, no trace domains, summarised by tools/pmc_summary.py).  Copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01x}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python "$ROOT/bench.py" --steps 199 --warmup 10 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY"; do
+    name=$(echo $pass | cut -d' ' -f1)
+    rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1
+done
+python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/pmc_hbm_traffic.json"
+rm -rf "$OUT"/trace "$OUT"/pmc_*/ 2>/dev/null
+ls -la "$OUT"
