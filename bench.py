@@ -108,7 +108,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--policy', choices=['fused', 'hip', 'torch', 'table'], default='fused',
                     help='fused: the generation kernel draws its own action from the actor table (mbx_rlepso_act_step, default); '
-                         'hip: mbx_rlepso_policy + mbx_step; torch: the two MLPs as batched PyTorch ops; table: (mu, sigma) gathered '
+                         'hip: mbx_gauss_policy + mbx_step; torch: the two MLPs as batched PyTorch ops; table: (mu, sigma) gathered '
                          'from the per-fes table with PyTorch ops')
     ap.add_argument('--graph-policy', action='store_true', help='with --policy torch / table: replay the policy as one hipGraph')
     ap.add_argument('--event-stride', type=int, default=8, help='bracket every n-th generation kernel with HIP events (1 = all)')
@@ -255,7 +255,7 @@ def main():
                        'policy': {'fused': 'act + step in one launch (mbx_rlepso_act_step): the generation kernel draws its action from the '
                                            'actor (mu, sigma) table built by mbx_rlepso_policy_table (actor evaluated at every reachable '
                                            'state fes/maxFEs)',
-                                  'hip': 'mbx_rlepso_policy (both MLPs over the whole batch, one launch) + mbx_step per generation',
+                                  'hip': 'mbx_gauss_policy (both MLPs over the whole batch, one launch) + mbx_step per generation',
                                   'torch': 'both actor MLPs as batched PyTorch ops every generation' + (', hipGraph replay' if args.graph_policy else ''),
                                   'table': '(mu, sigma) gathered from the per-fes table with PyTorch ops' + (', hipGraph replay' if args.graph_policy else '')}[args.policy],
                        'kernel_timing': f'HIP events around every {args.event_stride}-th generation kernel'},

@@ -96,6 +96,7 @@ int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f,
 #define MBX_ALGO_LDE    2   /* src/optimizer/lde_optimizer.py      one step = one generation       */
 #define MBX_ALGO_DEDDQN 3   /* src/optimizer/de_ddqn_optimizer.py  one step = one trial vector     */
 #define MBX_ALGO_RANDOM_SEARCH 4 /* src/optimizer/random_search.py  one step = NP uniform samples   */
+#define MBX_ALGO_RLPSO  5   /* src/optimizer/rl_pso_optimizer.py   one step = one particle         */
 
 typedef struct mbx_algo_cfg {
     int32_t algo;          /* MBX_ALGO_*                                                          */
@@ -113,7 +114,8 @@ typedef struct mbx_algo_cfg {
  *   RLEPSO        : state [1]      (fes/maxFEs, rlepso_optimizer.py:170-171), action [35] float32
  *   LDE           : state [np+10]  (lde_optimizer.py:145-157),               action [2*np] float32
  *   DEDDQN        : state [99]     (de_ddqn_optimizer.py:76-129),            action [1] int32
- *   RANDOM_SEARCH : state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step) */
+ *   RANDOM_SEARCH : state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step)
+ *   RLPSO         : state [2*dim]  (rl_pso_optimizer.py:62-63),             action [1] float32 */
 int mbx_state_dim(const mbx_algo_cfg* cfg);
 int mbx_action_dim(const mbx_algo_cfg* cfg);
 /* number of doubles of external random numbers one instance consumes per step (see mbx_set_tape) */
@@ -159,38 +161,50 @@ int mbx_results(mbx_batch* b, double* d_cost_curves /* [B, n_logpoint+1] */, dou
 int64_t mbx_instance_state_doubles(const mbx_batch* b);
 int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out);
 
-/* The RLEPSO actor as ONE kernel launch per generation (src/agent/rlepso_agent.py:9-47, Actor.forward without
- * fixed_action): two MLPs in_dim -> h1 -> h2 -> out_dim (ReLU, ReLU, none) sharing their input,
+/* The RLEPSO / RL-PSO actor as ONE kernel launch per step (src/agent/rlepso_agent.py:9-47 Actor.forward without
+ * fixed_action; src/agent/rl_pso_agent.py:9-47 PolicyNetwork.forward): two MLPs in_dim -> h1 -> h2 -> out_dim (ReLU, ReLU, none) sharing their input,
  *   mu = (tanh(mu_net(x)) + 1)/2,  sigma = (tanh(sigma_net(x)) + 1)/2 * (max_sigma - min_sigma) + min_sigma,
  *   action = clamp(Normal(mu, sigma).sample(), 0, 1).
  * float32 arithmetic like the reference's torch modules.  d_weights holds, for the mu net and then for the sigma net:
  *   W1^T [in_dim][h1] | b1 [h1] | W2^T [h1][h2] | b2 [h2] | W3^T [h2][out_dim] | b3 [out_dim]
  * (W^T = torch's nn.Linear.weight transposed, row-major).  The Normal draws replace torch's global generator by the
  * instance's Philox stream: counter (j, MBX_SITE_POLICY, next generation, episode). */
+#define MBX_POLICY_RLEPSO 0   /* sigma affine in tanh, action clamped to [0,1]        (rlepso_agent.py:24-32) */
+#define MBX_POLICY_RLPSO  1   /* sigma clamped to [min,max], out-of-range samples re-folded (rl_pso_agent.py:24-35) */
 typedef struct mbx_gauss_mlp {
     const float* d_weights;
     int32_t in_dim, h1, h2, out_dim;
     float min_sigma, max_sigma;
+    int32_t variant;              /* MBX_POLICY_* */
 } mbx_gauss_mlp;
 
 /* d_state [n_instances, in_dim] float64 (what mbx_reset / mbx_step wrote) -> d_actions [n_instances, out_dim] float32,
  * ready for mbx_step.  d_mu_sigma, if not NULL, receives [n_instances, 2, out_dim] float32 (mu row, sigma row). */
-int mbx_rlepso_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
+int mbx_gauss_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
                       void* stream);
 
 /* The agent's act() and the environment's step() in ONE launch (the loop body of RLEPSO_Agent.rollout_episode,
  * src/agent/rlepso_agent.py:294-303: `action = actor(state); state, reward, done = env.step(action)`).
  * RLEPSO's state is the scalar fes/maxFEs (rlepso_optimizer.py:170-171) and fes is an integer, so the actor's (mu, sigma)
  * take at most mbx_rlepso_policy_table_rows() distinct values.  mbx_rlepso_policy_table evaluates the actor once at all
- * of them (row k <- state k/maxFEs; same kernel and float32 arithmetic as mbx_rlepso_policy) into
+ * of them (row k <- state k/maxFEs; same kernel and float32 arithmetic as mbx_gauss_policy) into
  * d_table [rows, 2, out_dim] float32; it has to be rebuilt whenever the weights change.  mbx_rlepso_act_step then draws
- * each instance's action from row `fes` with exactly the Philox draws of mbx_rlepso_policy and performs mbx_step with
- * it: mbx_rlepso_policy + mbx_step and mbx_rlepso_act_step give bit-identical trajectories.  d_actions_out, if not
+ * each instance's action from row `fes` with exactly the Philox draws of mbx_gauss_policy and performs mbx_step with
+ * it: mbx_gauss_policy + mbx_step and mbx_rlepso_act_step give bit-identical trajectories.  d_actions_out, if not
  * NULL, receives the sampled actions [n_instances, out_dim] (e.g. for log-probabilities). */
 int mbx_rlepso_policy_table_rows(const mbx_batch* b);
 int mbx_rlepso_policy_table(mbx_batch* b, const mbx_gauss_mlp* net, float* d_table, void* stream);
 int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out, double* d_state_out,
                         double* d_reward_out, uint8_t* d_done_out, void* stream);
+
+/* RL-PSO moves ONE particle per env step, so a rollout is maxFEs - NP steps of D-element arithmetic plus one evaluation:
+ * launch latency, not work.  mbx_rlpso_rollout runs `n_steps` consecutive steps of every instance in ONE launch with the
+ * actor evaluated inside the kernel (the loop of RL_PSO_Agent.rollout_episode, src/agent/rl_pso_agent.py:112-124).  It is
+ * bit-identical to n_steps x (mbx_gauss_policy + mbx_step).  d_reward_out receives the SUM of the rewards of the steps
+ * executed by this call, d_state_out / d_done_out the state and flag after the last one; d_actions_out, if not NULL,
+ * the last sampled action [n_instances]. */
+int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_steps, float* d_actions_out, double* d_state_out,
+                      double* d_reward_out, uint8_t* d_done_out, void* stream);
 
 const char* mbx_last_error(void);
 const char* mbx_version(void);

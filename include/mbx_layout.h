@@ -166,7 +166,7 @@
 #define MBX_DQ_X_PREVIEW  8
 #define MBX_SITE_DQ_R      13u
 #define MBX_SITE_DQ_JRAND  14u
-/* mbx_rlepso_policy: index j = action component, u53(w0,w1), u53(w2,w3) -> Box-Muller, first normal used */
+/* mbx_gauss_policy: index j = action component, u53(w0,w1), u53(w2,w3) -> Box-Muller, first normal used */
 #define MBX_SITE_POLICY    15u
 
 /* ---------------------------------------------------------------- 6. Random_search (random_search.py) layouts
@@ -178,6 +178,34 @@
 #define MBX_RS_TAPE_STRIDE(NP, D)  ((int64_t)(NP) * (D) + 3 * (int64_t)(NP))
 #define MBX_RS_ST_SCALARS(NP, D)   ((int64_t)0)
 #define MBX_RS_STATE_DOUBLES(NP, D, NLOG) ((int64_t)MBX_NSCALAR + (int64_t)(NLOG) + 1)
+
+/* ---------------------------------------------------------------- 7. RL-PSO (rl_pso_optimizer.py) layouts
+ * One env step = ONE particle (index `cur`, round robin): velocity / position update with the action as the gbest
+ * attraction weight, one evaluation, pbest / gbest, reward (pre_cost - new_cost) / (max_cost - gbest) (:76-148).
+ * state vector [2 D] = gbest_position | current_position[cur]  (:62-63);  action [1] float32.
+ * state block: pos[NP*D] vel[NP*D] pbest_pos[NP*D] c_cost[NP] pbest[NP] gbest_pos[D] scalars[16] cost_curve[nlog+1];
+ * scalars beyond the common ones: inertia w (decremented EVERY step, :85-86), max_cost of the initial population (:41),
+ * cur.  tape per reset: pos_u[NP*D] | vel_u[NP*D] | noise[3*NP] (draw order of init_population :30-36);
+ * tape per step: rand1 | noise[3] (:89, then the evaluation's own draws).
+ * Philox: reset (gen 0): MBX_SITE_ELEM_R(e): u53(w0,w1) = pos_u, u53(w2,w3) = vel_u; noise MBX_SITE_NOISE1_A/B(i).
+ *         step (gen = number of the step): MBX_SITE_PART(0): u53(w0,w1) = rand1; noise MBX_SITE_NOISE0_A/B(0).       */
+#define MBX_RLPSO_TAPE_POS(NP, D)    ((int64_t)0)
+#define MBX_RLPSO_TAPE_VEL(NP, D)    ((int64_t)(NP) * (D))
+#define MBX_RLPSO_TAPE_NOISE_INIT(NP, D) (2 * (int64_t)(NP) * (D))
+#define MBX_RLPSO_TAPE_RAND1(NP, D)  ((int64_t)0)
+#define MBX_RLPSO_TAPE_NOISE(NP, D)  ((int64_t)1)
+#define MBX_RLPSO_TAPE_STRIDE(NP, D) (2 * (int64_t)(NP) * (D) + 3 * (int64_t)(NP))
+#define MBX_RLPSO_ST_POS(NP, D)      ((int64_t)0)
+#define MBX_RLPSO_ST_VEL(NP, D)      ((int64_t)(NP) * (D))
+#define MBX_RLPSO_ST_PBPOS(NP, D)    (2 * (int64_t)(NP) * (D))
+#define MBX_RLPSO_ST_CCOST(NP, D)    (3 * (int64_t)(NP) * (D))
+#define MBX_RLPSO_ST_PBEST(NP, D)    (3 * (int64_t)(NP) * (D) + (NP))
+#define MBX_RLPSO_ST_GBPOS(NP, D)    (3 * (int64_t)(NP) * (D) + 2 * (int64_t)(NP))
+#define MBX_RLPSO_ST_SCALARS(NP, D)  (3 * (int64_t)(NP) * (D) + 2 * (int64_t)(NP) + (D))
+#define MBX_RLPSO_STATE_DOUBLES(NP, D, NLOG) (MBX_RLPSO_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_SC_RLPSO_W       10
+#define MBX_SC_RLPSO_MAXCOST 11
+#define MBX_SC_RLPSO_CUR     12
 
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u

@@ -227,7 +227,7 @@ class RLEPSO_Agent(Basic_Agent):
         """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.  ``policy`` selects how the actor runs:
         'fused' act + step in ONE launch per generation (``mbx_rlepso_act_step``): the actor is evaluated once per rollout at
                 every reachable state (``mbx_rlepso_policy_table``) and the generation kernel draws its own action -- the default;
-        'hip'   one ``mbx_rlepso_policy`` launch per generation (weights in LDS), then ``mbx_step``; bit-identical to 'fused';
+        'hip'   one ``mbx_gauss_policy`` launch per generation (weights in LDS), then ``mbx_step``; bit-identical to 'fused';
         'torch' the two MLPs as batched PyTorch GEMMs (``Actor.act_batch``, torch's generator);
         'table' (mu, sigma) gathered from the per-fes table of the actor evaluated once (``ActorTable``).
         All of them sample the same distribution; 'torch' and 'table' use torch's generator instead of the instance's Philox stream.

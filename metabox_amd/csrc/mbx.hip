@@ -17,6 +17,7 @@
 #include "mbx_ddqn.hpp"
 #include "mbx_rs.hpp"
 #include "mbx_policy.hpp"
+#include "mbx_rlpso.hpp"
 
 using namespace mbx;
 
@@ -96,6 +97,12 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_RS_TAPE_STRIDE(c.np, c.dim);
         g.lds_doubles = rs_lds_doubles(c.np, c.dim);
         g.state_dim = 1; g.action_dim = 0;
+    } else if (c.algo == MBX_ALGO_RLPSO) {
+        g.state_doubles = MBX_RLPSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_RLPSO_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_RLPSO_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = rp_lds_doubles(c.np, c.dim);
+        g.state_dim = 2 * c.dim; g.action_dim = 1;
     }
     return g;
 }
@@ -324,7 +331,7 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_RANDOM_SEARCH)
+    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_RLPSO)
         return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
     if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
     if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
@@ -413,6 +420,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (cfg->algo == MBX_ALGO_RLPSO) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rs_population, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -443,6 +453,7 @@ static BatchParams make_params(const mbx_batch* b)
     p.tape = b->d_tape; p.tape_stride = b->tape_stride; p.order = b->d_order; p.pci = b->d_pci;
     p.NP = b->cfg.np; p.D = b->cfg.dim; p.max_fes = b->cfg.max_fes; p.log_interval = b->cfg.log_interval;
     p.n_logpoint = b->cfg.n_logpoint; p.early_stop = b->cfg.early_stop; p.n_group = b->cfg.n_group; p.B = b->B;
+    p.sc_off = b->sc_off;
     return p;
 }
 
@@ -454,6 +465,8 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
                            (double*)nullptr, (uint8_t*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    else if (b->cfg.algo == MBX_ALGO_RLPSO)
+        hipLaunchKernelGGL(k_rlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE)
@@ -475,6 +488,9 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_RLPSO)
+        hipLaunchKernelGGL(k_rlpso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, GaussMlp{}, 1, d_state_out, d_reward_out, d_done_out, (float*)nullptr);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE)
@@ -491,7 +507,10 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
 static int check_gauss_mlp(const mbx_batch* b, const mbx_gauss_mlp* net, const char* who, size_t* lds)
 {
     if (!b || !net || !net->d_weights) return fail(MBX_E_ARG, "%s: bad arguments", who);
-    if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "%s: the batch is not an RLEPSO batch", who);
+    if (b->cfg.algo != MBX_ALGO_RLEPSO && b->cfg.algo != MBX_ALGO_RLPSO)
+        return fail(MBX_E_UNSUPPORTED, "%s: the batch is neither an RLEPSO nor an RL-PSO batch", who);
+    if (net->variant != (b->cfg.algo == MBX_ALGO_RLPSO ? MBX_POLICY_RLPSO : MBX_POLICY_RLEPSO))
+        return fail(MBX_E_ARG, "%s: net.variant does not match the batch's algorithm", who);
     if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->h1 < 1 || net->h2 < 1)
         return fail(MBX_E_ARG, "%s: network dimensions do not match the batch (state_dim -> h1 -> h2 -> action_dim)", who);
     *lds = gauss_mlp_lds_bytes(net->in_dim, net->h1, net->h2, net->out_dim);
@@ -506,13 +525,13 @@ static int policy_blocks(int rows)
     return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
 }
 
-extern "C" int mbx_rlepso_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
+extern "C" int mbx_gauss_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
                                  void* stream)
 {
     size_t lds = 0;
-    if (const int rc = check_gauss_mlp(b, net, "mbx_rlepso_policy", &lds)) return rc;
-    if (!d_state || !d_actions) return fail(MBX_E_ARG, "mbx_rlepso_policy: bad arguments");
-    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma};
+    if (const int rc = check_gauss_mlp(b, net, "mbx_gauss_policy", &lds)) return rc;
+    if (!d_state || !d_actions) return fail(MBX_E_ARG, "mbx_gauss_policy: bad arguments");
+    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma, net->variant};
     hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(policy_blocks(b->B)), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
                        d_state, d_actions, d_mu_sigma, 0);
     HIP_TRY(hipGetLastError());
@@ -529,9 +548,9 @@ extern "C" int mbx_rlepso_policy_table(mbx_batch* b, const mbx_gauss_mlp* net, f
 {
     size_t lds = 0;
     if (const int rc = check_gauss_mlp(b, net, "mbx_rlepso_policy_table", &lds)) return rc;
-    if (!d_table || net->in_dim != 1) return fail(MBX_E_ARG, "mbx_rlepso_policy_table: bad arguments");
+    if (!d_table || net->in_dim != 1 || b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_ARG, "mbx_rlepso_policy_table: bad arguments");
     const int rows = mbx_rlepso_policy_table_rows(b);
-    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma};
+    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma, net->variant};
     hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(policy_blocks(rows)), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
                        (const double*)nullptr, (float*)nullptr, d_table, rows);
     HIP_TRY(hipGetLastError());
@@ -547,6 +566,23 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                        (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b),
                        d_actions_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_steps, float* d_actions_out, double* d_state_out,
+                                 double* d_reward_out, uint8_t* d_done_out, void* stream)
+{
+    size_t lds = 0;
+    if (const int rc = check_gauss_mlp(b, net, "mbx_rlpso_rollout", &lds)) return rc;
+    if (b->cfg.algo != MBX_ALGO_RLPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlpso_rollout: the batch is not an RL-PSO batch");
+    if (n_steps < 1) return fail(MBX_E_ARG, "mbx_rlpso_rollout: n_steps must be >= 1");
+    if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlpso_rollout: a replay tape holds one step; use mbx_step with recorded actions");
+    if ((size_t)(net->in_dim + 2 * net->h1 + 2 * net->h2 + 2) * sizeof(float) > (size_t)kRpActDoubles * sizeof(double))
+        return fail(MBX_E_UNSUPPORTED, "mbx_rlpso_rollout: hidden layers too wide for the in-kernel actor");
+    const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma, net->variant};
+    hipLaunchKernelGGL(k_rlpso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), (const float*)nullptr,
+                       g, n_steps, d_state_out, d_reward_out, d_done_out, d_actions_out);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

@@ -1,4 +1,4 @@
-// mbx_policy.hpp — the RLEPSO actor as one kernel launch per generation.
+// mbx_policy.hpp — the RLEPSO / RL-PSO actors as one kernel launch per step.
 //
 // Reference: src/agent/rlepso_agent.py:9-47 (Actor).  Two MLPs in -> H1 -> H2 -> A with ReLU share their input;
 // mu = (tanh(.) + 1)/2, sigma = (tanh(.) + 1)/2 * (max_sigma - min_sigma) + min_sigma, action = clamp(N(mu, sigma), 0, 1).
@@ -10,14 +10,6 @@
 #include "mbx_rlepso.hpp"
 
 namespace mbx {
-
-struct GaussMlp {
-    const float* w;              // packed weights, see mbx_gauss_mlp in include/mbx.h
-    int32_t in_dim, h1, h2, out_dim;
-    float min_sigma, max_sigma;
-};
-
-__host__ __device__ inline int gauss_mlp_net_floats(int in, int h1, int h2, int A) { return in * h1 + h1 + h1 * h2 + h2 + h2 * A + A; }
 
 constexpr int kPolicyWaves = kThreads / 64;
 
@@ -72,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, G
         if (live) {
             Rng rng{0u, 0u, 0u, 0u};
             if (table_rows == 0) {
-                const double* sc = bp.state + (int64_t)b * bp.state_stride + MBX_RLEPSO_ST_SCALARS(bp.NP, bp.D);
+                const double* sc = bp.state + (int64_t)b * bp.state_stride + bp.sc_off;
                 const uint64_t seed = bp.seeds[b];
                 // the action drawn here drives generation gen + 1 of the current episode
                 rng = Rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)((int)sc[MBX_SC_GEN] + 1), (uint32_t)(int)sc[MBX_SC_EPISODE]};
@@ -83,9 +75,9 @@ __global__ __launch_bounds__(kThreads) void k_gauss_mlp_policy(BatchParams bp, G
                 float am = Wm[o_b3 + j], as = Ws[o_b3 + j];
 #pragma unroll 8
                 for (int k = 0; k < H2; ++k) { am += h2v[k] * Wm[o_w3 + k * A + j]; as += h2v[H2 + k] * Ws[o_w3 + k * A + j]; }
-                const float mu = (tanhf(am) + 1.f) / 2.f;
-                const float sigma = (tanhf(as) + 1.f) / 2.f * (net.max_sigma - net.min_sigma) + net.min_sigma;
-                if (table_rows == 0) actions[(int64_t)b * A + j] = sample_action(rng, j, mu, sigma);
+                float mu, sigma;
+                gauss_head(net, am, as, mu, sigma);
+                if (table_rows == 0) actions[(int64_t)b * A + j] = sample_action(rng, j, mu, sigma, net.variant);
                 if (mu_sigma) { mu_sigma[((int64_t)b * 2) * A + j] = mu; mu_sigma[((int64_t)b * 2 + 1) * A + j] = sigma; }
             }
         }

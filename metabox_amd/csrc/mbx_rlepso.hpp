@@ -23,6 +23,7 @@ struct BatchParams {
     const int32_t* order;        // launch order: workgroup w owns instance order[w] (most expensive objectives first)
     const double* pci;           // [NP] RLEPSO learning-probability curve pci_i (rlepso_optimizer.py:23-24), computed at batch creation
     int32_t NP, D, max_fes, log_interval, n_logpoint, early_stop, n_group, B;
+    int64_t sc_off;              // offset of the scalar block inside an instance's state (per algorithm)
 };
 
 // LDS carve-up (all offsets in doubles; base is 16-byte aligned, every array starts 16-byte aligned)
@@ -132,17 +133,39 @@ struct MoveCtx {
     const int* ORDER; const int* NLESS; const int* RANK; int NP, D, G; double lb, ub, vmax; const FastDiv& fg;
 };
 
-// action_j = clamp(Normal(mu, sigma).sample(), 0, 1) (rlepso_agent.py:27-32) with the instance's Philox stream.  The policy is
-// float32 and its noise has no counterpart in the reference (torch's global generator), so Box-Muller runs on the hardware
-// float32 transcendentals: v_log_f32 (log2) and v_cos_f32 (argument in revolutions, i.e. cos(2 pi u) directly).
-__device__ __forceinline__ float sample_action(const Rng& rng, int j, float mu, float sigma)
+// Two-headed Gaussian MLP policy (mbx_gauss_mlp in include/mbx.h): RLEPSO's Actor (src/agent/rlepso_agent.py:9-47) and RL-PSO's
+// PolicyNetwork (src/agent/rl_pso_agent.py:9-47) share the architecture and differ in the heads.
+struct GaussMlp {
+    const float* w;              // packed weights
+    int32_t in_dim, h1, h2, out_dim;
+    float min_sigma, max_sigma;
+    int32_t variant;             // MBX_POLICY_RLEPSO / MBX_POLICY_RLPSO
+};
+
+__host__ __device__ inline int gauss_mlp_net_floats(int in, int h1, int h2, int A) { return in * h1 + h1 + h1 * h2 + h2 + h2 * A + A; }
+
+// (mu, sigma) from the two nets' raw outputs, float32 like the reference's torch modules
+__device__ __forceinline__ void gauss_head(const GaussMlp& net, float am, float as, float& mu, float& sigma)
+{
+    mu = (tanhf(am) + 1.f) / 2.f;
+    if (net.variant == MBX_POLICY_RLPSO) sigma = fminf(fmaxf((tanhf(as) + 1.f) / 2.f, net.min_sigma), net.max_sigma);   // rl_pso_agent.py:27-29
+    else sigma = (tanhf(as) + 1.f) / 2.f * (net.max_sigma - net.min_sigma) + net.min_sigma;                               // rlepso_agent.py:25
+}
+
+// Normal(mu, sigma).sample() with the instance's Philox stream, then the agent's post-processing:
+//   RLEPSO: clamp to [0, 1] (rlepso_agent.py:32);  RL-PSO: samples outside [0, 1) are re-folded as
+//   (a + 3 sigma - mu) * (1/6 * sigma) (rl_pso_agent.py:34-35, precedence as written there).
+// The policy is float32 and its noise has no counterpart in the reference (torch's global generator), so Box-Muller runs on the
+// hardware float32 transcendentals: v_log_f32 (log2) and v_cos_f32 (argument in revolutions, i.e. cos(2 pi u) directly).
+__device__ __forceinline__ float sample_action(const Rng& rng, int j, float mu, float sigma, int variant)
 {
     const U4 w = rng.draw((uint32_t)j, MBX_SITE_POLICY);
     const float u1 = (float)((w.x >> 8) + 1u) * 5.9604644775390625e-8f;      // (0, 1]
     const float u2 = (float)(w.y >> 8) * 5.9604644775390625e-8f;             // [0, 1)
     const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));     // sqrt(-2 ln u1)
-    const float n = r * __builtin_amdgcn_cosf(u2);
-    return fminf(fmaxf(mu + sigma * n, 0.f), 1.f);
+    const float a = mu + sigma * (r * __builtin_amdgcn_cosf(u2));
+    if (variant == MBX_POLICY_RLPSO) return fabsf(a - 0.5f) >= 0.5f ? (a + 3.f * sigma - mu) * ((1.f / 6.f) * sigma) : a;
+    return fminf(fmaxf(a, 0.f), 1.f);
 }
 
 // Per-phase wall-cycle accounting of k_rlepso_step (instrumented builds only: -DMBX_PHASE_TIMING; tools/kbench.py --phases).
@@ -292,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
 // ------------------------------------------------------------------------------------------------
 // Actions come either from `actions` [B, 7G] (PBO_Env.step(action)) or, when `policy_table` is given, are drawn here from
 // the actor's (mu, sigma) at the instance's current state (agent.act + env.step in one launch, mbx_rlepso_act_step): row
-// fes of the table built by k_gauss_mlp_policy, same Philox draws as mbx_rlepso_policy, optionally echoed to actions_out.
+// fes of the table built by k_gauss_mlp_policy, same Philox draws as mbx_gauss_policy, optionally echoed to actions_out.
 __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
                                                           double* __restrict__ state_out, double* __restrict__ reward_out,
                                                           uint8_t* __restrict__ done_out, const float* __restrict__ policy_table,
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         int row = (int)fes;
         row = row < table_rows ? row : table_rows - 1;
         const float* ms = policy_table + (int64_t)row * 2 * A;
-        const float a = sample_action(rng, tid, ms[tid], ms[A + tid]);
+        const float a = sample_action(rng, tid, ms[tid], ms[A + tid], MBX_POLICY_RLEPSO);
         ACT[tid] = a;
         if (actions_out) actions_out[(int64_t)b * A + tid] = a;
     }

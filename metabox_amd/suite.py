@@ -146,23 +146,40 @@ class Batch:
         _abi.check(self.lib.mbx_step(self._h, _ptr(actions), _ptr(self.state), _ptr(self.reward), _ptr(self.done), _stream()))
         return self.state, self.reward, self.done
 
+    def _net(self, weights, h1, h2, min_sigma, max_sigma):
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        variant = _abi.POLICY_RLPSO if self.cfg.algo == _abi.ALGO_RLPSO else _abi.POLICY_RLEPSO
+        return _abi.GaussMlp(weights.data_ptr(), self.state_dim, int(h1), int(h2), self.action_dim, float(min_sigma), float(max_sigma), variant)
+
+    def rlpso_rollout(self, weights, h1, h2, min_sigma, max_sigma, n_steps, want_actions=False):
+        """`n_steps` RL-PSO env steps of every instance in ONE launch, actor evaluated in the kernel (``mbx_rlpso_rollout``).
+        Returns (state, reward summed over the executed steps, done[, last actions])."""
+        acts = None
+        if want_actions:
+            if getattr(self, '_actions', None) is None:
+                self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
+            acts = self._actions
+        net = self._net(weights, h1, h2, min_sigma, max_sigma)
+        _abi.check(self.lib.mbx_rlpso_rollout(self._h, C.byref(net), int(n_steps), _ptr(acts), _ptr(self.state), _ptr(self.reward),
+                                              _ptr(self.done), _stream()))
+        return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
+
     def gauss_policy(self, weights, h1, h2, min_sigma, max_sigma, want_mu_sigma=False):
-        """RLEPSO actor over the batch's current state in one launch (``mbx_rlepso_policy``).  weights: packed float32 CUDA
+        """RLEPSO / RL-PSO actor over the batch's current state in one launch (``mbx_gauss_policy``).  weights: packed float32 CUDA
         tensor (``Actor.packed_weights``).  Returns the [B, action_dim] float32 action tensor (overwritten by the next
         call), plus [B, 2, action_dim] (mu, sigma) if asked."""
-        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
         if getattr(self, '_actions', None) is None:
             self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
         ms = torch.empty(self.B, 2, self.action_dim, dtype=torch.float32, device=self.device) if want_mu_sigma else None
-        net = _abi.GaussMlp(weights.data_ptr(), self.state_dim, int(h1), int(h2), self.action_dim, float(min_sigma), float(max_sigma))
-        _abi.check(self.lib.mbx_rlepso_policy(self._h, C.byref(net), _ptr(self.state), _ptr(self._actions), _ptr(ms), _stream()))
+        net = self._net(weights, h1, h2, min_sigma, max_sigma)
+        _abi.check(self.lib.mbx_gauss_policy(self._h, C.byref(net), _ptr(self.state), _ptr(self._actions), _ptr(ms), _stream()))
         return (self._actions, ms) if want_mu_sigma else self._actions
 
     def policy_table(self, weights, h1, h2, min_sigma, max_sigma):
         """(mu, sigma) of the actor at every reachable state fes/maxFEs -> [rows, 2, action_dim] float32 (``mbx_rlepso_policy_table``)."""
         rows = int(self.lib.mbx_rlepso_policy_table_rows(self._h))
         table = torch.empty(rows, 2, self.action_dim, dtype=torch.float32, device=self.device)
-        net = _abi.GaussMlp(weights.data_ptr(), self.state_dim, int(h1), int(h2), self.action_dim, float(min_sigma), float(max_sigma))
+        net = self._net(weights, h1, h2, min_sigma, max_sigma)
         _abi.check(self.lib.mbx_rlepso_policy_table(self._h, C.byref(net), _ptr(table), _stream()))
         return table
 

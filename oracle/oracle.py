@@ -389,3 +389,100 @@ class DqTapeFeeder:
         t[8:11] = self._noise(1).ravel()
         t[0:5] = self.rs.randint(0, NP, 5)
         return t
+
+
+# ======================================================================================== RL-PSO
+def _rlpso_lib():
+    L = lib()
+    if not getattr(L, '_rlpso_ready', False):
+        L.orc_rlpso_new.restype = C.c_void_p
+        L.orc_rlpso_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_rlpso_free.argtypes = [C.c_void_p]
+        L.orc_rlpso_reset.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_rlpso_step.argtypes = [C.c_void_p, C.c_float, _dp, _dp, _dp]
+        L.orc_rlpso_state.argtypes = [C.c_void_p, _dp]
+        L._rlpso_ready = True
+    return L
+
+
+SC_RLPSO_W, SC_RLPSO_MAXCOST, SC_RLPSO_CUR = 10, 11, 12
+
+
+def rlpso_state_doubles(NP, D, nlog):
+    return 3 * NP * D + 2 * NP + D + 16 + nlog + 1
+
+
+def split_rlpso_state(st, NP, D, nlog):
+    o, out = 0, {}
+    for name, n in (('pos', NP * D), ('vel', NP * D), ('pbpos', NP * D), ('ccost', NP), ('pbest', NP), ('gbpos', D),
+                    ('scalars', NSCALAR), ('cost', nlog + 1)):
+        out[name] = st[o:o + n]
+        o += n
+    return out
+
+
+class RlpsoOracle:
+    """One RL-PSO instance on the CPU (rl_pso_optimizer.py restated in C)."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = _rlpso_lib().orc_rlpso_new(C.byref(self._st), float('nan') if optimum is None else float(optimum), C.byref(cfg),
+                                             int(seed))
+        self._state = np.empty(2 * cfg.dim)
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            _rlpso_lib().orc_rlpso_free(self._h)
+            self._h = None
+
+    def reset(self, tape=None):
+        _rlpso_lib().orc_rlpso_reset(self._h, _p(tape) if tape is not None else None, _p(self._state))
+        return self._state.copy()
+
+    def step(self, action, tape=None):
+        out = np.empty(2)
+        _rlpso_lib().orc_rlpso_step(self._h, float(np.float32(action)), _p(tape) if tape is not None else None, _p(self._state), _p(out))
+        return self._state.copy(), out[0], bool(out[1])
+
+    def state(self):
+        out = np.empty(rlpso_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
+        _rlpso_lib().orc_rlpso_state(self._h, _p(out))
+        return out
+
+
+class RlpsoTapeFeeder:
+    """numpy legacy-stream draws of RL_PSO_Optimizer in the reference's call order (init_population: uniform(NP, D) positions,
+    uniform(NP, D) velocities, evaluation noise of NP values; update: rand(), evaluation noise of one value)."""
+
+    def __init__(self, seed, NP, D, noise_kind):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise = NP, D, noise_kind
+        self.stride = 2 * NP * D + 3 * NP
+
+    def _noise(self, n):
+        rows = np.zeros((3, n))
+        if self.noise == 1:
+            rows[0] = self.rs.randn(n) if n > 1 else self.rs.randn()
+        elif self.noise == 2:
+            rows[0] = self.rs.rand(n) if n > 1 else self.rs.rand()
+            rows[1] = self.rs.rand(n) if n > 1 else self.rs.rand()
+        elif self.noise == 3:
+            rows[0] = self.rs.rand(n) if n > 1 else self.rs.rand()
+            rows[1] = self.rs.randn(n) if n > 1 else self.rs.randn()
+            rows[2] = self.rs.randn(n) if n > 1 else self.rs.randn()
+        return rows
+
+    def reset_tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        t[0:NP * D] = self.rs.random_sample((NP, D)).ravel()
+        t[NP * D:2 * NP * D] = self.rs.random_sample((NP, D)).ravel()
+        t[2 * NP * D:2 * NP * D + 3 * NP] = self._noise(NP).ravel()
+        return t
+
+    def step_tape(self):
+        t = np.zeros(self.stride)
+        t[0] = self.rs.rand()
+        t[1:4] = self._noise(1).ravel()
+        return t

@@ -209,7 +209,7 @@ def test_actor_table_equals_mlp_forward():
 
 
 def test_policy_kernel_equals_actor_forward():
-    """mbx_rlepso_policy (one launch: both MLPs, squashing, Philox Normal draw, clamp) vs the PyTorch fp32 modules and the
+    """mbx_gauss_policy (one launch: both MLPs, squashing, Philox Normal draw, clamp) vs the PyTorch fp32 modules and the
     reference's recorded (state -> mu, sigma) pairs; the draws are N(0, 1), reproducible and keyed by (seed, generation)."""
     from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
     from metabox_amd.config import get_config
@@ -261,7 +261,7 @@ def test_policy_kernel_equals_actor_forward():
 
 
 def test_fused_act_step_equals_policy_then_step():
-    """mbx_rlepso_act_step (action drawn inside the generation kernel from the actor table) == mbx_rlepso_policy + mbx_step,
+    """mbx_rlepso_act_step (action drawn inside the generation kernel from the actor table) == mbx_gauss_policy + mbx_step,
     bit for bit, over a whole episode including early stops and re-initialisations; the table rows equal the actor's forward."""
     from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
     from metabox_amd.config import get_config

@@ -451,6 +451,89 @@ def gen_ddqn():
     np.savez_compressed(os.path.join(OUT, 'ddqn_traces.npz'), **data)
 
 
+def run_rlpso_episode(problem, seed, agent, config, max_steps, action_mode):
+    """One reference RL-PSO rollout (one particle per step), recording the float32 actions and the outcomes."""
+    from optimizer import RL_PSO_Optimizer
+    from environment import PBO_Env
+    import copy
+    opt = RL_PSO_Optimizer(copy.deepcopy(config))
+    env = PBO_Env(problem, opt)
+    nets = agent._RL_PSO_Agent__nets
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ars = np.random.RandomState(40_000 + seed)
+    state = env.reset()
+    rec = dict(actions=[], gbest=[], reward=[], done=[], states=[np.concatenate([[-1], state])])
+    done, g = False, 0
+    while not done and g < max_steps:
+        if action_mode == 'policy':
+            with torch.no_grad():
+                a, _ = nets(torch.FloatTensor(state))
+            a = a.cpu().numpy()                         # shape (1,), float32 -- what rollout_episode passes (rl_pso_agent.py:118-124)
+        else:
+            a = np.array([ars.rand() * 1.4 - 0.2], dtype=np.float32)
+        state, r, done = env.step(a)
+        rec['actions'].append(np.float32(a[0]))
+        rec['gbest'].append(float(opt._RL_PSO_Optimizer__particles['gbest_val']))
+        rec['reward'].append(float(r))
+        rec['done'].append(bool(done))
+        if g % 211 == 0 or done or g < 3 or 99 <= g <= 101:
+            rec['states'].append(np.concatenate([[g], state]))
+        g += 1
+    pt = opt._RL_PSO_Optimizer__particles
+    return {'actions': np.array(rec['actions'], dtype=np.float32), 'gbest': np.array(rec['gbest']), 'reward': np.array(rec['reward']),
+            'done': np.array(rec['done']), 'states': np.stack(rec['states']), 'cost': np.array(opt.cost, dtype=np.float64),
+            'fes': np.float64(opt.fes), 'final_pos': np.array(pt['current_position']), 'final_vel': np.array(pt['velocity']),
+            'final_pbest': np.array(pt['pbest']), 'final_ccost': np.array(pt['c_cost']), 'w': np.float64(opt._RL_PSO_Optimizer__w)}
+
+
+def gen_rlpso():
+    """RL-PSO: the shipped bbob_easy policy (weights + I/O pairs) and seeded reference episodes."""
+    scratch = tempfile.mkdtemp()
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/RL_PSO_Agent.pkl'))
+    nets = agent._RL_PSO_Agent__nets
+    pol = {'nets/' + k: v.detach().cpu().numpy() for k, v in nets.state_dict().items()}
+    x = torch.rand(32, 20) * 10 - 5
+    with torch.no_grad():
+        _, _, mu, sigma = nets(x, require_musigma=True)
+    pol['io/x'] = x.numpy(); pol['io/mu'] = mu.numpy(); pol['io/sigma'] = sigma.numpy()
+    pol['meta/max_sigma'] = np.float64(nets._PolicyNetwork__max_sigma); pol['meta/min_sigma'] = np.float64(nets._PolicyNetwork__min_sigma)
+    np.savez_compressed(os.path.join(OUT, 'rlpso_policy.npz'), **pol)
+    pkg = os.path.join(os.path.dirname(HERE), 'metabox_amd', 'agent_model')
+    np.savez_compressed(os.path.join(pkg, 'rlpso_bbob_easy.npz'), **{k: v for k, v in pol.items() if k.startswith('nets/')})
+    print('rlpso policy:', {k: v.shape for k, v in pol.items() if k.startswith('nets')})
+    data, cases = {}, []
+    for suite, fids, seed, mode in (('bbob', (1, 8, 15, 21), 5, 'policy'), ('bbob', (3, 16), 6, 'uniform'), ('bbob-noisy', (103, 116, 128), 7, 'policy')):
+        config = ref_import.ref_config(['--problem', suite, '--dim', '10'], scratch)
+        config.maxFEs = 2500                       # shortened budget keeps the fixture small (log_interval follows)
+        config.log_interval = config.maxFEs // config.n_logpoint
+        tr, te, _ = all_problems(suite, 10)
+        byfid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            p = byfid[fid]
+            p.reset()
+            rec = run_rlpso_episode(p, seed, agent, config, 10 ** 9, mode)
+            key = f'{suite}/10/{fid}/{seed}'
+            cases.append(key)
+            for k, v in rec.items():
+                data[f'{key}/{k}'] = v
+            print(key, mode, len(rec['gbest']), rec['gbest'][-1], rec['fes'], rec['w'])
+    byid, _, _ = protein_problems()
+    config = ref_import.ref_config(['--problem', 'protein'], scratch)
+    agent12 = None
+    for pid, seed in (('1AVX_1', 8),):
+        p = byid[pid]
+        p.reset()
+        rec = run_rlpso_episode(p, seed, agent, config, 10 ** 9, 'uniform')      # the shipped net is 20-dimensional: uniform actions
+        key = f'protein/12/{pid}/{seed}'
+        cases.append(key)
+        for k, v in rec.items():
+            data[f'{key}/{k}'] = v
+        print(key, len(rec['gbest']), rec['gbest'][-1], rec['fes'])
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'rlpso_traces.npz'), **data)
+
+
 def copy_config(config):
     import copy
     return copy.deepcopy(config)
@@ -595,7 +678,7 @@ def gen_mte():
         json.dump(out, f, indent=1)
 
 
-SECTIONS = {'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+SECTIONS = {'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
