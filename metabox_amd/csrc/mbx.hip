@@ -101,7 +101,7 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.state_doubles = MBX_RLPSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
         g.sc_off = MBX_RLPSO_ST_SCALARS(c.np, c.dim);
         g.tape_stride = MBX_RLPSO_TAPE_STRIDE(c.np, c.dim);
-        g.lds_doubles = rp_lds_doubles(c.np, c.dim);
+        g.lds_doubles = rp_lds_doubles(c.np, c.dim, 0);
         g.state_dim = 2 * c.dim; g.action_dim = 1;
     }
     return g;
@@ -422,7 +422,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_RLPSO) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rs_population, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -489,8 +490,9 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
-        hipLaunchKernelGGL(k_rlpso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)d_actions, GaussMlp{}, 1, d_state_out, d_reward_out, d_done_out, (float*)nullptr);
+        hipLaunchKernelGGL(k_rlpso_step<false>, dim3(b->B), dim3(kThreads), (size_t)rp_lds_doubles(1, b->cfg.dim, 0) * sizeof(double),
+                           (hipStream_t)stream, make_params(b), (const float*)d_actions, GaussMlp{}, 1, d_state_out, d_reward_out,
+                           d_done_out, (float*)nullptr);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE)
@@ -581,8 +583,14 @@ extern "C" int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_s
     if ((size_t)(net->in_dim + 2 * net->h1 + 2 * net->h2 + 2) * sizeof(float) > (size_t)kRpActDoubles * sizeof(double))
         return fail(MBX_E_UNSUPPORTED, "mbx_rlpso_rollout: hidden layers too wide for the in-kernel actor");
     const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma, net->variant};
-    hipLaunchKernelGGL(k_rlpso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), (const float*)nullptr,
-                       g, n_steps, d_state_out, d_reward_out, d_done_out, d_actions_out);
+    const size_t step_lds = (size_t)rp_lds_doubles(1, b->cfg.dim, 2 * gauss_mlp_net_floats(net->in_dim, net->h1, net->h2, 1)) * sizeof(double);
+    if (step_lds > 64 * 1024) return fail(MBX_E_UNSUPPORTED, "mbx_rlpso_rollout: the actor does not fit the LDS budget of the step kernel");
+    if (n_steps == 1)
+        hipLaunchKernelGGL(k_rlpso_step<false>, dim3(b->B), dim3(kThreads), step_lds, (hipStream_t)stream, make_params(b),
+                           (const float*)nullptr, g, 1, d_state_out, d_reward_out, d_done_out, d_actions_out);
+    else
+        hipLaunchKernelGGL(k_rlpso_step<true>, dim3(b->B), dim3(kThreads), step_lds, (hipStream_t)stream, make_params(b),
+                           (const float*)nullptr, g, n_steps, d_state_out, d_reward_out, d_done_out, d_actions_out);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

@@ -9,7 +9,7 @@
 //                                         consecutive steps run in ONE launch; nothing returns to the host in between.
 // One workgroup per instance.  The particle table stays in HBM/L2 (a step touches one row; element (i, d) is always
 // read and written by thread d, scalars by thread 0, so no cross-thread traffic goes through global memory); the
-// gbest position, the next particle's position, the policy activations and the problem constants live in LDS.
+// gbest position, the next particle's position, the actor's weights and activations and the problem constants live in LDS.
 #pragma once
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"   // BatchParams, align2, GaussMlp, sample_normal
@@ -19,26 +19,30 @@ namespace mbx {
 struct RpLds {
     double *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *NC, *RED, *GB, *XC, *SC;
     float* ACTV;            // policy activations: input [2D] | h1 [2 h1] | h2 [2 h2] | out [2]
+    float* WTS;             // packed actor weights (mbx_rlpso_rollout only)
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
 
 constexpr int kRpActDoubles = 192;       // room for 2D + 2 h1 + 2 h2 + 2 floats (checked on the host)
 
-__host__ __device__ inline int64_t rp_lds_doubles(int NP, int D)
+// `rows` = evaluation rows the launch needs: NP for the reset, 1 for a step (17 KB instead of 27 KB at D = 10: the step kernel is a
+// chain of short latency-bound phases, so the number of resident workgroups per CU is what buys throughput).
+__host__ __device__ inline int64_t rp_lds_doubles(int rows, int D, int weight_floats)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
-    return NE + eval_t_doubles(NP, D) + SC + 2 * DD + 6 * align2(D) + P + 16 + MBX_NSCALAR + kRpActDoubles;
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(rows);
+    return NE + eval_t_doubles(rows, D) + SC + 2 * DD + 6 * align2(D) + P + 16 + MBX_NSCALAR + kRpActDoubles + align2((weight_floats + 1) / 2);
 }
 
-__device__ __forceinline__ RpLds rp_carve(double* base, int NP, int D)
+__device__ __forceinline__ RpLds rp_carve(double* base, int rows, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(rows);
     RpLds L;
     double* p = base;
-    L.X = p; p += NE;  L.T = p; p += eval_t_doubles(NP, D);  L.Z = p; p += SC;  L.M1T = p; p += DD;  L.M2T = p; p += DD;
+    L.X = p; p += NE;  L.T = p; p += eval_t_doubles(rows, D);  L.Z = p; p += SC;  L.M1T = p; p += DD;  L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
     L.GB = p; p += align2(D);  L.XC = p; p += align2(D);
-    L.NC = p; p += P;  L.RED = p; p += 16;  L.SC = p; p += MBX_NSCALAR;  L.ACTV = reinterpret_cast<float*>(p);
+    L.NC = p; p += P;  L.RED = p; p += 16;  L.SC = p; p += MBX_NSCALAR;  L.ACTV = reinterpret_cast<float*>(p); p += kRpActDoubles;
+    L.WTS = reinterpret_cast<float*>(p);
     return L;
 }
 
@@ -113,23 +117,26 @@ __device__ __forceinline__ float rp_policy(const GaussMlp& net, const RpLds& L, 
     __syncthreads();
     for (int j = tid; j < 2 * H1; j += kThreads) {
         const int n = j >= H1, o = j - n * H1;
-        const float* W = net.w + n * NW;
+        const float* W = L.WTS + n * NW;
         float acc = W[o_b1 + o];
+#pragma unroll 2
         for (int k = 0; k < IN; ++k) acc += sin_[k] * W[k * H1 + o];
         h1v[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
     for (int j = tid; j < 2 * H2; j += kThreads) {
         const int n = j >= H2, o = j - n * H2;
-        const float* W = net.w + n * NW;
+        const float* W = L.WTS + n * NW;
         float acc = W[o_b2 + o];
+#pragma unroll 2
         for (int k = 0; k < H1; ++k) acc += h1v[n * H1 + k] * W[o_w2 + k * H2 + o];
         h2v[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
     if (tid < 2) {
-        const float* W = net.w + tid * NW;
+        const float* W = L.WTS + tid * NW;
         float acc = W[o_b3];
+#pragma unroll 2
         for (int k = 0; k < H2; ++k) acc += h2v[tid * H2 + k] * W[o_w3 + k];
         outv[tid] = acc;
     }
@@ -140,6 +147,9 @@ __device__ __forceinline__ float rp_policy(const GaussMlp& net, const RpLds& L, 
 }
 
 // ------------------------------------------------------------------------------------------------ step (update :76-148)
+// MULTI = false: exactly one step, no loop -- 82 VGPRs; MULTI = true: the n_steps loop, in which the evaluator's loop-invariant
+// address arithmetic gets hoisted and stays live across iterations (141 VGPRs, 3 waves per SIMD instead of 5).
+template <bool MULTI>
 __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const float* __restrict__ actions, GaussMlp net, int n_steps,
                                                          double* __restrict__ state_out, double* __restrict__ reward_out,
                                                          uint8_t* __restrict__ done_out, float* __restrict__ actions_out)
@@ -154,10 +164,14 @@ __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const f
         return;
     }
     const DevProblem P = bp.problems[bp.problem_idx[b]];
-    const RpLds L = rp_carve(smem, NP, D);
+    const RpLds L = rp_carve(smem, 1, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const uint64_t seed = bp.seeds[b];
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb), c = 2.05;
+    if (net.w) {
+        const int nw = 2 * gauss_mlp_net_floats(2 * D, net.h1, net.h2, 1);
+        for (int k = tid; k < nw; k += kThreads) L.WTS[k] = net.w[k];
+    }
     double* gPos = S + MBX_RLPSO_ST_POS(NP, D);
     double* gVel = S + MBX_RLPSO_ST_VEL(NP, D);
     double* gPB = S + MBX_RLPSO_ST_PBPOS(NP, D);
@@ -172,7 +186,8 @@ __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const f
     const int episode = (int)L.SC[MBX_SC_EPISODE];
     double reward_sum = 0.;
     int done = 0;
-    for (int it = 0; it < n_steps && !done; ++it) {
+    MBX_PHASE_BEGIN
+    for (int it = 0; it < (MULTI ? n_steps : 1) && !done; ++it) {
         const int step = (int)L.SC[MBX_SC_GEN] + 1, j = (int)L.SC[MBX_SC_RLPSO_CUR];
         const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)episode};
         float action;
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const f
             action = rp_policy(net, L, D, rng);
             if (actions_out && tid == 0) actions_out[b] = action;
         } else action = actions[b];
+        MBX_PHASE(0);                                                // actor
         const double w = L.SC[MBX_SC_RLPSO_W] - 0.5 / ((double)bp.max_fes / NP);          // every call, not every generation
         double rand1;
         if (tape) rand1 = tape[MBX_RLPSO_TAPE_RAND1(NP, D)];
@@ -198,7 +214,9 @@ __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const f
             L.X[tid] = nx;
         }
         __syncthreads();
+        MBX_PHASE(1);                                                // move
         eval_rows(P, L.eval(), 1);
+        MBX_PHASE(2);                                                // evaluation
         if (tid == 0) {
             double nc = L.NC[0];
             if (P.noise_kind != MBX_NOISE_NONE) {
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const f
             L.RED[8] = pb_better; L.RED[9] = gb_better; L.RED[10] = reward;
         }
         __syncthreads();
+        MBX_PHASE(3);                                                // bookkeeping
         const int pb_better = (int)L.RED[8], gb_better = (int)L.RED[9];
         reward_sum += L.RED[10];
         done = L.SC[MBX_SC_DONE] != 0.;
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const f
             L.XC[tid] = gPos[((j + 1) % NP) * D + tid];
         }
         __syncthreads();
+        MBX_PHASE(4);                                                // commit + next particle
     }
     if (tid < MBX_NSCALAR) sc[tid] = L.SC[tid];
     if (tid < D && state_out) { state_out[(int64_t)b * 2 * D + tid] = L.GB[tid]; state_out[(int64_t)b * 2 * D + D + tid] = L.XC[tid]; }

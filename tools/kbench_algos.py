@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Throughput of the other batched paths (BASELINE.json configs 3 and 4, one GPU's share), policy included.
-   python tools/kbench_algos.py [lde|ddqn|rs] """
+   python tools/kbench_algos.py [lde|ddqn|rs|rlpso] """
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from metabox_amd.utils import construct_problem_set
 def timed(fn, steps):
     torch.cuda.synchronize(); t0 = time.perf_counter(); fn(steps); torch.cuda.synchronize(); return time.perf_counter() - t0
 
-which = sys.argv[1:] or ['lde', 'ddqn', 'rs']
+which = sys.argv[1:] or ['lde', 'ddqn', 'rs', 'rlpso']
 if 'lde' in which:
     from metabox_amd.agent import LDE_Agent
     from metabox_amd.optimizer import LDE_Optimizer
@@ -60,3 +60,29 @@ if 'rs' in which:
     rs = Random_search(cfg)
     torch.cuda.synchronize(); t0 = time.perf_counter(); rs.run_batch(s, np.repeat(np.arange(24), 51), np.arange(B)); dt = time.perf_counter() - t0
     print(json.dumps({'path': 'Random_search baseline epoch: 24 bbob problems x 51 runs, 199 populations each', 'seconds': dt}))
+if 'rlpso' in which:
+    from metabox_amd.agent import RL_PSO_Agent
+    from metabox_amd.optimizer import RL_PSO_Optimizer
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda']); cfg.agent_save_dir = None
+    agent = RL_PSO_Agent(cfg).load_exported_weights(np.load(os.path.join(os.path.dirname(__file__), '..', 'metabox_amd', 'agent_model', 'rlpso_bbob_easy.npz'))).to('cuda')
+    tr, te = construct_problem_set(cfg); ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+    B = 4096
+    nets = agent.nets; h1, h2 = nets.hidden_sizes(); net = (nets.packed_weights(), h1, h2, nets.min_sigma, nets.max_sigma)
+    for mode, steps in (('fused', 2048), ('fused1', 512), ('hip', 256), ('torch', 128)):
+        env = BatchedPBO_Env(ps, RL_PSO_Optimizer(cfg), np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
+        state = env.reset()
+        def run(n):
+            global state
+            with torch.no_grad():
+                if mode == 'fused':
+                    for _ in range(n // 256): env.batch.rlpso_rollout(*net, 256)
+                elif mode == 'fused1':
+                    for _ in range(n): env.batch.rlpso_rollout(*net, 1)
+                elif mode == 'hip':
+                    for _ in range(n): env.step(env.batch.gauss_policy(*net))
+                else:
+                    for _ in range(n):
+                        a, _ = nets(state.to(torch.float32)); state, _, _ = env.step(a.contiguous())
+        run(256 if mode == 'fused' else 5); dt = timed(run, steps)
+        print(json.dumps({'path': f'RL-PSO bbob d=10 NP=100, 4096 instances, policy={mode}', 'us_per_step': dt / steps * 1e6, 'env_steps_per_s': B * steps / dt}))
+        env.close()
