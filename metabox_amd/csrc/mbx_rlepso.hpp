@@ -41,7 +41,7 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
                   P = align2(NP), TS = eval_t_doubles(NP, D);
     // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC; M1T, M2T;
     // DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT, R1, R2: P each; COEF: 6*16; RED: 16; 3 int arrays
-    // (32.4 KB at NP = 100, D = 10: five workgroups per CU)
+    // (32.4 KB at NP = 100, D = 10: room for five workgroups per CU; the 99 VGPRs of k_rlepso_step make it four)
     return TS + NE + SC + 2 * DD + 6 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
 }
 
