@@ -97,6 +97,7 @@ int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f,
 #define MBX_ALGO_DEDDQN 3   /* src/optimizer/de_ddqn_optimizer.py  one step = one trial vector     */
 #define MBX_ALGO_RANDOM_SEARCH 4 /* src/optimizer/random_search.py  one step = NP uniform samples   */
 #define MBX_ALGO_RLPSO  5   /* src/optimizer/rl_pso_optimizer.py   one step = one particle         */
+#define MBX_ALGO_GLEET  6   /* src/optimizer/gleet_optimizer.py    one step = one generation       */
 
 typedef struct mbx_algo_cfg {
     int32_t algo;          /* MBX_ALGO_*                                                          */
@@ -115,7 +116,8 @@ typedef struct mbx_algo_cfg {
  *   LDE           : state [np+10]  (lde_optimizer.py:145-157),               action [2*np] float32
  *   DEDDQN        : state [99]     (de_ddqn_optimizer.py:76-129),            action [1] int32
  *   RANDOM_SEARCH : state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step)
- *   RLPSO         : state [2*dim]  (rl_pso_optimizer.py:62-63),             action [1] float32 */
+ *   RLPSO         : state [2*dim]  (rl_pso_optimizer.py:62-63),             action [1] float32
+ *   GLEET         : state [np*27]  (gleet_optimizer.py:111-124),            action [np] float32 */
 int mbx_state_dim(const mbx_algo_cfg* cfg);
 int mbx_action_dim(const mbx_algo_cfg* cfg);
 /* number of doubles of external random numbers one instance consumes per step (see mbx_set_tape) */

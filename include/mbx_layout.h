@@ -207,6 +207,40 @@
 #define MBX_SC_RLPSO_MAXCOST 11
 #define MBX_SC_RLPSO_CUR     12
 
+/* ---------------------------------------------------------------- 8. GLEET (gleet_optimizer.py) layouts
+ * One env step = one PSO generation; action [NP] float32 = each particle's share of the pbest attraction (:206-210);
+ * state [NP, 27] = 9 features of the particle (observe() :127-152) | the features it had when it last improved
+ * (pbest_feature) | the features of the gbest particle when gbest last improved (gbest_feature)  (:111-124, 290-296).
+ * state block: pos[NP*D] vel[NP*D] pbest_pos[NP*D] c_cost[NP] pbest[NP] per_no_improve[NP] gbest_pos[D]
+ *              pbest_feature[NP*9] gbest_feature[9 (+1 pad)] scalars[16] cost_curve[nlog+1];
+ * scalars beyond the common ones: inertia w (-= 0.5 / (maxFEs / NP) per generation), max_cost (= the MINIMUM of the initial
+ * costs, :51), no_improve.
+ * tape per reset: pos_u[NP*D] | vel_u[NP*D] | noise[3*NP];  per step: rand1[NP] | rand2[NP] | noise[3*NP].
+ * Philox: reset (gen 0): MBX_SITE_ELEM_R(e): u53(w0,w1) = pos_u, u53(w2,w3) = vel_u; noise MBX_SITE_NOISE1_A/B(i).
+ *         step (gen = generation): MBX_SITE_PART(i): u53(w0,w1) = rand1, u53(w2,w3) = rand2; noise MBX_SITE_NOISE0_A/B(i). */
+#define MBX_GLEET_NFEAT 9
+#define MBX_GLEET_TAPE_POS(NP, D)    ((int64_t)0)
+#define MBX_GLEET_TAPE_VEL(NP, D)    ((int64_t)(NP) * (D))
+#define MBX_GLEET_TAPE_NOISE_INIT(NP, D) (2 * (int64_t)(NP) * (D))
+#define MBX_GLEET_TAPE_RAND1(NP, D)  ((int64_t)0)
+#define MBX_GLEET_TAPE_RAND2(NP, D)  ((int64_t)(NP))
+#define MBX_GLEET_TAPE_NOISE(NP, D)  (2 * (int64_t)(NP))
+#define MBX_GLEET_TAPE_STRIDE(NP, D) (2 * (int64_t)(NP) * (D) + 3 * (int64_t)(NP))
+#define MBX_GLEET_ST_POS(NP, D)      ((int64_t)0)
+#define MBX_GLEET_ST_VEL(NP, D)      ((int64_t)(NP) * (D))
+#define MBX_GLEET_ST_PBPOS(NP, D)    (2 * (int64_t)(NP) * (D))
+#define MBX_GLEET_ST_CCOST(NP, D)    (3 * (int64_t)(NP) * (D))
+#define MBX_GLEET_ST_PBEST(NP, D)    (3 * (int64_t)(NP) * (D) + (NP))
+#define MBX_GLEET_ST_PNI(NP, D)      (3 * (int64_t)(NP) * (D) + 2 * (int64_t)(NP))
+#define MBX_GLEET_ST_GBPOS(NP, D)    (3 * (int64_t)(NP) * (D) + 3 * (int64_t)(NP))
+#define MBX_GLEET_ST_PFEAT(NP, D)    (3 * (int64_t)(NP) * (D) + 3 * (int64_t)(NP) + (D))
+#define MBX_GLEET_ST_GFEAT(NP, D)    (MBX_GLEET_ST_PFEAT(NP, D) + 9 * (int64_t)(NP))
+#define MBX_GLEET_ST_SCALARS(NP, D)  (MBX_GLEET_ST_GFEAT(NP, D) + 10)
+#define MBX_GLEET_STATE_DOUBLES(NP, D, NLOG) (MBX_GLEET_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_SC_GLEET_W         10
+#define MBX_SC_GLEET_MAXCOST   11
+#define MBX_SC_GLEET_NOIMPROVE 12
+
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u
 #define MBX_PHILOX_W0 0x9E3779B9u

@@ -39,7 +39,7 @@ class GaussMlp(C.Structure):
                 ('min_sigma', C.c_float), ('max_sigma', C.c_float), ('variant', C.c_int32)]
 
 
-ALGO_RLEPSO, ALGO_LDE, ALGO_DEDDQN, ALGO_RANDOM_SEARCH, ALGO_RLPSO = 1, 2, 3, 4, 5
+ALGO_RLEPSO, ALGO_LDE, ALGO_DEDDQN, ALGO_RANDOM_SEARCH, ALGO_RLPSO, ALGO_GLEET = 1, 2, 3, 4, 5, 6
 POLICY_RLEPSO, POLICY_RLPSO = 0, 1
 _ARRAY_FIELDS = ('dshift', 'm1', 'm2', 'v0', 'v1', 'v2', 'py', 'pc', 'pw')
 

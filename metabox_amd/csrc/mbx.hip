@@ -18,6 +18,7 @@
 #include "mbx_rs.hpp"
 #include "mbx_policy.hpp"
 #include "mbx_rlpso.hpp"
+#include "mbx_gleet.hpp"
 
 using namespace mbx;
 
@@ -103,6 +104,12 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_RLPSO_TAPE_STRIDE(c.np, c.dim);
         g.lds_doubles = rp_lds_doubles(c.np, c.dim, 0);
         g.state_dim = 2 * c.dim; g.action_dim = 1;
+    } else if (c.algo == MBX_ALGO_GLEET) {
+        g.state_doubles = MBX_GLEET_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_GLEET_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_GLEET_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = gl_lds_doubles(c.np, c.dim);
+        g.state_dim = 27 * c.np; g.action_dim = c.np;
     }
     return g;
 }
@@ -331,7 +338,7 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_RLPSO)
+    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_GLEET)
         return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
     if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
     if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
@@ -420,6 +427,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (cfg->algo == MBX_ALGO_GLEET) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_RLPSO) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -468,6 +478,8 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
         hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
         hipLaunchKernelGGL(k_rlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    else if (b->cfg.algo == MBX_ALGO_GLEET)
+        hipLaunchKernelGGL(k_gleet_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE)
@@ -489,6 +501,9 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_GLEET)
+        hipLaunchKernelGGL(k_gleet_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
         hipLaunchKernelGGL(k_rlpso_step<false>, dim3(b->B), dim3(kThreads), (size_t)rp_lds_doubles(1, b->cfg.dim, 0) * sizeof(double),
                            (hipStream_t)stream, make_params(b), (const float*)d_actions, GaussMlp{}, 1, d_state_out, d_reward_out,

@@ -486,3 +486,105 @@ class RlpsoTapeFeeder:
         t[0] = self.rs.rand()
         t[1:4] = self._noise(1).ravel()
         return t
+
+
+# ======================================================================================== GLEET
+def _gleet_lib():
+    L = lib()
+    if not getattr(L, '_gleet_ready', False):
+        L.orc_gleet_new.restype = C.c_void_p
+        L.orc_gleet_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_gleet_free.argtypes = [C.c_void_p]
+        L.orc_gleet_reset.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_gleet_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), _dp, _dp, _dp]
+        L.orc_gleet_state.argtypes = [C.c_void_p, _dp]
+        L._gleet_ready = True
+    return L
+
+
+SC_GLEET_W, SC_GLEET_MAXCOST, SC_GLEET_NOIMPROVE = 10, 11, 12
+
+
+def gleet_state_doubles(NP, D, nlog):
+    return 3 * NP * D + 3 * NP + D + 9 * NP + 10 + 16 + nlog + 1
+
+
+def split_gleet_state(st, NP, D, nlog):
+    o, out = 0, {}
+    for name, n in (('pos', NP * D), ('vel', NP * D), ('pbpos', NP * D), ('ccost', NP), ('pbest', NP), ('pni', NP), ('gbpos', D),
+                    ('pfeat', 9 * NP), ('gfeat', 10), ('scalars', NSCALAR), ('cost', nlog + 1)):
+        out[name] = st[o:o + n]
+        o += n
+    return out
+
+
+class GleetOracle:
+    """One GLEET instance on the CPU (gleet_optimizer.py restated in C).  State = [NP, 27]."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = _gleet_lib().orc_gleet_new(C.byref(self._st), float('nan') if optimum is None else float(optimum), C.byref(cfg),
+                                             int(seed))
+        self._state = np.empty((cfg.np, 27))
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            _gleet_lib().orc_gleet_free(self._h)
+            self._h = None
+
+    def reset(self, tape=None):
+        _gleet_lib().orc_gleet_reset(self._h, _p(tape) if tape is not None else None, _p(self._state))
+        return self._state.copy()
+
+    def step(self, action, tape=None):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        out = np.empty(2)
+        _gleet_lib().orc_gleet_step(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), _p(tape) if tape is not None else None,
+                                    _p(self._state), _p(out))
+        return self._state.copy(), out[0], bool(out[1])
+
+    def state(self):
+        out = np.empty(gleet_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
+        _gleet_lib().orc_gleet_state(self._h, _p(out))
+        return out
+
+
+class GleetTapeFeeder:
+    """numpy legacy-stream draws of GLEET_Optimizer in the reference's call order (init: uniform(NP, D) positions, uniform(NP, D)
+    velocities, evaluation noise; update: rand(NP, 1), rand(NP, 1), evaluation noise)."""
+
+    def __init__(self, seed, NP, D, noise_kind):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise = NP, D, noise_kind
+        self.stride = 2 * NP * D + 3 * NP
+
+    def _noise(self):
+        NP = self.NP
+        rows = np.zeros((3, NP))
+        if self.noise == 1:
+            rows[0] = self.rs.randn(NP)
+        elif self.noise == 2:
+            rows[0] = self.rs.rand(NP)
+            rows[1] = self.rs.rand(NP)
+        elif self.noise == 3:
+            rows[0] = self.rs.rand(NP)
+            rows[1] = self.rs.randn(NP)
+            rows[2] = self.rs.randn(NP)
+        return rows.ravel()
+
+    def reset_tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        t[0:NP * D] = self.rs.random_sample((NP, D)).ravel()
+        t[NP * D:2 * NP * D] = self.rs.random_sample((NP, D)).ravel()
+        t[2 * NP * D:2 * NP * D + 3 * NP] = self._noise()
+        return t
+
+    def step_tape(self):
+        NP = self.NP
+        t = np.zeros(self.stride)
+        t[0:NP] = self.rs.rand(NP, 1).ravel()
+        t[NP:2 * NP] = self.rs.rand(NP, 1).ravel()
+        t[2 * NP:5 * NP] = self._noise()
+        return t

@@ -1,0 +1,131 @@
+"""GLEET optimizer: the C oracle replays the reference's episodes (CPU); the fused HIP generation kernel with the
+9-feature epilogue replays them too and matches the oracle under Philox (GPU)."""
+import numpy as np
+import pytest
+
+from helpers import close, load, problems
+from oracle import oracle
+
+TR = load('gleet_traces.npz')
+CASES = [str(c) for c in TR['cases']]
+NP = 100
+ALGO_GLEET = 6
+
+
+def _setup(case):
+    suite, dim, fid, seed = case.split('/')
+    dim, seed = int(dim), int(seed)
+    if suite == 'protein':
+        from test_protein import protein
+        p = protein()[0][fid]
+        return p, None, dim, 1000, 5, 0, seed
+    p = problems(suite, dim)[int(fid)]
+    return p, p.bias, dim, 2000 * dim, 50, p.noise[0], seed
+
+
+def _actions(seed, G):
+    """The float32 actions tools/gen_golden.py (gleet section) fed to the reference, regenerated from the same seed."""
+    ars = np.random.RandomState(50_000 + seed)
+    return [ars.rand(NP).astype(np.float32) for _ in range(G)]
+
+
+def _feat_close(got, want):
+    return np.all(np.abs(got - want) <= 1e-7 * np.abs(want) + 1e-9)
+
+
+def _check(case, gb, rw, dn, states, cost, clen, fin, fes):
+    assert close(gb, TR[f'{case}/gbest']), case
+    ref_r = TR[f'{case}/reward']
+    assert np.all(np.abs(rw - ref_r) <= 1e-5 * np.abs(ref_r) + 1e-9), (case, int(np.argmax(np.abs(rw - ref_r))))
+    assert np.array_equal(dn, TR[f'{case}/done']), case
+    for g, want in zip(TR[f'{case}/state_gen'], TR[f'{case}/states']):
+        assert _feat_close(states[int(g)], want), (case, int(g))
+    for g, want in zip(TR[f'{case}/sub_gen'], TR[f'{case}/sub_states']):
+        assert _feat_close(states[int(g)][::11], want), (case, int(g))
+    ref_cost = TR[f'{case}/cost']
+    assert clen == len(ref_cost) and close(cost[:clen], ref_cost), case
+    assert np.abs(fin['pos'] - TR[f'{case}/final_pos'].ravel()).max() <= 1e-10, case
+    assert close(fin['pbest'], TR[f'{case}/final_pbest']) and np.array_equal(fin['pni'], TR[f'{case}/final_pni']), case
+    assert fes == TR[f'{case}/fes'] and abs(fin['scalars'][oracle.SC_GLEET_W] - TR[f'{case}/w']) <= 1e-12
+    assert fin['scalars'][oracle.SC_GLEET_NOIMPROVE] == TR[f'{case}/no_improve']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_replays_reference_gleet_episode(case):
+    p, opt, dim, maxfes, nlog, nk, seed = _setup(case)
+    cfg = oracle.make_cfg(ALGO_GLEET, NP, dim, maxfes, maxfes // nlog, nlog)
+    o = oracle.GleetOracle(p.desc(), opt, cfg)
+    fd = oracle.GleetTapeFeeder(seed, NP, dim, nk)
+    states = {-1: o.reset(fd.reset_tape())}
+    G = len(TR[f'{case}/gbest'])
+    acts = _actions(seed, G)
+    gb, rw, dn = np.zeros(G), np.zeros(G), np.zeros(G, bool)
+    for g in range(G):
+        s, r, d = o.step(acts[g], fd.step_tape())
+        gb[g] = oracle.split_gleet_state(o.state(), NP, dim, nlog)['scalars'][0]
+        rw[g], dn[g], states[g] = r, d, s
+    st = oracle.split_gleet_state(o.state(), NP, dim, nlog)
+    _check(case, gb, rw, dn, states, st['cost'], int(st['scalars'][3]), st, st['scalars'][1])
+
+
+@pytest.mark.gpu
+def test_hip_gleet_tape_replay_matches_reference():
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    for case in CASES:
+        p, opt, dim, maxfes, nlog, nk, seed = _setup(case)
+        s = Suite([p])
+        b = Batch(s, ALGO_GLEET, [0], [0], NP, maxfes, maxfes // nlog, nlog)
+        assert (b.state_dim, b.action_dim) == (27 * NP, NP)
+        fd = oracle.GleetTapeFeeder(seed, NP, dim, nk)
+        b.set_tape(torch.from_numpy(fd.reset_tape()[None]).cuda())
+        states = {-1: b.reset()[0].cpu().numpy().reshape(NP, 27).copy()}
+        G = len(TR[f'{case}/gbest'])
+        acts = _actions(seed, G)
+        gb, rw, dn = np.zeros(G), np.zeros(G), np.zeros(G, bool)
+        tape_dev = torch.empty(1, b.tape_stride, dtype=torch.float64, device='cuda')
+        sc_off = oracle.gleet_state_doubles(NP, dim, nlog) - (nlog + 1) - 16
+        for g in range(G):
+            tape_dev.copy_(torch.from_numpy(fd.step_tape()[None]))
+            b.set_tape(tape_dev)
+            st, r, d = b.step(torch.from_numpy(acts[g][None]).cuda())
+            rw[g] = r[0].item(); dn[g] = bool(d[0].item())
+            states[g] = st[0].cpu().numpy().reshape(NP, 27).copy()
+            gb[g] = b.read_state(0)[sc_off]
+        res = b.results()
+        fin = oracle.split_gleet_state(b.read_state(0), NP, dim, nlog)
+        _check(case, gb, rw, dn, states, res['cost'][0].cpu().numpy(), int(res['cost_len'][0].item()), fin, fin['scalars'][1])
+        b.close()
+
+
+@pytest.mark.gpu
+def test_hip_gleet_philox_parity_with_oracle():
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    ps = problems('bbob-noisy', 10)
+    ids = sorted(ps)
+    s = Suite([ps[i] for i in ids])
+    B, G = len(ids), 40
+    rs = np.random.RandomState(21)
+    actions = rs.rand(G, B, NP).astype(np.float32)
+    seeds = np.arange(B, dtype=np.uint64) * 53 + 17
+    b = Batch(s, ALGO_GLEET, np.arange(B), seeds, NP, 20000, 400, 50)
+    st0 = b.reset().cpu().numpy().reshape(B, NP, 27).copy()
+    hist = []
+    for g in range(G):
+        st, r, d = b.step(torch.from_numpy(actions[g]).cuda())
+        hist.append((st.cpu().numpy().reshape(B, NP, 27).copy(), r.cpu().numpy().copy()))
+    cfg = oracle.make_cfg(ALGO_GLEET, NP, 10, 20000, 400, 50)
+    for k in range(B):
+        p = s.problems[k]
+        o = oracle.GleetOracle(p.desc(), p.bias, cfg, seed=int(seeds[k]))
+        f0 = o.reset()
+        assert _feat_close(st0[k], f0), ids[k]
+        for g in range(G):
+            f, rew, d = o.step(actions[g, k])
+            assert _feat_close(hist[g][0][k], f), (ids[k], g)
+            assert abs(rew - hist[g][1][k]) <= 1e-5 * abs(rew) + 1e-9, (ids[k], g)
+        fin, ref = oracle.split_gleet_state(b.read_state(k), NP, 10, 50), oracle.split_gleet_state(o.state(), NP, 10, 50)
+        assert close(fin['pbest'], ref['pbest']) and np.array_equal(fin['pni'], ref['pni']) and close(fin['scalars'][:7], ref['scalars'][:7])
+        assert np.abs(fin['pfeat'] - ref['pfeat']).max() <= 1e-7 and np.abs(fin['gfeat'] - ref['gfeat']).max() <= 1e-7
+    b.close()

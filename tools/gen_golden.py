@@ -534,6 +534,77 @@ def gen_rlpso():
     np.savez_compressed(os.path.join(OUT, 'rlpso_traces.npz'), **data)
 
 
+def run_gleet_episode(problem, seed, config):
+    """One reference GLEET rollout driven by seeded float32 actions in [0, 1] (the agent's squashed output range)."""
+    from optimizer import GLEET_Optimizer
+    from environment import PBO_Env
+    import copy
+    opt = GLEET_Optimizer(copy.deepcopy(config))
+    env = PBO_Env(problem, opt)
+    np.random.seed(seed)
+    ars = np.random.RandomState(50_000 + seed)
+    state = env.reset()
+    rec = dict(gbest=[], reward=[], done=[], states=[(-1, state)], sub=[])
+    done, g = False, 0
+    while not done:
+        a = ars.rand(opt.ps).astype(np.float32)
+        state, r, done = env.step(a)
+        rec['gbest'].append(float(opt.particles['gbest_val']))
+        rec['reward'].append(float(r))
+        rec['done'].append(bool(done))
+        if done:
+            rec['states'].append((g, state))
+        elif g % 37 == 0:
+            rec['sub'].append((g, state[::11]))              # particles 0, 11, ..., 99: keeps the fixture small
+        g += 1
+    pt = opt.particles
+    # the actions are NOT stored: the tests regenerate them from RandomState(50000 + seed) exactly as above
+    return {'gbest': np.array(rec['gbest']), 'reward': np.array(rec['reward']),
+            'done': np.array(rec['done']), 'state_gen': np.array([k for k, _ in rec['states']]),
+            'states': np.stack([s for _, s in rec['states']]), 'sub_gen': np.array([k for k, _ in rec['sub']]),
+            'sub_states': np.stack([s for _, s in rec['sub']]), 'cost': np.array(opt.cost, dtype=np.float64), 'fes': np.float64(opt.fes),
+            'final_pos': np.array(pt['current_position']), 'final_pbest': np.array(pt['pbest']),
+            'final_pni': np.array(opt.per_no_improve), 'w': np.float64(opt.w), 'no_improve': np.float64(opt.no_improve)}
+
+
+def gen_gleet():
+    """GLEET optimizer: seeded reference episodes with recorded actions."""
+    scratch = tempfile.mkdtemp()
+    data, cases = {}, []
+    for suite, fids, seed in (('bbob', (1, 6, 15, 21), 11), ('bbob-noisy', (104, 117, 130), 12)):
+        config = ref_import.ref_config(['--problem', suite, '--dim', '10'], scratch)
+        tr, te, _ = all_problems(suite, 10)
+        byfid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            p = byfid[fid]
+            p.reset()
+            rec = run_gleet_episode(p, seed, config)
+            key = f'{suite}/10/{fid}/{seed}'
+            cases.append(key)
+            for k, v in rec.items():
+                data[f'{key}/{k}'] = v
+            print(key, len(rec['gbest']), rec['gbest'][-1], rec['fes'], rec['w'], rec['no_improve'])
+    config = ref_import.ref_config(['--problem', 'bbob', '--dim', '30'], scratch)
+    tr, te, _ = all_problems('bbob', 30)
+    byfid = {fid_of(p): p for p in tr + te}
+    byfid[10].reset()
+    rec = run_gleet_episode(byfid[10], 13, config)
+    cases.append('bbob/30/10/13')
+    for k, v in rec.items():
+        data[f'bbob/30/10/13/{k}'] = v
+    byid, _, _ = protein_problems()
+    config = ref_import.ref_config(['--problem', 'protein'], scratch)
+    p = byid['1ATN_7']
+    p.reset()
+    rec = run_gleet_episode(p, 14, config)
+    cases.append('protein/12/1ATN_7/14')
+    for k, v in rec.items():
+        data[f'protein/12/1ATN_7/14/{k}'] = v
+    print('protein', len(rec['gbest']), rec['gbest'][-1], rec['fes'])
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'gleet_traces.npz'), **data)
+
+
 def copy_config(config):
     import copy
     return copy.deepcopy(config)
@@ -678,7 +749,7 @@ def gen_mte():
         json.dump(out, f, indent=1)
 
 
-SECTIONS = {'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+SECTIONS = {'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
