@@ -5,3 +5,4 @@ from .de_ddqn_optimizer import DE_DDQN_Optimizer
 from .basic_optimizer import Basic_Optimizer
 from .random_search import Random_search
 from .rl_pso_optimizer import RL_PSO_Optimizer
+from .gleet_optimizer import GLEET_Optimizer

@@ -129,3 +129,74 @@ def test_hip_gleet_philox_parity_with_oracle():
         assert close(fin['pbest'], ref['pbest']) and np.array_equal(fin['pni'], ref['pni']) and close(fin['scalars'][:7], ref['scalars'][:7])
         assert np.abs(fin['pfeat'] - ref['pfeat']).max() <= 1e-7 and np.abs(fin['gfeat'] - ref['gfeat']).max() <= 1e-7
     b.close()
+
+
+def _agent(device):
+    from metabox_amd.agent import GLEET_Agent
+    from metabox_amd.config import get_config
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', device])
+    cfg.agent_save_dir = None
+    return GLEET_Agent(cfg).load_exported_weights(load('gleet_policy.npz')), cfg
+
+
+def test_gleet_networks_match_reference_io():
+    """The restated attention actor / critic load the reference's state_dict unchanged and reproduce its decoder output, (mu, sigma),
+    joint log-probability of a fixed action and value (host logic: runs on the CPU)."""
+    import torch
+    pol = load('gleet_policy.npz')
+    agent, cfg = _agent('cpu')
+    assert (cfg.embedding_dim, cfg.n_step, cfg.K_epochs, cfg.max_grad_norm) == (16, 10, 3, 0.1)
+    assert sum(p.numel() for p in agent.actor.parameters()) == 5426
+    x = torch.from_numpy(pol['io/x'])
+    with torch.no_grad():
+        z = agent.actor(x, only_critic=True)
+        mu, sigma = agent.actor.distribution(z)
+        _, logp, _ = agent.actor(x, fixed_action=torch.from_numpy(pol['io/fixed']))
+        value = agent.critic(z)[0]
+    assert np.allclose(z.numpy(), pol['io/z'], atol=2e-5) and np.allclose(mu.numpy(), pol['io/mu'], atol=2e-6)
+    assert np.allclose(sigma.numpy(), pol['io/sigma'], atol=2e-6) and np.allclose(logp.numpy(), pol['io/logp'], rtol=1e-5, atol=1e-4)
+    assert np.allclose(value.numpy(), pol['io/value'], atol=2e-5)
+    a, lp, zc, ent = agent.actor(x, require_entropy=True, to_critic=True)
+    assert a.shape == (3, 100, 1) and lp.shape == (3, 1) and zc.shape == (3, 100, 16) and ent.shape == (3, 100, 1)
+    assert float(a.min()) >= 0 and float(a.max()) <= 1
+
+
+@pytest.mark.gpu
+def test_gleet_protocol_rollout_and_training(tmp_path):
+    """PBO_Env(problem, GLEET_Optimizer) with the reference loops: rollout_episode, a few PPO updates of train_episode, and the
+    lock-step rollout_batch; the tester harness accepts the pair by name."""
+    import copy
+    import torch
+    from metabox_amd.environment import BatchedPBO_Env, PBO_Env
+    from metabox_amd.optimizer import GLEET_Optimizer
+    agent, cfg = _agent('cuda')
+    agent.to('cuda')
+    small = copy.deepcopy(cfg)
+    small.maxFEs, small.log_interval, small.n_logpoint = 1500, 100, 15
+    np.random.seed(5); torch.manual_seed(5)
+    p = problems('bbob', 10)[1]
+    opt = GLEET_Optimizer(small)
+    env = PBO_Env(p, opt)
+    s = env.reset()
+    assert s.shape == (100, 27) and opt.fes == 100 and np.all(s[:, :9] == s[:, 9:18])         # memories start as the features
+    s2, r, d = env.step(np.full(100, 0.5, dtype=np.float32))
+    assert s2.shape == (100, 27) and opt.fes == 200 and r >= 0 and not d
+    info = agent.rollout_episode(env)
+    assert info['fes'] == 1500 and len(info['cost']) == 16 and info['cost'][0] >= info['cost'][-1] and info['return'] >= 0
+    # PPO: 2 segments x 3 epochs, weights move
+    tcfg = copy.deepcopy(small)
+    tcfg.max_learning_step, tcfg.save_interval, tcfg.agent_save_dir = 6, 100, str(tmp_path) + '/'
+    agent.update_setting(tcfg)
+    before = [q.detach().clone() for q in agent.actor.parameters()]
+    with torch.enable_grad():
+        exceed, tinfo = agent.train_episode(PBO_Env(p, GLEET_Optimizer(small)))
+    assert exceed and tinfo['learn_steps'] == 6 and any(not torch.equal(a, b) for a, b in zip(before, agent.actor.parameters()))
+    # lock-step batch on the default budget
+    ps = [problems('bbob', 10)[f] for f in (1, 8, 21)]
+    B = 96
+    envb = BatchedPBO_Env(ps, GLEET_Optimizer(cfg), np.arange(B) % 3, np.arange(B, dtype=np.uint64) + 3)
+    out = agent.rollout_batch(envb)
+    cost = out['cost'].cpu().numpy()
+    assert cost.shape == (B, 51) and np.all(cost[:, 0] >= cost[:, -1]) and int(out['steps'].max()) <= 199
+    assert float(out['fes'].max()) == 20000 and bool((out['return'] >= 0).all())
+    envb.close()

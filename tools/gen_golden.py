@@ -605,6 +605,29 @@ def gen_gleet():
     np.savez_compressed(os.path.join(OUT, 'gleet_traces.npz'), **data)
 
 
+def gen_gleet_policy():
+    """GLEET actor / critic (no checkpoint ships for this agent): weights of a seeded fresh reference agent + I/O pairs."""
+    scratch = tempfile.mkdtemp()
+    config = ref_import.ref_config(['--problem', 'bbob', '--dim', '10'], scratch)
+    torch.manual_seed(321)
+    from agent import GLEET_Agent
+    agent = GLEET_Agent(copy_config(config))
+    pol = {'actor/' + k: v.detach().cpu().numpy() for k, v in agent.actor.state_dict().items()}
+    pol.update({'critic/' + k: v.detach().cpu().numpy() for k, v in agent.critic.state_dict().items()})
+    x = torch.rand(3, 100, 27) * 2 - 0.5
+    with torch.no_grad():
+        z = agent.actor(x, only_critic=True)
+        mu = (torch.tanh(agent.actor.mu_net(z)) + 1.) / 2.
+        sigma = (torch.tanh(agent.actor.sigma_net(z)) + 1.) / 2. * (agent.actor.max_sigma - agent.actor.min_sigma) + agent.actor.min_sigma
+        fixed = torch.rand(3, 100, 1)
+        _, logp, _ = agent.actor(x, fixed_action=fixed)
+        value = agent.critic(z)[0]
+    pol.update({'io/x': x.numpy(), 'io/z': z.numpy(), 'io/mu': mu.numpy(), 'io/sigma': sigma.numpy(), 'io/fixed': fixed.numpy(),
+                'io/logp': logp.numpy(), 'io/value': value.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'gleet_policy.npz'), **pol)
+    print('gleet policy:', {k: v.shape for k, v in pol.items()})
+
+
 def copy_config(config):
     import copy
     return copy.deepcopy(config)
@@ -749,7 +772,7 @@ def gen_mte():
         json.dump(out, f, indent=1)
 
 
-SECTIONS = {'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+SECTIONS = {'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Throughput of the other batched paths (BASELINE.json configs 3 and 4, one GPU's share), policy included.
-   python tools/kbench_algos.py [lde|ddqn|rs|rlpso] """
+   python tools/kbench_algos.py [lde|ddqn|rs|rlpso|gleet] """
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from metabox_amd.utils import construct_problem_set
 def timed(fn, steps):
     torch.cuda.synchronize(); t0 = time.perf_counter(); fn(steps); torch.cuda.synchronize(); return time.perf_counter() - t0
 
-which = sys.argv[1:] or ['lde', 'ddqn', 'rs', 'rlpso']
+which = sys.argv[1:] or ['lde', 'ddqn', 'rs', 'rlpso', 'gleet']
 if 'lde' in which:
     from metabox_amd.agent import LDE_Agent
     from metabox_amd.optimizer import LDE_Optimizer
@@ -86,3 +86,24 @@ if 'rlpso' in which:
         run(256 if mode == 'fused' else 5); dt = timed(run, steps)
         print(json.dumps({'path': f'RL-PSO bbob d=10 NP=100, 4096 instances, policy={mode}', 'us_per_step': dt / steps * 1e6, 'env_steps_per_s': B * steps / dt}))
         env.close()
+if 'gleet' in which:
+    from metabox_amd.agent import GLEET_Agent
+    from metabox_amd.optimizer import GLEET_Optimizer
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda']); cfg.agent_save_dir = None
+    torch.manual_seed(0)
+    agent = GLEET_Agent(cfg).to('cuda')
+    tr, te = construct_problem_set(cfg); ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+    B = 4096
+    env = BatchedPBO_Env(ps, GLEET_Optimizer(cfg), np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
+    state = env.reset()
+    const = torch.full((B, 100), 0.5, dtype=torch.float32, device='cuda')
+    def run_kernel(n):
+        for _ in range(n): env.step(const)
+    def run(n):
+        global state
+        for _ in range(n): state, _, _ = env.step(agent.act_batch(state))
+    run_kernel(5); dk = timed(run_kernel, 60)
+    run(3); dt = timed(run, 30)
+    print(json.dumps({'path': 'GLEET bbob d=10 NP=100, 4096 instances', 'kernel_us_per_step': dk / 60 * 1e6,
+                      'kernel_env_steps_per_s': B * 60 / dk, 'with_attention_policy_ms_per_step': dt / 30 * 1e3, 'env_steps_per_s': B * 30 / dt}))
+    env.close()
