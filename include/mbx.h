@@ -98,6 +98,7 @@ int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f,
 #define MBX_ALGO_RANDOM_SEARCH 4 /* src/optimizer/random_search.py  one step = NP uniform samples   */
 #define MBX_ALGO_RLPSO  5   /* src/optimizer/rl_pso_optimizer.py   one step = one particle         */
 #define MBX_ALGO_GLEET  6   /* src/optimizer/gleet_optimizer.py    one step = one generation       */
+#define MBX_ALGO_QLPSO  7   /* src/optimizer/qlpso_optimizer.py    one step = one particle         */
 
 typedef struct mbx_algo_cfg {
     int32_t algo;          /* MBX_ALGO_*                                                          */
@@ -117,7 +118,8 @@ typedef struct mbx_algo_cfg {
  *   DEDDQN        : state [99]     (de_ddqn_optimizer.py:76-129),            action [1] int32
  *   RANDOM_SEARCH : state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step)
  *   RLPSO         : state [2*dim]  (rl_pso_optimizer.py:62-63),             action [1] float32
- *   GLEET         : state [np*27]  (gleet_optimizer.py:111-124),            action [np] float32 */
+ *   GLEET         : state [np*27]  (gleet_optimizer.py:111-124),            action [np] float32
+ *   QLPSO         : state [1]      (qlpso_optimizer.py:89-90,125),          action [1] int32 in {0..3} */
 int mbx_state_dim(const mbx_algo_cfg* cfg);
 int mbx_action_dim(const mbx_algo_cfg* cfg);
 /* number of doubles of external random numbers one instance consumes per step (see mbx_set_tape) */
@@ -206,6 +208,13 @@ int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out
  * executed by this call, d_state_out / d_done_out the state and flag after the last one; d_actions_out, if not NULL,
  * the last sampled action [n_instances]. */
 int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_steps, float* d_actions_out, double* d_state_out,
+                      double* d_reward_out, uint8_t* d_done_out, void* stream);
+
+/* QLPSO with its tabular policy inside the step kernel, `n_steps` env steps per launch: the loop of QLPSO_Agent.rollout_episode
+ * (src/agent/qlpso_agent.py:66-75) with __get_action (:35-38: softmax over the Q-row of the state, np.random.choice) evaluated on
+ * the device.  d_q_table is [4, 4] float64 (states x actions).  With a replay tape (n_steps = 1) the choice uniform comes from
+ * the tape, so the reference's own decisions are reproduced.  Outputs as mbx_rlpso_rollout; d_actions_out [n_instances] int32. */
+int mbx_qlpso_rollout(mbx_batch* b, const double* d_q_table, int n_steps, int32_t* d_actions_out, double* d_state_out,
                       double* d_reward_out, uint8_t* d_done_out, void* stream);
 
 const char* mbx_last_error(void);

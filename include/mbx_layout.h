@@ -241,6 +241,35 @@
 #define MBX_SC_GLEET_MAXCOST   11
 #define MBX_SC_GLEET_NOIMPROVE 12
 
+/* ---------------------------------------------------------------- 9. QLPSO (qlpso_optimizer.py) layouts
+ * One env step = ONE particle (round robin over NP = 30): ring-neighbourhood best of size 4 / 8 / 16 / 30 chosen by the action,
+ * velocity (W = 0.729844, C = 1.49618, no velocity clamp), position clipping, one evaluation, swarm diversity, reward in
+ * {2, 1, 0, -2} from (cost improved?, diversity grew?) (:7-16, 45-125).  state [1] = the action the NEXT particle took last time
+ * (initially a random integer in 0..3, :89); action [1] int32 in 0..3.  The pointer is NOT reset by init_population (:33).
+ * state block: pop[NP*D] vel[NP*D] pbest_pos[NP*D] cost[NP] sstate[NP] scalars[16] cost_curve[nlog+1];
+ * scalars beyond the common ones: diversity, pointer.
+ * tape per reset: pos_u[NP*D] | noise[3*NP] | sstate[NP];  per step: rand_a | rand_b | noise[3] | choice_u (the uniform that
+ * QLPSO_Agent's np.random.choice consumes before the step; used by the fused policy only).
+ * Philox: reset (gen 0): MBX_SITE_LDE_ELEM(e): u53(w0,w1) = pos_u; noise MBX_SITE_NOISE1_A/B(i); MBX_SITE_PART(i): mulhi(w0, 4) = sstate.
+ *         step (gen = number of the step): MBX_SITE_PART(0): u53(w0,w1) = rand_a, u53(w2,w3) = rand_b; noise MBX_SITE_NOISE0_A/B(0);
+ *         MBX_SITE_POLICY(0): u53(w0,w1) = choice_u.                                                                              */
+#define MBX_QLPSO_TAPE_POS(NP, D)        ((int64_t)0)
+#define MBX_QLPSO_TAPE_NOISE_INIT(NP, D) ((int64_t)(NP) * (D))
+#define MBX_QLPSO_TAPE_SSTATE(NP, D)     ((int64_t)(NP) * (D) + 3 * (int64_t)(NP))
+#define MBX_QLPSO_TAPE_RAND(NP, D)       ((int64_t)0)
+#define MBX_QLPSO_TAPE_NOISE(NP, D)      ((int64_t)2)
+#define MBX_QLPSO_TAPE_CHOICE(NP, D)     ((int64_t)5)
+#define MBX_QLPSO_TAPE_STRIDE(NP, D)     ((int64_t)(NP) * (D) + 4 * (int64_t)(NP) + 8)
+#define MBX_QLPSO_ST_POP(NP, D)          ((int64_t)0)
+#define MBX_QLPSO_ST_VEL(NP, D)          ((int64_t)(NP) * (D))
+#define MBX_QLPSO_ST_PBPOS(NP, D)        (2 * (int64_t)(NP) * (D))
+#define MBX_QLPSO_ST_COST(NP, D)         (3 * (int64_t)(NP) * (D))
+#define MBX_QLPSO_ST_SSTATE(NP, D)       (3 * (int64_t)(NP) * (D) + (NP))
+#define MBX_QLPSO_ST_SCALARS(NP, D)      (3 * (int64_t)(NP) * (D) + 2 * (int64_t)(NP))
+#define MBX_QLPSO_STATE_DOUBLES(NP, D, NLOG) (MBX_QLPSO_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_SC_QLPSO_DIVERSITY 10
+#define MBX_SC_QLPSO_POINTER   11
+
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u
 #define MBX_PHILOX_W0 0x9E3779B9u

@@ -19,6 +19,7 @@
 #include "mbx_policy.hpp"
 #include "mbx_rlpso.hpp"
 #include "mbx_gleet.hpp"
+#include "mbx_qlpso.hpp"
 
 using namespace mbx;
 
@@ -110,6 +111,12 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_GLEET_TAPE_STRIDE(c.np, c.dim);
         g.lds_doubles = gl_lds_doubles(c.np, c.dim);
         g.state_dim = 27 * c.np; g.action_dim = c.np;
+    } else if (c.algo == MBX_ALGO_QLPSO) {
+        g.state_doubles = MBX_QLPSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = MBX_QLPSO_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = MBX_QLPSO_TAPE_STRIDE(c.np, c.dim);
+        g.lds_doubles = ql_lds_doubles(c.np, c.np, c.dim);
+        g.state_dim = 1; g.action_dim = 1;
     }
     return g;
 }
@@ -338,7 +345,7 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_GLEET)
+    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_QLPSO)
         return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
     if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
     if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
@@ -427,6 +434,10 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (cfg->algo == MBX_ALGO_QLPSO) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_qlpso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_qlpso_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_qlpso_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_GLEET) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -478,6 +489,8 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
         hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
         hipLaunchKernelGGL(k_rlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    else if (b->cfg.algo == MBX_ALGO_QLPSO)
+        hipLaunchKernelGGL(k_qlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_GLEET)
         hipLaunchKernelGGL(k_gleet_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
@@ -501,6 +514,10 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_QLPSO)
+        hipLaunchKernelGGL(k_qlpso_step<false>, dim3(b->B), dim3(kThreads), (size_t)ql_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double),
+                           (hipStream_t)stream, make_params(b), (const int32_t*)d_actions, (const double*)nullptr, 1, d_state_out,
+                           d_reward_out, d_done_out, (int32_t*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_GLEET)
         hipLaunchKernelGGL(k_gleet_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
@@ -606,6 +623,24 @@ extern "C" int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_s
     else
         hipLaunchKernelGGL(k_rlpso_step<true>, dim3(b->B), dim3(kThreads), step_lds, (hipStream_t)stream, make_params(b),
                            (const float*)nullptr, g, n_steps, d_state_out, d_reward_out, d_done_out, d_actions_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_qlpso_rollout(mbx_batch* b, const double* d_q_table, int n_steps, int32_t* d_actions_out, double* d_state_out,
+                                 double* d_reward_out, uint8_t* d_done_out, void* stream)
+{
+    if (!b || !d_q_table) return fail(MBX_E_ARG, "mbx_qlpso_rollout: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_QLPSO) return fail(MBX_E_UNSUPPORTED, "mbx_qlpso_rollout: the batch is not a QLPSO batch");
+    if (n_steps < 1) return fail(MBX_E_ARG, "mbx_qlpso_rollout: n_steps must be >= 1");
+    if (b->d_tape && n_steps != 1) return fail(MBX_E_ARG, "mbx_qlpso_rollout: a replay tape holds one step");
+    const size_t lds = (size_t)ql_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double);
+    if (n_steps == 1)
+        hipLaunchKernelGGL(k_qlpso_step<false>, dim3(b->B), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), (const int32_t*)nullptr,
+                           d_q_table, 1, d_state_out, d_reward_out, d_done_out, d_actions_out);
+    else
+        hipLaunchKernelGGL(k_qlpso_step<true>, dim3(b->B), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), (const int32_t*)nullptr,
+                           d_q_table, n_steps, d_state_out, d_reward_out, d_done_out, d_actions_out);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

@@ -138,7 +138,7 @@ class Batch:
         """actions: CUDA tensor [B, action_dim] (float32).  Returns (state, reward, done) device tensors that are
         overwritten by the next call."""
         if self.action_dim > 0:
-            want = torch.int32 if self.cfg.algo == _abi.ALGO_DEDDQN else torch.float32
+            want = torch.int32 if self.cfg.algo in (_abi.ALGO_DEDDQN, _abi.ALGO_QLPSO) else torch.float32
             assert actions.is_cuda and actions.is_contiguous() and actions.dtype == want
             assert actions.numel() == self.B * self.action_dim
         else:
@@ -161,6 +161,19 @@ class Batch:
             acts = self._actions
         net = self._net(weights, h1, h2, min_sigma, max_sigma)
         _abi.check(self.lib.mbx_rlpso_rollout(self._h, C.byref(net), int(n_steps), _ptr(acts), _ptr(self.state), _ptr(self.reward),
+                                              _ptr(self.done), _stream()))
+        return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
+
+    def qlpso_rollout(self, q_table, n_steps, want_actions=False):
+        """`n_steps` QLPSO env steps of every instance in ONE launch, tabular policy evaluated in the kernel (``mbx_qlpso_rollout``).
+        q_table: [4, 4] float64 CUDA tensor.  Returns (state, reward summed over the executed steps, done[, last actions int32])."""
+        assert q_table.is_cuda and q_table.dtype == torch.float64 and q_table.is_contiguous() and tuple(q_table.shape) == (4, 4)
+        acts = None
+        if want_actions:
+            if getattr(self, '_iactions', None) is None:
+                self._iactions = torch.empty(self.B, dtype=torch.int32, device=self.device)
+            acts = self._iactions
+        _abi.check(self.lib.mbx_qlpso_rollout(self._h, _ptr(q_table), int(n_steps), _ptr(acts), _ptr(self.state), _ptr(self.reward),
                                               _ptr(self.done), _stream()))
         return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
 

@@ -588,3 +588,116 @@ class GleetTapeFeeder:
         t[NP:2 * NP] = self.rs.rand(NP, 1).ravel()
         t[2 * NP:5 * NP] = self._noise()
         return t
+
+
+# ======================================================================================== QLPSO
+def _qlpso_lib():
+    L = lib()
+    if not getattr(L, '_qlpso_ready', False):
+        L.orc_qlpso_new.restype = C.c_void_p
+        L.orc_qlpso_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_qlpso_free.argtypes = [C.c_void_p]
+        L.orc_qlpso_reset.restype = C.c_double
+        L.orc_qlpso_reset.argtypes = [C.c_void_p, _dp]
+        L.orc_qlpso_step.restype = C.c_double
+        L.orc_qlpso_step.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.orc_qlpso_choose.restype = C.c_int
+        L.orc_qlpso_choose.argtypes = [_dp, C.c_double]
+        L.orc_qlpso_state.argtypes = [C.c_void_p, _dp]
+        L._qlpso_ready = True
+    return L
+
+
+SC_QLPSO_DIVERSITY, SC_QLPSO_POINTER = 10, 11
+
+
+def qlpso_state_doubles(NP, D, nlog):
+    return 3 * NP * D + 2 * NP + 16 + nlog + 1
+
+
+def split_qlpso_state(st, NP, D, nlog):
+    o, out = 0, {}
+    for name, n in (('pop', NP * D), ('vel', NP * D), ('pbpos', NP * D), ('cost', NP), ('sstate', NP), ('scalars', NSCALAR),
+                    ('clog', nlog + 1)):
+        out[name] = st[o:o + n]
+        o += n
+    return out
+
+
+def qlpso_choose(q_row, u):
+    """QLPSO_Agent.__get_action for one state row of the Q-table and one uniform (C restatement)."""
+    q = np.ascontiguousarray(q_row, dtype=np.float64)
+    return int(_qlpso_lib().orc_qlpso_choose(_p(q), float(u)))
+
+
+class QlpsoOracle:
+    """One QLPSO instance on the CPU (qlpso_optimizer.py restated in C).  Like the reference object, it keeps its particle pointer
+    across resets."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = _qlpso_lib().orc_qlpso_new(C.byref(self._st), float('nan') if optimum is None else float(optimum), C.byref(cfg),
+                                             int(seed))
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            _qlpso_lib().orc_qlpso_free(self._h)
+            self._h = None
+
+    def reset(self, tape=None):
+        return int(_qlpso_lib().orc_qlpso_reset(self._h, _p(tape) if tape is not None else None))
+
+    def step(self, action, tape=None):
+        out = np.empty(2)
+        s = _qlpso_lib().orc_qlpso_step(self._h, int(action), _p(tape) if tape is not None else None, _p(out))
+        return int(s), out[0], bool(out[1])
+
+    def state(self):
+        out = np.empty(qlpso_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
+        _qlpso_lib().orc_qlpso_state(self._h, _p(out))
+        return out
+
+
+class QlpsoTapeFeeder:
+    """numpy legacy-stream draws of a QLPSO rollout in the reference's call order.  init_population: rand(NP, D), evaluation noise,
+    randint(0, 4, NP).  Per step: (agent) the uniform of np.random.choice when `policy_draws`, then (optimizer) rand(), rand(),
+    evaluation noise of one value."""
+
+    def __init__(self, seed, NP, D, noise_kind, policy_draws=True):
+        self.rs = np.random.RandomState(seed)
+        self.NP, self.D, self.noise, self.policy_draws = NP, D, noise_kind, policy_draws
+        self.stride = NP * D + 4 * NP + 8
+
+    def _noise(self, n):
+        rows = np.zeros((3, n))
+        if self.noise == 1:
+            rows[0] = self.rs.randn(n) if n > 1 else self.rs.randn()
+        elif self.noise == 2:
+            rows[0] = self.rs.rand(n) if n > 1 else self.rs.rand()
+            rows[1] = self.rs.rand(n) if n > 1 else self.rs.rand()
+        elif self.noise == 3:
+            rows[0] = self.rs.rand(n) if n > 1 else self.rs.rand()
+            rows[1] = self.rs.randn(n) if n > 1 else self.rs.randn()
+            rows[2] = self.rs.randn(n) if n > 1 else self.rs.randn()
+        return rows
+
+    def reset_tape(self):
+        NP, D = self.NP, self.D
+        t = np.zeros(self.stride)
+        t[0:NP * D] = self.rs.rand(NP, D).ravel()
+        t[NP * D:NP * D + 3 * NP] = self._noise(NP).ravel()
+        t[NP * D + 3 * NP:NP * D + 4 * NP] = self.rs.randint(low=0, high=4, size=NP)
+        return t
+
+    def choice_uniform(self):
+        """The agent's draw, consumed BEFORE the optimizer's draws of the same step."""
+        return float(self.rs.random_sample(1)[0]) if self.policy_draws else 0.
+
+    def step_tape(self, choice_u=0.):
+        t = np.zeros(self.stride)
+        t[0] = self.rs.rand()
+        t[1] = self.rs.rand()
+        t[2:5] = self._noise(1).ravel()
+        t[5] = choice_u
+        return t

@@ -628,6 +628,69 @@ def gen_gleet_policy():
     print('gleet policy:', {k: v.shape for k, v in pol.items()})
 
 
+def run_qlpso_episode(problem, seed, agent, config, mode, opt=None):
+    """One reference QLPSO rollout.  mode 'policy': QLPSO_Agent.__get_action (softmax over the Q-row + np.random.choice from the
+    global stream); mode 'uniform': actions from a private RandomState (the global stream then only feeds the optimizer)."""
+    from optimizer import QLPSO_Optimizer
+    from environment import PBO_Env
+    import copy
+    opt = opt or QLPSO_Optimizer(copy.deepcopy(config))
+    env = PBO_Env(problem, opt)
+    np.random.seed(seed)
+    ars = np.random.RandomState(60_000 + seed)
+    state = env.reset()
+    rec = dict(actions=[], gbest=[], reward=[], done=[], states=[state])
+    done = False
+    while not done:
+        a = agent._QLPSO_Agent__get_action(state) if mode == 'policy' else np.array([ars.randint(0, 4)])
+        state, r, done = env.step(a)
+        rec['actions'].append(int(a[0]))
+        rec['gbest'].append(float(opt._QLPSO_Optimizer__gbest_cost))
+        rec['reward'].append(float(r))
+        rec['done'].append(bool(done))
+        rec['states'].append(int(np.squeeze(state)))
+    return opt, {'actions': np.array(rec['actions'], dtype=np.uint8), 'gbest': np.array(rec['gbest']), 'reward': np.array(rec['reward'], dtype=np.int8),
+                 'done': np.array(rec['done']), 'states': np.array(rec['states'], dtype=np.uint8), 'cost': np.array(opt.cost, dtype=np.float64),
+                 'fes': np.float64(opt.fes), 'final_pop': np.array(opt._QLPSO_Optimizer__population),
+                 'final_cost': np.array(opt._QLPSO_Optimizer__cost), 'diversity': np.float64(opt._QLPSO_Optimizer__diversity),
+                 'pointer': np.int64(opt._QLPSO_Optimizer__solution_pointer)}
+
+
+def gen_qlpso():
+    """QLPSO: the shipped bbob_easy Q-table and seeded reference episodes (policy- and uniform-driven); one optimizer
+    object is reused for two consecutive episodes because the reference never resets its particle pointer."""
+    scratch = tempfile.mkdtemp()
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/QLPSO_Agent.pkl'))
+    q = np.array(agent._QLPSO_Agent__q_table, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'qlpso_policy.npz'), q_table=q)
+    pkg = os.path.join(os.path.dirname(HERE), 'metabox_amd', 'agent_model')
+    np.savez_compressed(os.path.join(pkg, 'qlpso_bbob_easy.npz'), q_table=q)
+    print('q_table', q)
+    data, cases = {}, []
+    for suite, fids, seed, mode in (('bbob', (1, 8, 17, 21), 15, 'policy'), ('bbob', (3,), 16, 'uniform'), ('bbob-noisy', (105, 118, 129), 17, 'policy')):
+        config = ref_import.ref_config(['--problem', suite, '--dim', '10'], scratch)
+        config.maxFEs = 2500
+        config.log_interval = config.maxFEs // config.n_logpoint
+        tr, te, _ = all_problems(suite, 10)
+        byfid = {fid_of(p): p for p in tr + te}
+        for fid in fids:
+            p = byfid[fid]
+            p.reset()
+            opt, rec = run_qlpso_episode(p, seed, agent, config, mode)
+            key = f'{suite}/10/{fid}/{seed}/{mode}'
+            cases.append(key)
+            for k, v in rec.items():
+                data[f'{key}/{k}'] = v
+            print(key, len(rec['gbest']), rec['gbest'][-1], rec['fes'], rec['pointer'], np.bincount(rec['actions'], minlength=4))
+            if fid == 8:                            # second episode on the SAME optimizer object: the pointer carries over
+                _, rec2 = run_qlpso_episode(p, seed + 100, agent, config, mode, opt=opt)
+                for k, v in rec2.items():
+                    data[f'{key}/second/{k}'] = v
+                print('   second episode', rec2['gbest'][-1], rec2['pointer'])
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'qlpso_traces.npz'), **data)
+
+
 def copy_config(config):
     import copy
     return copy.deepcopy(config)
@@ -772,7 +835,7 @@ def gen_mte():
         json.dump(out, f, indent=1)
 
 
-SECTIONS = {'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+SECTIONS = {'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':

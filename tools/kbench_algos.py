@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Throughput of the other batched paths (BASELINE.json configs 3 and 4, one GPU's share), policy included.
-   python tools/kbench_algos.py [lde|ddqn|rs|rlpso|gleet] """
+   python tools/kbench_algos.py [lde|ddqn|rs|rlpso|gleet|qlpso] """
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from metabox_amd.utils import construct_problem_set
 def timed(fn, steps):
     torch.cuda.synchronize(); t0 = time.perf_counter(); fn(steps); torch.cuda.synchronize(); return time.perf_counter() - t0
 
-which = sys.argv[1:] or ['lde', 'ddqn', 'rs', 'rlpso', 'gleet']
+which = sys.argv[1:] or ['lde', 'ddqn', 'rs', 'rlpso', 'gleet', 'qlpso']
 if 'lde' in which:
     from metabox_amd.agent import LDE_Agent
     from metabox_amd.optimizer import LDE_Optimizer
@@ -106,4 +106,18 @@ if 'gleet' in which:
     run(3); dt = timed(run, 30)
     print(json.dumps({'path': 'GLEET bbob d=10 NP=100, 4096 instances', 'kernel_us_per_step': dk / 60 * 1e6,
                       'kernel_env_steps_per_s': B * 60 / dk, 'with_attention_policy_ms_per_step': dt / 30 * 1e3, 'env_steps_per_s': B * 30 / dt}))
+    env.close()
+if 'qlpso' in which:
+    from metabox_amd.optimizer import QLPSO_Optimizer
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda']); cfg.agent_save_dir = None
+    q = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), '..', 'metabox_amd', 'agent_model', 'qlpso_bbob_easy.npz'))['q_table']).cuda()
+    tr, te = construct_problem_set(cfg); ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+    B = 4096
+    env = BatchedPBO_Env(ps, QLPSO_Optimizer(cfg), np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
+    env.reset()
+    def run(n):
+        for _ in range(n // 256): env.batch.qlpso_rollout(q, 256)
+    run(256); dt = timed(run, 2048)
+    print(json.dumps({'path': 'QLPSO bbob d=10 NP=30, 4096 instances, tabular policy in the kernel, 256 steps per launch', 'us_per_step': dt / 2048 * 1e6,
+                      'env_steps_per_s': B * 2048 / dt}))
     env.close()
