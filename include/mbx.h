@@ -210,6 +210,20 @@ int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out
 int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_steps, float* d_actions_out, double* d_state_out,
                       double* d_reward_out, uint8_t* d_done_out, void* stream);
 
+/* GLEET's attention actor (src/agent/gleet_agent.py:314-444, Actor.forward without fixed_action) for every swarm of the batch in
+ * ONE launch: embedding, encoder layer, memory-query decoder layer (4 heads of 4, swarm-wide normalisation, FF 16), the two
+ * 16-32-8-1 heads, squashing, Normal sample and clamp.  The architecture is the reference's fixed configuration (:31-45);
+ * d_weights is the actor's state_dict flattened in its own order (5426 float32: embedder, encoder.0 {W_query, W_key, W_val,
+ * W_out, FF.0.weight, FF.0.bias, FF.2.weight, FF.2.bias}, embedder_for_decoder, decoder.0 {...}, mu_net, sigma_net).
+ * d_state [n_instances, np, 27] float64 (what mbx_reset / mbx_step wrote) -> d_actions [n_instances, np] float32;
+ * d_mu_sigma, if not NULL, receives [n_instances, 2, np].  float32 arithmetic; Philox draws (i, MBX_SITE_POLICY, gen + 1, episode). */
+typedef struct mbx_gleet_actor {
+    const float* d_weights;
+    int32_t n_floats;             /* must be 5426 */
+    float min_sigma, max_sigma;
+} mbx_gleet_actor;
+int mbx_gleet_policy(mbx_batch* b, const mbx_gleet_actor* net, const double* d_state, float* d_actions, float* d_mu_sigma, void* stream);
+
 /* QLPSO with its tabular policy inside the step kernel, `n_steps` env steps per launch: the loop of QLPSO_Agent.rollout_episode
  * (src/agent/qlpso_agent.py:66-75) with __get_action (:35-38: softmax over the Q-row of the state, np.random.choice) evaluated on
  * the device.  d_q_table is [4, 4] float64 (states x actions).  With a replay tape (n_steps = 1) the choice uniform comes from

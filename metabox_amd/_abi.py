@@ -39,6 +39,11 @@ class GaussMlp(C.Structure):
                 ('min_sigma', C.c_float), ('max_sigma', C.c_float), ('variant', C.c_int32)]
 
 
+class GleetActor(C.Structure):
+    """mbx_gleet_actor"""
+    _fields_ = [('d_weights', C.c_void_p), ('n_floats', C.c_int32), ('min_sigma', C.c_float), ('max_sigma', C.c_float)]
+
+
 ALGO_RLEPSO, ALGO_LDE, ALGO_DEDDQN, ALGO_RANDOM_SEARCH, ALGO_RLPSO, ALGO_GLEET, ALGO_QLPSO = 1, 2, 3, 4, 5, 6, 7
 POLICY_RLEPSO, POLICY_RLPSO = 0, 1
 _ARRAY_FIELDS = ('dshift', 'm1', 'm2', 'v0', 'v1', 'v2', 'py', 'pc', 'pw')
@@ -120,6 +125,7 @@ def load_lib():
         'mbx_rlepso_act_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
         'mbx_rlpso_rollout': (C.c_int, [vp, C.POINTER(GaussMlp), C.c_int, vp, vp, vp, vp, vp]),
         'mbx_qlpso_rollout': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+        'mbx_gleet_policy': (C.c_int, [vp, C.POINTER(GleetActor), vp, vp, vp, vp]),
         'mbx_instance_state_doubles': (i64, [vp]),
         'mbx_debug_read_state': (C.c_int, [vp, C.c_int, c_double_p]),
         'mbx_last_error': (C.c_char_p, []),
@@ -136,7 +142,7 @@ def load_lib():
 EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval',
                     'mbx_state_dim', 'mbx_action_dim', 'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy',
                     'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results', 'mbx_gauss_policy', 'mbx_rlepso_policy_table_rows',
-                    'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_instance_state_doubles',
+                    'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_instance_state_doubles',
                     'mbx_debug_read_state', 'mbx_last_error', 'mbx_version')
 
 

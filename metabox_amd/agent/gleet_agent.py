@@ -111,6 +111,25 @@ class Actor(nn.Module):
         self.sigma_net = _head(embedding_dim, hidden_dim1, hidden_dim2)
         self.max_sigma, self.min_sigma = max_sigma, min_sigma
 
+    _PACK_ORDER = ('embedder.embedder.weight',) + tuple(
+        f'{blk}.0.{name}' for blk in ('encoder', 'decoder') for name in (
+            'MHA_sublayer.MHA.W_query', 'MHA_sublayer.MHA.W_key', 'MHA_sublayer.MHA.W_val', 'MHA_sublayer.MHA.W_out',
+            'FFandNorm_sublayer.FF.0.weight', 'FFandNorm_sublayer.FF.0.bias', 'FFandNorm_sublayer.FF.2.weight', 'FFandNorm_sublayer.FF.2.bias'))
+
+    def packed_weights(self):
+        """float32 CUDA tensor in the layout ``mbx_gleet_actor`` documents (include/mbx.h); re-packed after in-place updates."""
+        ps = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_pw_key', None) != key:
+            sd = self.state_dict()
+            enc = [k for k in self._PACK_ORDER if k.startswith(('embedder.', 'encoder.'))]
+            dec = [k for k in self._PACK_ORDER if k.startswith('decoder.')]
+            heads = [f'{n}.net.layer{i}-linear.{w}' for n in ('mu_net', 'sigma_net') for i in range(3) for w in ('weight', 'bias')]
+            order = enc + ['embedder_for_decoder.embedder.weight'] + dec + heads
+            self._pw = torch.cat([sd[k].detach().reshape(-1) for k in order]).to(torch.float32).contiguous()
+            self._pw_key = key
+        return self._pw
+
     def features(self, x):
         """[B, ps, 27] -> decoder output z [B, ps, E] (what the critic consumes)."""
         n = self.node_dim
@@ -289,13 +308,20 @@ class GLEET_Agent(Basic_Agent):
             out[a:a + chunk] = torch.addcmul(mu, sigma, torch.randn_like(mu)).clamp_(0, 1).squeeze(-1)
         return out
 
-    def rollout_batch(self, env, max_steps=None):
-        """Lock-step rollout of a BatchedPBO_Env: one policy forward over the whole batch and one fused generation kernel per step."""
+    def rollout_batch(self, env, max_steps=None, policy='hip'):
+        """Lock-step rollout of a BatchedPBO_Env, two launches per generation: policy = 'hip' (default) evaluates the attention actor
+        with ``mbx_gleet_policy`` (one workgroup per swarm), 'torch' with the PyTorch modules (``act_batch``); then the fused
+        generation kernel.  Both sample the same distribution; 'torch' uses torch's generator instead of the instance's Philox stream."""
         bc = env.batch.cfg
         if max_steps is None:
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         state = env.reset()
+        actor = self.actor
         for _ in range(max_steps):
-            state, _, _ = env.step(self.act_batch(state))
+            if policy == 'hip':
+                actions = env.batch.gleet_policy(actor.packed_weights(), actor.min_sigma, actor.max_sigma)
+            else:
+                actions = self.act_batch(state)
+            state, _, _ = env.step(actions)
         res = env.results()
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}

@@ -20,6 +20,7 @@
 #include "mbx_rlpso.hpp"
 #include "mbx_gleet.hpp"
 #include "mbx_qlpso.hpp"
+#include "mbx_gleet_policy.hpp"
 
 using namespace mbx;
 
@@ -623,6 +624,20 @@ extern "C" int mbx_rlpso_rollout(mbx_batch* b, const mbx_gauss_mlp* net, int n_s
     else
         hipLaunchKernelGGL(k_rlpso_step<true>, dim3(b->B), dim3(kThreads), step_lds, (hipStream_t)stream, make_params(b),
                            (const float*)nullptr, g, n_steps, d_state_out, d_reward_out, d_done_out, d_actions_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_gleet_policy(mbx_batch* b, const mbx_gleet_actor* net, const double* d_state, float* d_actions, float* d_mu_sigma,
+                                void* stream)
+{
+    if (!b || !net || !net->d_weights || !d_state || !d_actions) return fail(MBX_E_ARG, "mbx_gleet_policy: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_GLEET) return fail(MBX_E_UNSUPPORTED, "mbx_gleet_policy: the batch is not a GLEET batch");
+    if (net->n_floats != GpOff::total) return fail(MBX_E_ARG, "mbx_gleet_policy: expected %d weights, got %d", GpOff::total, net->n_floats);
+    if (b->cfg.np > kGpThreads) return fail(MBX_E_UNSUPPORTED, "mbx_gleet_policy: np %d > %d", b->cfg.np, kGpThreads);
+    const GleetActor g{net->d_weights, net->min_sigma, net->max_sigma};
+    hipLaunchKernelGGL(k_gleet_policy, dim3(b->B), dim3(kGpThreads), gleet_policy_lds_bytes(b->cfg.np), (hipStream_t)stream, make_params(b),
+                       g, d_state, d_actions, d_mu_sigma);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

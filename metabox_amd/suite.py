@@ -164,6 +164,18 @@ class Batch:
                                               _ptr(self.done), _stream()))
         return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
 
+    def gleet_policy(self, weights, min_sigma, max_sigma, want_mu_sigma=False):
+        """GLEET's attention actor over the batch's current state in one launch (``mbx_gleet_policy``).  weights: the actor's
+        state_dict flattened (``Actor.packed_weights``).  Returns [B, np] float32 actions (overwritten by the next call), plus
+        [B, 2, np] (mu, sigma) if asked."""
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        if getattr(self, '_actions', None) is None:
+            self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
+        ms = torch.empty(self.B, 2, self.action_dim, dtype=torch.float32, device=self.device) if want_mu_sigma else None
+        net = _abi.GleetActor(weights.data_ptr(), int(weights.numel()), float(min_sigma), float(max_sigma))
+        _abi.check(self.lib.mbx_gleet_policy(self._h, C.byref(net), _ptr(self.state), _ptr(self._actions), _ptr(ms), _stream()))
+        return (self._actions, ms) if want_mu_sigma else self._actions
+
     def qlpso_rollout(self, q_table, n_steps, want_actions=False):
         """`n_steps` QLPSO env steps of every instance in ONE launch, tabular policy evaluated in the kernel (``mbx_qlpso_rollout``).
         q_table: [4, 4] float64 CUDA tensor.  Returns (state, reward summed over the executed steps, done[, last actions int32])."""

@@ -200,3 +200,41 @@ def test_gleet_protocol_rollout_and_training(tmp_path):
     assert cost.shape == (B, 51) and np.all(cost[:, 0] >= cost[:, -1]) and int(out['steps'].max()) <= 199
     assert float(out['fes'].max()) == 20000 and bool((out['return'] >= 0).all())
     envb.close()
+
+
+@pytest.mark.gpu
+def test_gleet_policy_kernel_equals_attention_modules():
+    """mbx_gleet_policy (one workgroup per swarm: embeddings, two attention layers, normalisations, heads, sampling) vs the PyTorch
+    modules on the states of a running batch and on the reference's recorded I/O; float32 round-off tolerance."""
+    import torch
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import GLEET_Optimizer
+    agent, cfg = _agent('cuda')
+    agent.to('cuda')
+    actor = agent.actor
+    w = actor.packed_weights()
+    assert w.numel() == 5426
+    ps = [problems('bbob', 10)[f] for f in (1, 8, 21)]
+    B = 67
+    env = BatchedPBO_Env(ps, GLEET_Optimizer(cfg), np.arange(B) % 3, np.arange(B, dtype=np.uint64) + 3)
+    state = env.reset()
+    for g in range(6):
+        act, ms = env.batch.gleet_policy(w, actor.min_sigma, actor.max_sigma, want_mu_sigma=True)
+        with torch.no_grad():
+            mu, sg = actor.distribution(actor.features(state.view(B, 100, 27).to(torch.float32)))
+        assert torch.allclose(ms[:, 0], mu[..., 0], atol=2e-4) and torch.allclose(ms[:, 1], sg[..., 0], atol=2e-4), g
+        assert float(act.min()) >= 0 and float(act.max()) <= 1
+        z = ((act - ms[:, 0]) / ms[:, 1])[(act > 0) & (act < 1)]
+        assert z.numel() > 1000 and float(z.abs().max()) < 6.5 and float(z.std()) > 0.3     # un-clamped draws: bounded normal deviates
+        again = env.batch.gleet_policy(w, actor.min_sigma, actor.max_sigma).clone()
+        assert torch.equal(again, act)
+        state, _, _ = env.step(act)
+    # the reference's recorded swarms
+    pol = load('gleet_policy.npz')
+    x = torch.from_numpy(pol['io/x']).cuda().double().reshape(3, 2700)
+    env.batch.state[:3] = x
+    _, ms = env.batch.gleet_policy(w, actor.min_sigma, actor.max_sigma, want_mu_sigma=True)
+    assert np.allclose(ms[:3, 0].cpu().numpy(), pol['io/mu'][..., 0], atol=2e-4) and np.allclose(ms[:3, 1].cpu().numpy(), pol['io/sigma'][..., 0], atol=2e-4)
+    env.close()
+    out = agent.rollout_batch(BatchedPBO_Env(ps, GLEET_Optimizer(cfg), np.arange(B) % 3, np.arange(B, dtype=np.uint64) + 3))
+    assert bool((out['cost'][:, 0] >= out['cost'][:, -1]).all()) and float(out['fes'].max()) == 20000

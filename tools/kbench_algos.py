@@ -102,10 +102,15 @@ if 'gleet' in which:
     def run(n):
         global state
         for _ in range(n): state, _, _ = env.step(agent.act_batch(state))
+    w = agent.actor.packed_weights()
+    def run_hip(n):
+        for _ in range(n): env.step(env.batch.gleet_policy(w, agent.actor.min_sigma, agent.actor.max_sigma))
     run_kernel(5); dk = timed(run_kernel, 60)
     run(3); dt = timed(run, 30)
+    run_hip(5); dh = timed(run_hip, 60)
     print(json.dumps({'path': 'GLEET bbob d=10 NP=100, 4096 instances', 'kernel_us_per_step': dk / 60 * 1e6,
-                      'kernel_env_steps_per_s': B * 60 / dk, 'with_attention_policy_ms_per_step': dt / 30 * 1e3, 'env_steps_per_s': B * 30 / dt}))
+                      'kernel_env_steps_per_s': B * 60 / dk, 'with_torch_policy_ms_per_step': dt / 30 * 1e3, 'torch_env_steps_per_s': B * 30 / dt,
+                      'with_hip_policy_us_per_step': dh / 60 * 1e6, 'hip_env_steps_per_s': B * 60 / dh}))
     env.close()
 if 'qlpso' in which:
     from metabox_amd.optimizer import QLPSO_Optimizer
