@@ -231,6 +231,10 @@ int mbx_gleet_policy(mbx_batch* b, const mbx_gleet_actor* net, const double* d_s
 int mbx_qlpso_rollout(mbx_batch* b, const double* d_q_table, int n_steps, int32_t* d_actions_out, double* d_state_out,
                       double* d_reward_out, uint8_t* d_done_out, void* stream);
 
+/* Test / diagnostics: apply one of the device math routines the objectives are built from to n device values.
+ * op: 0 log, 1 exp, 2 sin, 3 cos, 4 pow(x, y), 5 T_osz(x) (bbob.py:51-67), 6 T_asy(x; beta_lin = y) (bbob.py:70-82). */
+int mbx_debug_math(int op, const double* d_x, const double* d_y, double* d_out, int n, void* stream);
+
 const char* mbx_last_error(void);
 const char* mbx_version(void);
 

@@ -671,6 +671,33 @@ extern "C" int mbx_results(mbx_batch* b, double* d_cost_curves, double* d_fes, d
     return MBX_OK;
 }
 
+// Test / diagnostics: the device math routines the objectives are built from, applied element-wise.
+__global__ void k_debug_math(int op, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y ? y[i] : 0.;
+    double r;
+    switch (op) {
+    case 0: r = m_log(a); break;
+    case 1: r = m_exp(a); break;
+    case 2: r = m_sin(a); break;
+    case 3: r = m_cos(a); break;
+    case 4: r = m_pow(a, b); break;
+    case 5: r = osc1(a); break;
+    default: r = asy1(a, b); break;
+    }
+    out[i] = r;
+}
+
+extern "C" int mbx_debug_math(int op, const double* d_x, const double* d_y, double* d_out, int n, void* stream)
+{
+    if (op < 0 || op > 6 || !d_x || !d_out || n < 0 || ((op == 4 || op == 6) && !d_y)) return fail(MBX_E_ARG, "mbx_debug_math: bad arguments");
+    if (n) hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, d_x, d_y, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
 extern "C" int64_t mbx_instance_state_doubles(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "null batch");

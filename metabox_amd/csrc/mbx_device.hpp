@@ -11,6 +11,7 @@
 
 #include "../../include/mbx.h"
 #include "../../include/mbx_layout.h"
+#include "mbx_math.hpp"
 
 namespace mbx {
 
@@ -19,11 +20,19 @@ namespace mbx {
 #else
 #define MBX_MATH __device__ __forceinline__
 #endif
+#ifdef MBX_LIBM_MATH
 MBX_MATH double m_pow(double a, double b) { return pow(a, b); }
 MBX_MATH double m_sin(double a) { return sin(a); }
 MBX_MATH double m_cos(double a) { return cos(a); }
 MBX_MATH double m_exp(double a) { return exp(a); }
 MBX_MATH double m_log(double a) { return log(a); }
+#else                                   // range-specialised routines of mbx_math.hpp (library fall-through outside their ranges)
+MBX_MATH double m_pow(double a, double b) { return fm::pow_fast(a, b); }
+MBX_MATH double m_sin(double a) { return fm::sincos_fast<false>(a); }
+MBX_MATH double m_cos(double a) { return fm::sincos_fast<true>(a); }
+MBX_MATH double m_exp(double a) { return fm::exp_fast(a); }
+MBX_MATH double m_log(double a) { return fm::log_fast(a); }
+#endif
 
 
 constexpr int kThreads = 256;          // 4 waves of 64
@@ -164,14 +173,21 @@ __device__ __forceinline__ void block_argmin(const double* a, int n, double* red
 // The reference's exp(t) ** 0.1 is evaluated as exp(0.1 t): the same real number, one transcendental instead of two
 // (a general pow is the most expensive libm call on this path); |t| <= ~750 so the re-association costs < 1e-13
 // relative, eight orders of magnitude inside the 1e-5 contract (tests pin it at 1e-10 against the reference's KATs).
+// L / 0.1 as the reference writes it (0.1 is not 1/10): one Newton correction of L * fl(1 / 0.1) instead of a full fp64 division
+__device__ __forceinline__ double div_by_tenth(double L)
+{
+    const double q = L * 10.0;
+    return __builtin_fma(__builtin_fma(-0.1, q, L), 10.0, q);
+}
+
 __device__ __forceinline__ double osc1(double x)
 {
     if (x > 0.) {
-        const double y = m_log(x) / 0.1;
+        const double y = div_by_tenth(m_log(x));
         return m_exp(0.1 * (y + 0.49 * (m_sin(y) + m_sin(0.79 * y))));
     }
     if (x < 0.) {
-        const double y = m_log(-x) / 0.1;
+        const double y = div_by_tenth(m_log(-x));
         return -m_exp(0.1 * (y + 0.49 * (m_sin(0.55 * y) + m_sin(0.31 * y))));
     }
     return x;

@@ -99,3 +99,57 @@ def test_abi_rejects_bad_arguments():
     assert lib.mbx_state_dim(C.byref(cfg)) == -3 and b'not implemented' in lib.mbx_last_error()
     cfg = _abi.AlgoCfg(1, 1000, 10, 20000, 400, 50, 1, 5)    # population larger than a workgroup
     assert lib.mbx_action_dim(C.byref(cfg)) == -1
+
+
+def _ulp_err(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    return np.abs(got - want) / np.spacing(np.abs(want))
+
+
+@pytest.mark.gpu
+def test_device_math_accuracy():
+    """The range-specialised log / exp / sin / cos / pow of mbx_math.hpp (and T_osz / T_asy built on them) against numpy's libm on
+    the argument ranges the objectives produce, in ulps; values outside the fast ranges fall through to the device library."""
+    import ctypes as C
+    import torch
+    from metabox_amd import _abi
+    lib = _abi.load_lib()
+    rs = np.random.RandomState(0)
+    N = 200_000
+
+    def run(op, x, y=None):
+        xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+        yd = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).cuda() if y is not None else None
+        out = torch.empty_like(xd)
+        _abi.check(lib.mbx_debug_math(op, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()) if yd is not None else C.c_void_p(),
+                                      C.c_void_p(out.data_ptr()), xd.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out.cpu().numpy()
+
+    x = np.concatenate([np.exp(rs.uniform(-40, 5, N)), 1 + rs.uniform(-1e-3, 1e-3, 1000), [1.0, 0.5, 2.0, 1e-300, 1e300, np.sqrt(2), np.sqrt(0.5)]])
+    assert _ulp_err(run(0, x), np.log(x)).max() <= 2.0
+    x = np.concatenate([rs.uniform(-700, 700, N), rs.uniform(-1, 1, N), [0.0, 1e-20, -1e-20, 700.0, -700.0]])
+    assert _ulp_err(run(1, x), np.exp(x)).max() <= 2.0
+    x = np.concatenate([rs.uniform(-400, 400, N), rs.uniform(-6e7, 6e7, N), rs.uniform(-1e-3, 1e-3, 1000), np.arange(-50, 50) * np.pi / 2])
+    for op, fn in ((2, np.sin), (3, np.cos)):
+        got, want = run(op, x), fn(x)
+        big = np.abs(want) > 1e-3                     # near the zeros the error is absolute: the reduction keeps 2^-53 of the argument
+        assert _ulp_err(got[big], want[big]).max() <= 4.0
+        assert np.abs(got - want).max() <= 4e-16
+    xs = np.array([1e8, -3e9, 1e15, np.inf, np.nan])                     # library fall-through
+    got = run(2, xs)
+    assert np.allclose(got[:3], np.sin(xs[:3]), rtol=0, atol=1e-15) and np.isnan(got[3:]).all()
+    x, y = np.exp(rs.uniform(-20, 6, N)), rs.uniform(-3, 7, N)
+    err = _ulp_err(run(4, x, y), np.power(x, y))
+    assert (err <= 3.0 + np.abs(y * np.log(x))).all() and np.median(err) <= 1.0
+    assert np.array_equal(run(4, np.array([-2.0, 3.0, 9.0, -8.0, 0.0]), np.array([2.0, 2.0, 0.5, 3.0, 2.5])), np.array([4.0, 9.0, 3.0, -512.0, 0.0]))
+    # T_osz / T_asy as the reference writes them (bbob.py:51-82)
+    x = np.concatenate([rs.uniform(-10, 10, N), rs.uniform(-1e-6, 1e-6, 1000), [0.0]])
+    xh = np.where(x != 0, np.log(np.abs(np.where(x != 0, x, 1.0))) / 0.1, 0.0)
+    want = np.where(x > 0, np.exp(xh + 0.49 * (np.sin(xh) + np.sin(0.79 * xh))) ** 0.1,
+                    np.where(x < 0, -np.exp(xh + 0.49 * (np.sin(0.55 * xh) + np.sin(0.31 * xh))) ** 0.1, 0.0))
+    got = run(5, x)
+    assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want)) and got[-1] == 0.0
+    x, beta = rs.uniform(-5, 30, N), rs.uniform(0, 0.5, N)
+    want = np.where(x > 0, np.power(np.abs(x), 1 + beta * np.sqrt(np.abs(x))), x)
+    got = run(6, x, beta)
+    assert np.all(np.abs(got - want) <= 1e-13 * np.abs(want))
