@@ -190,7 +190,7 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
     const int NP = c.NP, D = c.D;
     const int i = c.ORDER[rk], e0 = i * D + d0, es0 = rk * D + d0;
     const double r1 = L.R1[i], r2 = L.R2[i], fi = L.PBC[i], pci = c.bp.pci[i];
-    double uc[W], uf[W], cur[W], pp[W], v_clpso[W];
+    double uc[W], uf[W], cur[W], vel[W], pp[W], v_clpso[W];
     int t1[W], t2[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) {
@@ -204,11 +204,12 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
             t1[q] = (int)__umulhi(w.z, (uint32_t)NP); t2[q] = (int)__umulhi(w.w, (uint32_t)NP);
             w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf[q] = u53(w.x, w.y);
         }
-        cur[q] = L.X[e]; pp[q] = L.PB[es0 + q];
+        // position and velocity come straight from HBM: the loads are issued here and first used after the FDR scan below, which
+        // hides their latency (they are no longer staged through LDS by the prologue)
+        cur[q] = c.gPos[e]; vel[q] = c.gVel[e]; pp[q] = L.PB[es0 + q];
         // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
         const int tw = L.PBC[t2[q]] < L.PBC[t1[q]] ? t2[q] : t1[q];
-        const double exemplar = uc[q] > pci ? pp[q] : L.PB[c.RANK[tw] * D + d0 + q];
-        v_clpso[q] = uc[q] * (exemplar - cur[q]);
+        v_clpso[q] = uc[q] > pci ? pp[q] : L.PB[c.RANK[tw] * D + d0 + q];      // the exemplar; turned into the velocity term below
     }
     // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109).
     //  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
@@ -250,7 +251,8 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
         const double v_fdr = uf[q] * (L.PB[kb[q] * D + d] - pp[q]);
         const double v_pbest = r1 * (pp[q] - cur[q]);
         const double v_gbest = r2 * (L.GB[d] - cur[q]);
-        double nv = cw * L.Z[e] + c1 * v_clpso[q] + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
+        const double v_cl = uc[q] * (v_clpso[q] - cur[q]);
+        double nv = cw * vel[q] + c1 * v_cl + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
         nv = fmin(fmax(nv, -c.vmax), c.vmax);
         double np_ = cur[q] + nv;
         np_ = fmin(fmax(np_, c.lb), c.ub);
@@ -364,9 +366,6 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         ACT[tid] = a;
         if (actions_out) actions_out[(int64_t)b * A + tid] = a;
     }
-    // positions and velocities are parked in X / Z (both free until the new positions / the evaluation need them): every HBM
-    // read of the generation is issued up front, coalesced, and overlaps the ranking below
-    for (int e = tid; e < NE; e += kThreads) { L.X[e] = gPos[e]; L.Z[e] = gVel[e]; }
     for (int i = tid; i < NP; i += kThreads) {
         L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
         L.RANK[i] = 0; L.MASK[i] = 0;
