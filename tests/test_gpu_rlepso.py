@@ -400,3 +400,43 @@ def test_end_to_end_statistics_match_the_reference():
                 assert sps.mannwhitneyu(fes[k], rf).pvalue > 1e-3, f
             else:
                 assert fes[k].min() >= 20000 and fes[k].max() < 20200
+
+
+@pytest.mark.parametrize('dim', [5, 7])
+def test_odd_dimension_single_coordinate_work_items(dim):
+    """Odd D takes the one-coordinate work-item path of the move phase (even D pairs coordinates): HIP == oracle under Philox for
+    RLEPSO, and the other generation kernels run at the same dimension."""
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_GLEET, ALGO_LDE, ALGO_RLEPSO
+    ps = problems('bbob', dim)
+    ids = [1, 3, 8, 15, 17, 21]
+    s = Suite([ps[i] for i in ids])
+    B, G = len(ids), 25
+    rs = np.random.RandomState(dim)
+    actions = rs.uniform(0, 1, size=(G, B, 35)).astype(np.float32)
+    seeds = np.arange(B, dtype=np.uint64) * 104729 + 5
+    maxfes, nlog = 2000 * dim, 50
+    batch = Batch(s, ALGO_RLEPSO, np.arange(B), seeds, NP, maxfes, maxfes // nlog, nlog)
+    batch.reset()
+    for g in range(G):
+        batch.step(torch.from_numpy(actions[g]).cuda())
+    cfg = oracle.make_cfg(ALGO_RLEPSO, NP, dim, maxfes, maxfes // nlog, nlog)
+    same = 0
+    for b in range(B):
+        o = oracle.RlepsoOracle(s.problems[b].desc(), s.problems[b].bias, cfg, seed=int(seeds[b]))
+        o.reset()
+        for g in range(G):
+            o.step(actions[g, b])
+        hip, ref = oracle.split_rlepso_state(batch.read_state(b), NP, dim, nlog), oracle.split_rlepso_state(o.state(), NP, dim, nlog)
+        assert close(hip['scalars'][:1], ref['scalars'][:1]), ids[b]
+        if hip['scalars'][1] == ref['scalars'][1]:
+            same += 1
+            assert close(hip['pbest'], ref['pbest']) and np.abs(hip['pos'] - ref['pos']).max() <= 1e-9, ids[b]
+    assert same >= B - 1
+    batch.close()
+    for algo, np_, adim in ((ALGO_LDE, 50, 100), (ALGO_GLEET, 100, 100)):
+        bt = Batch(s, algo, np.arange(B), seeds, np_, maxfes, maxfes // nlog, nlog)
+        st0 = bt.reset().clone()
+        st1, r, d = bt.step(torch.rand(B, adim, device='cuda'))
+        assert torch.isfinite(st1).all() and torch.isfinite(r).all() and not torch.equal(st0, st1)
+        bt.close()
