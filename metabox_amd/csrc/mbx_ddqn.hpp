@@ -332,13 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
     if (tid == 0) {
         int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
         double* cost = sc + MBX_NSCALAR;
-        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
-        bool done = fes >= bp.max_fes;
-        if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
-        if (done) {
-            if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
-            else cost[cost_len++] = gbest;
-        }
+        const bool done = log_and_terminate(bp, P, fes, gbest, log_index, cost_len, cost);
         ex[MBX_DQ_X_GWORST] = gworst; ex[MBX_DQ_X_POINTER] = pointer; ex[MBX_DQ_X_GEN] = gen; ex[MBX_DQ_X_STAG] = stag;
         ex[MBX_DQ_X_OMWLEN] = omw_len; ex[MBX_DQ_X_GBVIEW] = gb_view; ex[MBX_DQ_X_PREVIEW] = pre_view;
         sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;

@@ -230,15 +230,8 @@ __global__ __launch_bounds__(kThreads) void k_gleet_step(BatchParams bp, const f
     }
     if (tid == 0) {
         int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
-        double* cost = sc + MBX_NSCALAR;
-        bool done = fes >= bp.max_fes;
-        if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
+        const bool done = log_and_terminate(bp, P, fes, gbest, log_index, cost_len, sc + MBX_NSCALAR);
         const double reward = (pre_gbest - gbest) / max_cost * 100.;
-        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
-        if (done) {
-            if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
-            else cost[cost_len++] = gbest;
-        }
         sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
         sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += reward; sc[MBX_SC_GEN] = gen; sc[MBX_SC_GBEST_IDX] = gbest_idx;
         sc[MBX_SC_GLEET_W] = w; sc[MBX_SC_GLEET_NOIMPROVE] = no_improve;

@@ -252,15 +252,8 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
 
     if (tid == 0) {
         const double reward = (bsf - bsf_next) / bsf;             // :170
-        bool done = fes >= bp.max_fes;
-        if (!isnan(P.optimum) && bp.early_stop) done = done || bsf_next <= 1e-8;
         int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
-        double* cost = sc + MBX_NSCALAR;
-        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = bsf_next; }
-        if (done) {
-            if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = bsf_next;
-            else cost[cost_len++] = bsf_next;
-        }
+        const bool done = log_and_terminate(bp, P, fes, bsf_next, log_index, cost_len, sc + MBX_NSCALAR);
         sc[MBX_SC_GBEST] = bsf_next; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
         sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += reward; sc[MBX_SC_GEN] = gen; sc[MBX_SC_HCOUNT] = hcount + 1;
         if (reward_out) reward_out[b] = reward;

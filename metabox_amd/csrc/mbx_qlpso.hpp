@@ -251,13 +251,7 @@ __global__ __launch_bounds__(kThreads) void k_qlpso_step(BatchParams bp, const i
             const double fes = L.SC[MBX_SC_FES] + 1;
             int log_index = (int)L.SC[MBX_SC_LOG_INDEX], cost_len = (int)L.SC[MBX_SC_COST_LEN];
             double* cost = sc + MBX_NSCALAR;
-            if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
-            bool dn = fes >= bp.max_fes;
-            if (!isnan(P.optimum) && bp.early_stop) dn = dn || gbest <= 1e-8;
-            if (dn) {
-                if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
-                else cost[cost_len++] = gbest;
-            }
+            const bool dn = log_and_terminate(bp, P, fes, gbest, log_index, cost_len, cost);
             L.SC[MBX_SC_GBEST] = gbest; L.SC[MBX_SC_FES] = fes; L.SC[MBX_SC_LOG_INDEX] = log_index; L.SC[MBX_SC_COST_LEN] = cost_len;
             L.SC[MBX_SC_DONE] = dn ? 1. : 0.; L.SC[MBX_SC_RETURN] += reward; L.SC[MBX_SC_GEN] = step;
             L.SC[MBX_SC_QLPSO_DIVERSITY] = d_new; L.SC[MBX_SC_QLPSO_POINTER] = pointer;

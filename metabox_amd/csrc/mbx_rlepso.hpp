@@ -26,6 +26,22 @@ struct BatchParams {
     int64_t sc_off;              // offset of the scalar block inside an instance's state (per algorithm)
 };
 
+// optimizer.cost bookkeeping shared by every update() of the reference (e.g. rlepso_optimizer.py:241-261): append gbest when fes
+// reaches the next log point (one append per call at most), decide termination, and on termination overwrite the last entry if the
+// curve is already n_logpoint + 1 long, else append.  `cost` is the instance's curve in HBM; returns is_done.
+__device__ __forceinline__ bool log_and_terminate(const BatchParams& bp, const DevProblem& P, double fes, double gbest, int& log_index,
+                                                  int& cost_len, double* __restrict__ cost)
+{
+    if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
+    bool done = fes >= bp.max_fes;
+    if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
+    if (done) {
+        if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
+        else cost[cost_len++] = gbest;
+    }
+    return done;
+}
+
 // LDS carve-up (all offsets in doubles; base is 16-byte aligned, every array starts 16-byte aligned)
 struct RlLds {
     double *PB, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *PBC, *NC, *PNI, *CMUT, *R1, *R2, *GB, *COEF, *RED;
@@ -518,14 +534,8 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     if (tid == 0) {
         int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
         double* cost = sc + MBX_NSCALAR;
-        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
-        bool done = fes >= bp.max_fes;
-        if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
+        const bool done = log_and_terminate(bp, P, fes, gbest, log_index, cost_len, cost);
         const double reward = gbest < pre_gbest ? 1. : -1.;
-        if (done) {
-            if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
-            else cost[cost_len++] = gbest;
-        }
         sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
         sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += reward; sc[MBX_SC_GEN] = gen;
         sc[MBX_SC_GBEST_IDX] = gbest_idx; sc[MBX_SC_REINIT] = n_reinit > 0 ? 1. : 0.;

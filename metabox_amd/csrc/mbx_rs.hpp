@@ -68,13 +68,7 @@ __global__ __launch_bounds__(kThreads) void k_rs_population(BatchParams bp, int 
             const double fes = sc[MBX_SC_FES] + NP;
             if (gbest > m) gbest = m;
             int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
-            if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
-            bool done = fes >= bp.max_fes;
-            if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
-            if (done) {
-                if (cost_len >= bp.n_logpoint + 1) cost[cost_len - 1] = gbest;
-                else cost[cost_len++] = gbest;
-            }
+            const bool done = log_and_terminate(bp, P, fes, gbest, log_index, cost_len, cost);
             sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
             sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_GEN] = gen;
             if (state_out) state_out[b] = fes / bp.max_fes;
