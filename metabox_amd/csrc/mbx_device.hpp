@@ -610,4 +610,30 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
     __syncthreads();
 }
 
+
+// cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
+// rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
+// (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
+__device__ __forceinline__ void population_costs(const DevProblem& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
+                                                 uint32_t siteA, uint32_t siteB)
+{
+#ifdef MBX_ABLATE_EVAL
+    for (int i = threadIdx.x; i < n; i += kThreads) L.F[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
+    __syncthreads();
+#else
+    eval_rows(P, L, n);
+#endif
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        double f = L.F[i];
+        if (P.noise_kind != MBX_NOISE_NONE) {
+            double a, b, c;
+            if (tape_noise) { a = tape_noise[i]; b = tape_noise[n + i]; c = tape_noise[2 * n + i]; }
+            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, b, c);
+            f = apply_noise(P, f, a, b, c);
+        }
+        L.F[i] = isnan(P.optimum) ? f : f - P.optimum;
+    }
+    __syncthreads();
+}
+
 }  // namespace mbx

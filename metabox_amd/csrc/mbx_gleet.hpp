@@ -59,24 +59,6 @@ __device__ __forceinline__ void gl_features(const double* x, const double* pb, c
     f[8] = isnan(c8) ? 0. : c8;
 }
 
-// Costs of the NP rows in L.X -> L.NC (noise applied, optimum subtracted).  All threads call.
-__device__ __forceinline__ void gl_costs(const DevProblem& P, const GlLds& L, int NP, const Rng& rng, const double* tape_noise,
-                                         uint32_t siteA, uint32_t siteB)
-{
-    eval_rows(P, L.eval(), NP);
-    for (int i = threadIdx.x; i < NP; i += kThreads) {
-        double f = L.NC[i];
-        if (P.noise_kind != MBX_NOISE_NONE) {
-            double a, bb, c;
-            if (tape_noise) { a = tape_noise[i]; bb = tape_noise[NP + i]; c = tape_noise[2 * NP + i]; }
-            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, bb, c);
-            f = apply_noise(P, f, a, bb, c);
-        }
-        L.NC[i] = isnan(P.optimum) ? f : f - P.optimum;
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------ reset (init_population :80-112)
 __global__ __launch_bounds__(kThreads) void k_gleet_reset(BatchParams bp, double* __restrict__ state_out)
 {
@@ -104,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void k_gleet_reset(BatchParams bp, double
         S[MBX_GLEET_ST_VEL(NP, D) + e] = -vmax + (vmax - (-vmax)) * uv;
     }
     __syncthreads();
-    gl_costs(P, L, NP, rng, tape ? tape + MBX_GLEET_TAPE_NOISE_INIT(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_GLEET_TAPE_NOISE_INIT(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
     double gb; int g0;
     block_argmin(L.NC, NP, L.RED, gb, g0);
     if (tid < D) { L.GB[tid] = L.X[g0 * D + tid]; S[MBX_GLEET_ST_GBPOS(NP, D) + tid] = L.X[g0 * D + tid]; }
@@ -186,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_gleet_step(BatchParams bp, const f
         gVel[e] = nv; gPos[e] = nx; L.X[e] = nx;
     }
     __syncthreads();
-    gl_costs(P, L, NP, rng, tape ? tape + MBX_GLEET_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_GLEET_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
 
     // ---- pbest / stagnation per particle (:236-266); thread i owns particle i
     double ccost = 0., pbest = 0., pni = 0.;

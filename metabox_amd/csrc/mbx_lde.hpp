@@ -72,23 +72,6 @@ __device__ __forceinline__ void lde_norm_hist(const double* F, int NP, double* N
     __syncthreads();
 }
 
-__device__ __forceinline__ void lde_costs(const DevProblem& P, const LdeLds& L, int NP, const Rng& rng, const double* tape_noise,
-                                          uint32_t siteA, uint32_t siteB)
-{
-    eval_rows(P, L.eval(), NP);
-    for (int i = threadIdx.x; i < NP; i += kThreads) {
-        double f = L.NC[i];
-        if (P.noise_kind != MBX_NOISE_NONE) {
-            double a, b, c;
-            if (tape_noise) { a = tape_noise[i]; b = tape_noise[NP + i]; c = tape_noise[2 * NP + i]; }
-            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, b, c);
-            f = apply_noise(P, f, a, b, c);
-        }
-        L.NC[i] = isnan(P.optimum) ? f : f - P.optimum;
-    }
-    __syncthreads();
-}
-
 // __order_by_f (stable) + __get_feature (lde_optimizer.py:74-79,145-157): rows of L.P with fitness L.FIT are written
 // to HBM in ascending-fitness order and the [NP+10] state vector is emitted.  hs/hcount = past_histo sum / length.
 __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, double* gPop, double* gFit, const double* hs,
@@ -141,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* 
         L.X[e] = x; L.P[e] = x;
     }
     __syncthreads();
-    lde_costs(P, L, NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
     for (int i = tid; i < NP; i += kThreads) L.FIT[i] = L.NC[i];
     if (tid < 8) { L.HS[tid] = tid < MBX_LDE_BINS ? (double)NP / MBX_LDE_BINS : 0.; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
     double gb; int gi;
@@ -232,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
         L.X[e] = c;
     }
     __syncthreads();
-    lde_costs(P, L, NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
 
     // ---- selection (:55-59): offspring survives when it is better than or equal to its parent

@@ -91,29 +91,6 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
     return L;
 }
 
-// cost_i = problem.eval(x_i) [- optimum]   (__get_costs, rlepso_optimizer.py:68-74), noise from tape or Philox
-__device__ __forceinline__ void rl_costs(const DevProblem& P, const RlLds& L, int NP, const Rng& rng, const double* tape_noise,
-                                         uint32_t siteA, uint32_t siteB)
-{
-#ifdef MBX_ABLATE_EVAL
-    for (int i = threadIdx.x; i < NP; i += kThreads) L.NC[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
-    __syncthreads();
-#else
-    eval_rows(P, L.eval(), NP);
-#endif
-    for (int i = threadIdx.x; i < NP; i += kThreads) {
-        double f = L.NC[i];
-        if (P.noise_kind != MBX_NOISE_NONE) {
-            double a, b, c;
-            if (tape_noise) { a = tape_noise[i]; b = tape_noise[NP + i]; c = tape_noise[2 * NP + i]; }
-            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, b, c);
-            f = apply_noise(P, f, a, b, c);
-        }
-        L.NC[i] = isnan(P.optimum) ? f : f - P.optimum;
-    }
-    __syncthreads();
-}
-
 // pbest / gbest bookkeeping shared by update() and __reinit() (rlepso_optimizer.py:200-222, 145-168).
 // Candidate positions are in L.X, their costs in L.NC.  `stagnation` additionally updates per_no_improve
 // against the previous c_cost (:225-233), which only update() does.
@@ -309,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
         S[MBX_RLEPSO_ST_VEL(NP, D) + e] = -vmax + (vmax - (-vmax)) * uv;
     }
     __syncthreads();
-    rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
     double gb; int gi;
     block_argmin(L.NC, NP, L.RED, gb, gi);
     for (int i = tid; i < NP; i += kThreads) {
@@ -484,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     MBX_PHASE(3);                                                 // move (draws, exemplars, FDR scan, velocity)
 
     // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
-    rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     MBX_PHASE(4);                                                 // evaluation
     fes += NP;
     rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
@@ -517,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         }
         __syncthreads();
         // the whole population is re-evaluated but only the re-initialised particles are billed (:141-143)
-        rl_costs(P, L, NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+        population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
         fes += n_reinit;
         rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
     }
