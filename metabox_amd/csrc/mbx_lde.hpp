@@ -12,7 +12,7 @@
 namespace mbx {
 
 struct LdeLds {
-    double *P, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *FIT, *NC, *SF, *CR, *ONEM, *SORTED, *RED, *HS;
+    double *P, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *FIT, *NC, *SF, *CR, *SORTED, *RED, *HS;
     int *PIDX, *R0, *R1, *JR, *HIST;
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
@@ -21,7 +21,8 @@ __host__ __device__ inline int64_t lde_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP), PI = align2((P + 1) / 2);
-    return 2 * NE + eval_t_doubles(NP, D) + SC + 2 * DD + 4 * align2(D) + 6 * P + 16 + 8 + 4 * PI + 8;
+    const int64_t TS = eval_t_doubles(NP, D), PT = NE > TS ? NE : TS;     // parents and the evaluator's scratch T share storage
+    return NE + PT + SC + 2 * DD + 4 * align2(D) + 4 * P + 16 + 8 + 4 * PI + 8;
 }
 
 __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
@@ -30,10 +31,15 @@ __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
                   P = align2(NP), PI = align2((P + 1) / 2);
     LdeLds L;
     double* p = base;
-    L.P = p; p += NE;  L.X = p; p += NE;  L.T = p; p += eval_t_doubles(NP, D);  L.Z = p; p += SC;
+    const int64_t TS = eval_t_doubles(NP, D);
+    // P (the parents) is dead between the mutation and the selection, exactly while the evaluator needs its scratch T: they share
+    // storage and the unchanged parents are re-read from HBM after the evaluation (12 KB less LDS at NP = 50, D = 30: three resident
+    // workgroups per CU instead of two).
+    L.P = p; L.T = p; p += NE > TS ? NE : TS;  L.X = p; p += NE;  L.Z = p; p += SC;
     L.M1T = p; p += DD;  L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
-    L.FIT = p; p += P;  L.NC = p; p += P;  L.SF = p; p += P;  L.CR = p; p += P;  L.ONEM = p; p += P;  L.SORTED = p; p += P;
+    L.FIT = p; p += P;  L.NC = p; p += P;  L.SF = p; p += P;  L.CR = p; p += P;
+    L.SORTED = L.NC;                                             // the trials' costs are dead once the selection is done
     L.RED = p; p += 16;  L.HS = p; p += 8;
     L.PIDX = (int*)p; p += PI;  L.R0 = (int*)p; p += PI;  L.R1 = (int*)p; p += PI;  L.JR = (int*)p; p += PI;
     L.HIST = (int*)p;
@@ -121,10 +127,11 @@ __global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* 
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
         else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
         const double x = lb + u * (ub - lb);
-        L.X[e] = x; L.P[e] = x;
+        L.X[e] = x;
     }
     __syncthreads();
     population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    for (int e = tid; e < NE; e += kThreads) L.P[e] = L.X[e];      // T is free again: the population moves into P for the sort
     for (int i = tid; i < NP; i += kThreads) L.FIT[i] = L.NC[i];
     if (tid < 8) { L.HS[tid] = tid < MBX_LDE_BINS ? (double)NP / MBX_LDE_BINS : 0.; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
     double gb; int gi;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
         }
         L.PIDX[i] = pidx; L.R0[i] = r0; L.R1[i] = r1; L.JR[i] = jr;
         const float sf32 = act[i];
-        L.SF[i] = (double)sf32; L.ONEM[i] = (double)(1.f - sf32); L.CR[i] = (double)act[NP + i];
+        L.SF[i] = (double)sf32; L.CR[i] = (double)act[NP + i];
     }
     __syncthreads();
     // histogram of the pre-update (sorted) fitness: appended to past_histo at :186
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
         else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
         if (d == L.JR[i]) u = 0.;
-        const double xi = L.P[e], sf = L.SF[i], om = L.ONEM[i];
+        const double xi = L.P[e], sf = L.SF[i], om = (double)(1.f - (float)sf);      // 1 - sf in float32, like the policy's tensor
         const int pidx = L.PIDX[i];
         double m;
         if (pidx == i) m = xi;
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
         if (surv) L.FIT[i] = L.NC[i];
     }
     __syncthreads();
-    for (int e = tid; e < NE; e += kThreads) if (L.R0[fd.div(e)]) L.P[e] = L.X[e];
+    // survivors take the trial vector; the other rows are re-read from HBM (P's storage served as evaluator scratch meanwhile)
+    for (int e = tid; e < NE; e += kThreads) L.P[e] = L.R0[fd.div(e)] ? L.X[e] : gPop[e];
     double bsf_next; int bi;
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
     if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
