@@ -99,6 +99,9 @@ int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f,
 #define MBX_ALGO_RLPSO  5   /* src/optimizer/rl_pso_optimizer.py   one step = one particle         */
 #define MBX_ALGO_GLEET  6   /* src/optimizer/gleet_optimizer.py    one step = one generation       */
 #define MBX_ALGO_QLPSO  7   /* src/optimizer/qlpso_optimizer.py    one step = one particle         */
+#define MBX_ALGO_DE     8   /* src/optimizer/deap_de.py            one step = one sweep (np trials)   -- classic baseline, no agent */
+#define MBX_ALGO_PSO    9   /* src/optimizer/deap_pso.py           one step = one sweep (np moves)    -- classic baseline, no agent */
+#define MBX_ALGO_CMAES  10  /* src/optimizer/deap_cmaes.py         one step = one generation          -- classic baseline, no agent */
 
 typedef struct mbx_algo_cfg {
     int32_t algo;          /* MBX_ALGO_*                                                          */
@@ -119,7 +122,8 @@ typedef struct mbx_algo_cfg {
  *   RANDOM_SEARCH : state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step)
  *   RLPSO         : state [2*dim]  (rl_pso_optimizer.py:62-63),             action [1] float32
  *   GLEET         : state [np*27]  (gleet_optimizer.py:111-124),            action [np] float32
- *   QLPSO         : state [1]      (qlpso_optimizer.py:89-90,125),          action [1] int32 in {0..3} */
+ *   QLPSO         : state [1]      (qlpso_optimizer.py:89-90,125),          action [1] int32 in {0..3}
+ *   DE, PSO, CMAES: state [1]      (fes/maxFEs),                             no action (pass NULL to mbx_step) */
 int mbx_state_dim(const mbx_algo_cfg* cfg);
 int mbx_action_dim(const mbx_algo_cfg* cfg);
 /* number of doubles of external random numbers one instance consumes per step (see mbx_set_tape) */

@@ -270,6 +270,48 @@
 #define MBX_SC_QLPSO_DIVERSITY 10
 #define MBX_SC_QLPSO_POINTER   11
 
+/* ---------------------------------------------------------------- 10. classic baselines (deap_de.py, deap_pso.py, deap_cmaes.py)
+ * No agent: mbx_reset builds and evaluates the initial population, every mbx_step (actions = NULL) is one sweep over the
+ * population (DE, PSO: NP sequential single-individual updates, each billed 1 FE and checked for logging / termination like the
+ * reference's inner loop) or one generation (CMA-ES).  state [1] = fes / maxFEs.  DEAP itself (deap==1.3.3, requirements.txt:7) is
+ * not part of the reference tree: DE and PSO are fully written out in the reference's wrappers, CMA-ES follows deap.cma.Strategy's
+ * published algorithm.  There are no reference traces for these (parity unpinned); no replay tape either.
+ * DE   (deap_de.py:8-82, NP 50, F 0.5, Cr 0.5, selTournament(k=3, tournsize=3) donors):
+ *      state block: X[NP*D] cost[NP] scalars[16] cost_curve[nlog+1].
+ *      Philox, reset (gen 0): MBX_SITE_LDE_ELEM(e) -> position; noise MBX_SITE_NOISE1_A/B(i).
+ *      sweep (gen = sweep number): MBX_SITE_CLASSIC(3k+j), j = 0..2: mulhi(w0..w2, NP) = the three aspirants of donor j,
+ *      w3 of j = 0: mulhi(w3, D) = forced crossover index; MBX_SITE_LDE_ELEM(k*D+i) -> crossover uniform; noise MBX_SITE_NOISE0_A/B(k).
+ * PSO  (deap_pso.py:8-122, 50 particles, phi1 = phi2 = 2, speed in +-ub/2, gbest updated inside the sweep):
+ *      state block: X[NP*D] speed[NP*D] pbest_pos[NP*D] pbest[NP] gbest_pos[D] scalars[16] cost_curve[nlog+1].
+ *      Philox, reset: MBX_SITE_ELEM_R(e): u53(w0,w1) -> position, u53(w2,w3) -> speed; noise MBX_SITE_NOISE1_A/B(i).
+ *      sweep: MBX_SITE_ELEM_A(k*D+i): u53(w0,w1) -> u1, u53(w2,w3) -> u2; noise MBX_SITE_NOISE0_A/B(k).
+ * CMAES (deap_cmaes.py:12-66 + deap.cma.Strategy, lambda 50, centroid = ub, sigma 0.5):
+ *      state block: centroid[D] C[D*D] B[D*D] diagD[D] ps[D] pc[D] scalars[16] cost_curve[nlog+1]; scalars: sigma, update_count.
+ *      Philox, generation g >= 1: MBX_SITE_ELEM_A(i*D+d): Box-Muller(u53(w0,w1), u53(w2,w3)) first normal -> arz[i][d];
+ *      noise MBX_SITE_NOISE0_A/B(i).                                                                                            */
+#define MBX_SITE_CLASSIC     16u
+#define MBX_DE_ST_X(NP, D)          ((int64_t)0)
+#define MBX_DE_ST_COST(NP, D)       ((int64_t)(NP) * (D))
+#define MBX_DE_ST_SCALARS(NP, D)    ((int64_t)(NP) * (D) + (NP))
+#define MBX_DE_STATE_DOUBLES(NP, D, NLOG) (MBX_DE_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_PSO_ST_X(NP, D)         ((int64_t)0)
+#define MBX_PSO_ST_SPEED(NP, D)     ((int64_t)(NP) * (D))
+#define MBX_PSO_ST_PBPOS(NP, D)     (2 * (int64_t)(NP) * (D))
+#define MBX_PSO_ST_PBEST(NP, D)     (3 * (int64_t)(NP) * (D))
+#define MBX_PSO_ST_GBPOS(NP, D)     (3 * (int64_t)(NP) * (D) + (NP))
+#define MBX_PSO_ST_SCALARS(NP, D)   (3 * (int64_t)(NP) * (D) + (NP) + (D))
+#define MBX_PSO_STATE_DOUBLES(NP, D, NLOG) (MBX_PSO_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_CMA_ST_CENTROID(NP, D)  ((int64_t)0)
+#define MBX_CMA_ST_C(NP, D)         ((int64_t)(D))
+#define MBX_CMA_ST_B(NP, D)         ((int64_t)(D) + (int64_t)(D) * (D))
+#define MBX_CMA_ST_DIAGD(NP, D)     ((int64_t)(D) + 2 * (int64_t)(D) * (D))
+#define MBX_CMA_ST_PS(NP, D)        (2 * (int64_t)(D) + 2 * (int64_t)(D) * (D))
+#define MBX_CMA_ST_PC(NP, D)        (3 * (int64_t)(D) + 2 * (int64_t)(D) * (D))
+#define MBX_CMA_ST_SCALARS(NP, D)   (4 * (int64_t)(D) + 2 * (int64_t)(D) * (D))
+#define MBX_CMA_STATE_DOUBLES(NP, D, NLOG) (MBX_CMA_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
+#define MBX_SC_CMA_SIGMA   10
+#define MBX_SC_CMA_UPDATES 11
+
 #define MBX_PHILOX_M0 0xD2511F53u
 #define MBX_PHILOX_M1 0xCD9E8D57u
 #define MBX_PHILOX_W0 0x9E3779B9u

@@ -44,7 +44,7 @@ class GleetActor(C.Structure):
     _fields_ = [('d_weights', C.c_void_p), ('n_floats', C.c_int32), ('min_sigma', C.c_float), ('max_sigma', C.c_float)]
 
 
-ALGO_RLEPSO, ALGO_LDE, ALGO_DEDDQN, ALGO_RANDOM_SEARCH, ALGO_RLPSO, ALGO_GLEET, ALGO_QLPSO = 1, 2, 3, 4, 5, 6, 7
+ALGO_RLEPSO, ALGO_LDE, ALGO_DEDDQN, ALGO_RANDOM_SEARCH, ALGO_RLPSO, ALGO_GLEET, ALGO_QLPSO, ALGO_DE, ALGO_PSO, ALGO_CMAES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 POLICY_RLEPSO, POLICY_RLPSO = 0, 1
 _ARRAY_FIELDS = ('dshift', 'm1', 'm2', 'v0', 'v1', 'v2', 'py', 'pc', 'pw')
 

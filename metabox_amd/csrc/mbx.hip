@@ -21,6 +21,7 @@
 #include "mbx_gleet.hpp"
 #include "mbx_qlpso.hpp"
 #include "mbx_gleet_policy.hpp"
+#include "mbx_classic.hpp"
 
 using namespace mbx;
 
@@ -118,6 +119,13 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_QLPSO_TAPE_STRIDE(c.np, c.dim);
         g.lds_doubles = ql_lds_doubles(c.np, c.np, c.dim);
         g.state_dim = 1; g.action_dim = 1;
+    } else if (c.algo == MBX_ALGO_DE || c.algo == MBX_ALGO_PSO || c.algo == MBX_ALGO_CMAES) {
+        g.state_doubles = c.algo == MBX_ALGO_DE ? MBX_DE_STATE_DOUBLES(c.np, c.dim, c.n_logpoint)
+                        : c.algo == MBX_ALGO_PSO ? MBX_PSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint) : MBX_CMA_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
+        g.sc_off = c.algo == MBX_ALGO_DE ? MBX_DE_ST_SCALARS(c.np, c.dim) : c.algo == MBX_ALGO_PSO ? MBX_PSO_ST_SCALARS(c.np, c.dim) : MBX_CMA_ST_SCALARS(c.np, c.dim);
+        g.tape_stride = 0;
+        g.lds_doubles = cl_lds_doubles(c.np, c.np, c.dim, 0, c.algo == MBX_ALGO_CMAES);       // the largest carve-up of the family
+        g.state_dim = 1; g.action_dim = 0;
     }
     return g;
 }
@@ -346,7 +354,7 @@ extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, dou
 static int check_cfg(const mbx_algo_cfg* c)
 {
     if (!c) return fail(MBX_E_ARG, "null cfg");
-    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_QLPSO)
+    if (c->algo < MBX_ALGO_RLEPSO || c->algo > MBX_ALGO_CMAES)
         return fail(MBX_E_UNSUPPORTED, "algo %d is not implemented in this build", c->algo);
     if (c->np < 4 || c->np > kThreads) return fail(MBX_E_ARG, "np %d outside [4, %d]", c->np, kThreads);
     if (c->dim < 2 || c->dim > 64) return fail(MBX_E_ARG, "dim %d outside [2, 64]", c->dim);
@@ -435,6 +443,11 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (cfg->algo == MBX_ALGO_DE || cfg->algo == MBX_ALGO_PSO || cfg->algo == MBX_ALGO_CMAES) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_classic_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_de_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_pso_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_cmaes_generation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_QLPSO) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_qlpso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_qlpso_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -490,6 +503,9 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
         hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
         hipLaunchKernelGGL(k_rlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+    else if (b->cfg.algo == MBX_ALGO_DE || b->cfg.algo == MBX_ALGO_PSO || b->cfg.algo == MBX_ALGO_CMAES)
+        hipLaunchKernelGGL(k_classic_reset, dim3(b->B), dim3(kThreads), (size_t)cl_lds_doubles(b->cfg.np, b->cfg.np, b->cfg.dim, 0, 0) * sizeof(double),
+                           (hipStream_t)stream, make_params(b), (int)b->cfg.algo, d_state_out);
     else if (b->cfg.algo == MBX_ALGO_QLPSO)
         hipLaunchKernelGGL(k_qlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_GLEET)
@@ -508,13 +524,24 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
 extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out, uint8_t* d_done_out,
                         void* stream)
 {
-    if (!b || (!d_actions && b->cfg.algo != MBX_ALGO_RANDOM_SEARCH)) return fail(MBX_E_ARG, "mbx_step: bad arguments");
+    const bool no_agent = b && (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH || b->cfg.algo == MBX_ALGO_DE || b->cfg.algo == MBX_ALGO_PSO ||
+                                b->cfg.algo == MBX_ALGO_CMAES);
+    if (!b || (!d_actions && !no_agent)) return fail(MBX_E_ARG, "mbx_step: bad arguments");
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 0, d_state_out,
                            d_reward_out, d_done_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
         hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_DE)
+        hipLaunchKernelGGL(k_de_sweep, dim3(b->B), dim3(kThreads), (size_t)cl_lds_doubles(1, b->cfg.np, b->cfg.dim, 1, 0) * sizeof(double),
+                           (hipStream_t)stream, make_params(b), d_state_out, d_reward_out, d_done_out);
+    else if (b->cfg.algo == MBX_ALGO_PSO)
+        hipLaunchKernelGGL(k_pso_sweep, dim3(b->B), dim3(kThreads), (size_t)cl_lds_doubles(1, b->cfg.np, b->cfg.dim, 0, 0) * sizeof(double),
+                           (hipStream_t)stream, make_params(b), d_state_out, d_reward_out, d_done_out);
+    else if (b->cfg.algo == MBX_ALGO_CMAES)
+        hipLaunchKernelGGL(k_cmaes_generation, dim3(b->B), dim3(kThreads), (size_t)cl_lds_doubles(b->cfg.np, b->cfg.np, b->cfg.dim, 0, 1) * sizeof(double),
+                           (hipStream_t)stream, make_params(b), d_state_out, d_reward_out, d_done_out);
     else if (b->cfg.algo == MBX_ALGO_QLPSO)
         hipLaunchKernelGGL(k_qlpso_step<false>, dim3(b->B), dim3(kThreads), (size_t)ql_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double),
                            (hipStream_t)stream, make_params(b), (const int32_t*)d_actions, (const double*)nullptr, 1, d_state_out,

@@ -7,3 +7,4 @@ from .random_search import Random_search
 from .rl_pso_optimizer import RL_PSO_Optimizer
 from .gleet_optimizer import GLEET_Optimizer
 from .qlpso_optimizer import QLPSO_Optimizer
+from .classic import DEAP_CMAES, DEAP_DE, DEAP_PSO

@@ -137,7 +137,7 @@ class Tester(object):
             if hasattr(_optimizers, n):
                 self.t_optimizer_for_cp.append(getattr(_optimizers, n)(copy.deepcopy(config)))
             else:
-                self.skipped.append(n)      # DEAP_* / Bayesian / ...: arithmetic lives in un-vendored packages (parity unpinned)
+                self.skipped.append(n)      # BayesianOptimizer (scikit-optimize), ...: not built
         if config.agent is not None:
             with open(config.agent_load_dir + config.agent + '.pkl', 'rb') as f:
                 self.agent_for_cp.append(pickle.load(f))

@@ -701,3 +701,51 @@ class QlpsoTapeFeeder:
         t[2:5] = self._noise(1).ravel()
         t[5] = choice_u
         return t
+
+
+# ======================================================================================== classic baselines (DE / PSO / CMA-ES)
+def _classic_lib():
+    L = lib()
+    if not getattr(L, '_classic_ready', False):
+        L.orc_classic_new.restype = C.c_void_p
+        L.orc_classic_new.argtypes = [C.POINTER(ProblemDesc), C.c_double, C.POINTER(AlgoCfg), C.c_uint64]
+        L.orc_classic_free.argtypes = [C.c_void_p]
+        L.orc_classic_reset.argtypes = [C.c_void_p]
+        L.orc_classic_step.restype = C.c_int
+        L.orc_classic_step.argtypes = [C.c_void_p]
+        L.orc_classic_result.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_int), _dp, _dp]
+        L.orc_classic_population.argtypes = [C.c_void_p, _dp, _dp]
+        L._classic_ready = True
+    return L
+
+
+class ClassicOracle:
+    """DEAP_DE (algo 8) / DEAP_PSO (9) / DEAP_CMAES (10) on the CPU, Philox draws only (no reference traces exist for these)."""
+
+    def __init__(self, desc, optimum, cfg, seed=0):
+        self._st, self._keep = pack_desc(desc)
+        self.cfg = cfg
+        self._h = _classic_lib().orc_classic_new(C.byref(self._st), float('nan') if optimum is None else float(optimum), C.byref(cfg),
+                                                 int(seed))
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            _classic_lib().orc_classic_free(self._h)
+            self._h = None
+
+    def reset(self):
+        _classic_lib().orc_classic_reset(self._h)
+
+    def step(self):
+        return bool(_classic_lib().orc_classic_step(self._h))
+
+    def result(self):
+        cost = np.empty(self.cfg.n_logpoint + 1)
+        fes, gb, sg, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _classic_lib().orc_classic_result(self._h, _p(cost), C.byref(fes), C.byref(n), C.byref(gb), C.byref(sg))
+        return {'cost': cost, 'fes': fes.value, 'cost_len': n.value, 'gbest': gb.value, 'sigma': sg.value}
+
+    def population(self):
+        X, c = np.empty((self.cfg.np, self.cfg.dim)), np.empty(self.cfg.np)
+        _classic_lib().orc_classic_population(self._h, _p(X), _p(c))
+        return X, c

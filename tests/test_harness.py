@@ -136,9 +136,9 @@ def test_tester_and_rollout_write_reference_schema(tmp_path):
     for cp in (0, 1):
         save_class(load_dir + 'RLEPSO_Agent/', f'checkpoint{cp}', agent)
     tester = Tester(cfg)
-    assert tester.skipped == ['DEAP_CMAES']            # always appended by get_config; un-vendored => not run
+    assert tester.skipped == []                        # DEAP_CMAES (always appended by get_config) runs as a batched kernel
     res = tester.test()
-    names = {'RLEPSO_Agent', 'Random_search'}
+    names = {'RLEPSO_Agent', 'Random_search', 'DEAP_CMAES'}
     assert set(res['T1']) == names and set(res['T2']) == names and res['T0'] > 0
     test_names = ['Sphere', 'Linear_Slope', 'Attractive_Sector', 'Ellipsoidal_high_cond', 'Rastrigin_F15', 'Schwefel']
     assert list(res['cost']) == test_names                                    # bbob-easy test split
@@ -280,7 +280,7 @@ def test_cli_entry_point_test_mode(tmp_path):
                 '--agent_for_cp', 'LDE_Agent', 'DE_DDQN_Agent', '--l_optimizer_for_cp', 'LDE_Optimizer', 'DE_DDQN_Optimizer'])
     assert len(res['cost']) == 210                                       # protein-difficult test split: 21 complexes x 10 models
     one = res['cost'][next(iter(res['cost']))]
-    assert set(one) == {'LDE_Agent', 'DE_DDQN_Agent', 'Random_search'}
+    assert set(one) == {'LDE_Agent', 'DE_DDQN_Agent', 'Random_search', 'DEAP_CMAES'}
     for rows in one.values():
         assert len(rows) == 2 and all(len(r) == 51 and r[0] >= r[5] and r[5] == r[50] for r in rows)   # 6 log points, padded to 51
     assert all(v == 1000 for v in res['fes'][next(iter(res['fes']))]['DE_DDQN_Agent'])
