@@ -69,6 +69,7 @@ struct mbx_batch {
     int64_t sc_off = 0;          // offset of the scalar block inside an instance's state
     int64_t tape_stride = 0;
     int state_dim = 0, action_dim = 0;
+    int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
 };
 
 // per-algorithm geometry
@@ -397,6 +398,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     std::unique_ptr<mbx_batch, int (*)(mbx_batch*)> guard(new mbx_batch(), mbx_batch_destroy);   // freed on every error return
     mbx_batch* b = guard.get();
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
+    // More than half a CU's LDS per workgroup means one resident workgroup per CU: give it 8 waves instead of 4 (D >= 16 keeps the
+    // evaluator's per-wave scratch inside its T region).
+    if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = 512;
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
 #endif
@@ -435,8 +439,10 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipMalloc(&b->d_pci, cfg->np * sizeof(double)));
         HIP_TRY(hipMemcpy(b->d_pci, pci.data(), cfg->np * sizeof(double), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_LDE) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -499,8 +505,10 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 1, d_state_out,
                            (double*)nullptr, (uint8_t*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 512)
+        hipLaunchKernelGGL(k_rlepso_reset<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
-        hipLaunchKernelGGL(k_rlepso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        hipLaunchKernelGGL(k_rlepso_reset<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
         hipLaunchKernelGGL(k_rlpso_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_DE || b->cfg.algo == MBX_ALGO_PSO || b->cfg.algo == MBX_ALGO_CMAES)
@@ -530,8 +538,11 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 0, d_state_out,
                            d_reward_out, d_done_out);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 512)
+        hipLaunchKernelGGL(k_rlepso_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
-        hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+        hipLaunchKernelGGL(k_rlepso_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_DE)
         hipLaunchKernelGGL(k_de_sweep, dim3(b->B), dim3(kThreads), (size_t)cl_lds_doubles(1, b->cfg.np, b->cfg.dim, 1, 0) * sizeof(double),
@@ -625,9 +636,12 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     if (!b || !d_table) return fail(MBX_E_ARG, "mbx_rlepso_act_step: bad arguments");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_act_step: the batch is not an RLEPSO batch");
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_act_step: a replay tape carries no policy draws; use mbx_step with recorded actions");
-    hipLaunchKernelGGL(k_rlepso_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                       (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b),
-                       d_actions_out);
+    if (b->threads == 512)
+        hipLaunchKernelGGL(k_rlepso_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
+    else
+        hipLaunchKernelGGL(k_rlepso_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

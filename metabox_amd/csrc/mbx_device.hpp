@@ -35,7 +35,10 @@ MBX_MATH double m_log(double a) { return fm::log_fast(a); }
 #endif
 
 
-constexpr int kThreads = 256;          // 4 waves of 64
+constexpr int kThreads = 256;          // 4 waves of 64: the default workgroup
+// The block-cooperative helpers take the workgroup size from the launch (256, or 512 for the LDS-bound geometries of mbx_rlepso.hpp)
+#define MBX_NT ((int)blockDim.x)
+#define MBX_NW ((int)blockDim.x >> 6)
 constexpr double kTwoPi = 6.283185307179586;
 
 // ------------------------------------------------------------------------------------------------
@@ -233,12 +236,12 @@ __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds
 {
     const int D = P.dim;
     const FastDiv fd(D);
-    for (int t = threadIdx.x; t < D * D; t += kThreads) {
+    for (int t = threadIdx.x; t < D * D; t += MBX_NT) {
         const int d = fd.div(t), k = t - d * D;
         if (P.m1) L.M1T[k * D + d] = P.m1[t];
         if (P.m2) L.M2T[k * D + d] = P.m2[t];
     }
-    for (int d = threadIdx.x; d < D; d += kThreads) {
+    for (int d = threadIdx.x; d < D; d += MBX_NT) {
         L.DSH[d] = P.dshift ? P.dshift[d] : 0.;
         L.V0[d] = P.v0 ? P.v0[d] : 0.;
         L.V1[d] = P.v1 ? P.v1[d] : 0.;
@@ -251,7 +254,7 @@ __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, 
 {
     const int NE = n * D;
     const FastDiv fd(D);
-    for (int e = threadIdx.x; e < NE; e += kThreads) {
+    for (int e = threadIdx.x; e < NE; e += MBX_NT) {
         const int i = fd.div(e), d = e - i * D;
         const double* row = In + i * D;
         const double* col = MT + d;
@@ -270,7 +273,8 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
-    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    double s = (red[0] + red[1]) + (red[2] + red[3]);
+    if (MBX_NW == 8) s = s + ((red[4] + red[5]) + (red[6] + red[7]));
     __syncthreads();
     return s;
 }
@@ -291,17 +295,17 @@ __device__ void eval_rows_protein(const DevProblem& P, const EvalLds& L, int n_r
     const double* __restrict__ rm = P.pw + 2 * (size_t)n * n;
     for (int r = 0; r < n_rows; ++r) {
         const double* x = L.X + r * D;
-        for (int m = tid; m < m3; m += kThreads) {
+        for (int m = tid; m < m3; m += MBX_NT) {
             double s = 0.;
             for (int k = 0; k < D; ++k) s += (x[k] * L.V0[k]) * P.py[(size_t)k * m3 + m];
             COOR[m] = s + P.pc[m];
         }
         __syncthreads();
-        for (int i = tid; i < n; i += kThreads)
+        for (int i = tid; i < n; i += MBX_NT)
             P2[i] = COOR[3 * i] * COOR[3 * i] + COOR[3 * i + 1] * COOR[3 * i + 1] + COOR[3 * i + 2] * COOR[3 * i + 2];
         __syncthreads();
         double acc = 0.;
-        for (int w = tid; w < n * n; w += kThreads) {
+        for (int w = tid; w < n * n; w += MBX_NT) {
             const int i = w / n, j = w - i * n;
             const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
             double pd = sqrt(P2[i] - 2 * p3 + P2[j] + 0.01);
@@ -345,7 +349,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
     if (first_map) {
         const bool gall = kind == 21 || kind == 22;
         if (!gall) {
-            for (int e = tid; e < NE; e += kThreads) { const int d = fd.mod(e); T[e] = X[e] - dsh[d]; }
+            for (int e = tid; e < NE; e += MBX_NT) { const int d = fd.mod(e); T[e] = X[e] - dsh[d]; }
             __syncthreads();
         }
         matvec_rows(M1T, gall ? X : T, n, D, Z);
@@ -358,7 +362,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         // exp is monotone, so the winning peak of a row is found on key_k = log(w_k) - s_k/(2D) (log w_k pre-computed at
         // upload) and the reference's expression is evaluated for that peak only: one exp per row instead of n_peaks.
         // The pre-rotated peaks, C and log w are streamed through LDS in chunks (T); inside a chunk wave w takes the peaks
-        // k = w (mod 4) — uniform per wave, i.e. broadcast LDS reads — and lane l the rows l, l+64, ..; the running
+        // k = w (mod number of waves) — uniform per wave, i.e. broadcast LDS reads — and lane l the rows l, l+64, ..; the running
         // maximum of a (row, wave) pair lives in registers across chunks.  Peaks that tie to within rounding are both
         // "the maximum" to 1 ulp; the lower peak index is kept.
         const int npk = P.n_peaks, lane = tid & 63, wave = tid >> 6;
@@ -369,15 +373,15 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         double* TY = T; double* TC = T + CH * D; double* TW = T + 2 * CH * D;
         for (int c0 = 0; c0 < npk; c0 += CH) {
             const int cn = npk - c0 < CH ? npk - c0 : CH;
-            for (int t = tid; t < cn * D; t += kThreads) { TY[t] = P.pyr[c0 * D + t]; TC[t] = P.pc[c0 * D + t]; }
-            for (int t = tid; t < cn; t += kThreads) TW[t] = P.plogw[c0 + t];
+            for (int t = tid; t < cn * D; t += MBX_NT) { TY[t] = P.pyr[c0 * D + t]; TC[t] = P.pc[c0 * D + t]; }
+            for (int t = tid; t < cn; t += MBX_NT) TW[t] = P.plogw[c0 + t];
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = lane + 64 * q;
                 if (i < n) {
                     const double* rx = Z + i * D;
-                    for (int kk = wave; kk < cn; kk += 4) {
+                    for (int kk = wave; kk < cn; kk += MBX_NW) {
                         const double* ry = TY + kk * D;
                         const double* ck = TC + kk * D;
                         double acc = 0.;
@@ -396,7 +400,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         }
     } else {
         const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const int d = fd.mod(e);
             switch (kind) {
             case 2: case 10: { const double o = osc1(Z[e]); T[e] = v0[d] * (o * o); break; }
@@ -449,7 +453,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
 
     // ---- phase C: second linear map (F7 keeps |z_hat_0| in F first)
     if (kind == 7) {
-        for (int i = tid; i < n; i += kThreads) F[i] = fabs(Z[i * D]);
+        for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
         matvec_rows(M2T, T, n, D, Z);
     } else if (kind == 12 || kind == 24) {
@@ -461,9 +465,9 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
 
     // ---- phase E2: element-wise terms after the second map
     if (kind == 15 || kind == 24) {
-        for (int e = tid; e < NE; e += kThreads) T[e] = m_cos(kTwoPi * Z[e]);
+        for (int e = tid; e < NE; e += MBX_NT) T[e] = m_cos(kTwoPi * Z[e]);
     } else if (kind == 16) {                                        // Weierstrass series, bbob.py:623
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const double base = kTwoPi * (Z[e] + 0.5);
             double s = 0., ak = 1., bk = 1.;
 #pragma unroll 1
@@ -471,7 +475,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
             T[e] = s;
         }
     } else if (kind == 17 || kind == 18) {                          // Schaffers, bbob.py:642-643
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const int d = fd.mod(e);
             if (d < D - 1) {
                 const double s = sqrt(Z[e] * Z[e] + Z[e + 1] * Z[e + 1]);
@@ -479,7 +483,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
             }
         }
     } else if (kind == 19) {                                        // Griewank-Rosenbrock, bbob.py:702-703
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const int d = fd.mod(e);
             if (d < D - 1) {
                 const double a = Z[e] * Z[e] - Z[e + 1];
@@ -489,14 +493,14 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
             }
         }
     } else if (kind == 20) {                                        // Schwefel, bbob.py:754-756
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const int d = fd.mod(e);
             double zi = T[e];
             if (d > 0) zi += 0.25 * (T[e - 1] - v1[d - 1]);
             Z[e] = 100. * (v0[d] * (zi - v1[d]) + v1[d]);
         }
         __syncthreads();
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const double z = Z[e];
             const double q = fmax(0., fabs(z / 100) - ub);
             T[e] = q * q;
@@ -506,7 +510,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
     __syncthreads();
 
     // ---- row phase: sequential sums over d in ascending order (one thread per row)
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += MBX_NT) {
         const double* x = X + i * D;
         const double* z = Z + i * D;
         const double* t = T + i * D;
@@ -571,8 +575,8 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
             break;
         }
         case 21: case 22: {
-            double key = T[i * 2]; int ks = (int)T[i * 2 + 1];                 // combine the four waves' partial maxima
-            for (int w = 1; w < 4; ++w) {
+            double key = T[i * 2]; int ks = (int)T[i * 2 + 1];                 // combine the waves' partial maxima
+            for (int w = 1; w < MBX_NW; ++w) {
                 const double kw = T[(w * n + i) * 2]; const int kq = (int)T[(w * n + i) * 2 + 1];
                 if (kw > key || (kw == key && kq < ks)) { key = kw; ks = kq; }
             }
@@ -618,12 +622,12 @@ __device__ __forceinline__ void population_costs(const DevProblem& P, const Eval
                                                  uint32_t siteA, uint32_t siteB)
 {
 #ifdef MBX_ABLATE_EVAL
-    for (int i = threadIdx.x; i < n; i += kThreads) L.F[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
+    for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
     __syncthreads();
 #else
     eval_rows(P, L, n);
 #endif
-    for (int i = threadIdx.x; i < n; i += kThreads) {
+    for (int i = threadIdx.x; i < n; i += MBX_NT) {
         double f = L.F[i];
         if (P.noise_kind != MBX_NOISE_NONE) {
             double a, b, c;

@@ -98,7 +98,7 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
                                           double* __restrict__ gPB, double* __restrict__ gCC)
 {
     const int tid = threadIdx.x;
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         const double nc = L.NC[i];
         if (stagnation) L.PNI[i] = nc < gCC[i] ? 0. : L.PNI[i] + 1;   // c_cost lives in HBM only: thread i is its sole reader/writer
         const int impr = nc < L.PBC[i];
@@ -112,7 +112,7 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
     if (better) { gbest = cbv; gbest_idx = cb; }
     const int NE = NP * D;
     const FastDiv fd(D);
-    for (int e = tid; e < NE; e += kThreads) {
+    for (int e = tid; e < NE; e += MBX_NT) {
         const int i = fd.div(e);
         if (L.IMPR[i]) gPB[e] = L.X[e];                // pbest_position <- new position, straight to HBM
     }
@@ -258,7 +258,9 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
 // ------------------------------------------------------------------------------------------------
 // PBO_Env.reset(): init_population (rlepso_optimizer.py:39-65)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, double* __restrict__ state_out)
+// THREADS = 256, or 512 when the geometry leaves room for one workgroup per CU only (see rl_block_threads)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
 
     stage_problem(P, L.eval());
-    for (int e = tid; e < NE; e += kThreads) {
+    for (int e = tid; e < NE; e += MBX_NT) {
         double up, uv;
         if (tape) { up = tape[MBX_RLEPSO_TAPE_REPOS(NP, D) + e]; uv = tape[MBX_RLEPSO_TAPE_REVEL(NP, D) + e]; }
         else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_ELEM_R); up = u53(w.x, w.y); uv = u53(w.z, w.w); }
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
     population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
     double gb; int gi;
     block_argmin(L.NC, NP, L.RED, gb, gi);
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         const double c = L.NC[i];
         S[MBX_RLEPSO_ST_CCOST(NP, D) + i] = c;
         S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = c;
@@ -311,7 +313,8 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_reset(BatchParams bp, doubl
 // Actions come either from `actions` [B, 7G] (PBO_Env.step(action)) or, when `policy_table` is given, are drawn here from
 // the actor's (mu, sigma) at the instance's current state (agent.act + env.step in one launch, mbx_rlepso_act_step): row
 // fes of the table built by k_gauss_mlp_policy, same Philox draws as mbx_gauss_policy, optionally echoed to actions_out.
-__global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
                                                           double* __restrict__ state_out, double* __restrict__ reward_out,
                                                           uint8_t* __restrict__ done_out, const float* __restrict__ policy_table,
                                                           int table_rows, float* __restrict__ actions_out)
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         ACT[tid] = a;
         if (actions_out) actions_out[(int64_t)b * A + tid] = a;
     }
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         L.PBC[i] = S[MBX_RLEPSO_ST_PBEST(NP, D) + i];
         L.RANK[i] = 0; L.MASK[i] = 0;
         L.IMPR[i] = i;                                             // ORDER stays a valid index table even if a NaN cost breaks the ranking
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     int* NLESS = L.MASK;
     int* RANK = L.RANK;           // doubles as the nle accumulator
     {
-        const int parts = kThreads / NP > 0 ? kThreads / NP : 1;
-        for (int w = tid; w < parts * NP; w += kThreads) {
+        const int parts = MBX_NT / NP > 0 ? MBX_NT / NP : 1;
+        for (int w = tid; w < parts * NP; w += MBX_NT) {
             const int part = w / NP, i = w - part * NP;
             const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
             const double fi = L.PBC[i];
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
         }
     }
     __syncthreads();
-    for (int i = tid; i < NP; i += kThreads) {                    // per-particle quantities
+    for (int i = tid; i < NP; i += MBX_NT) {                    // per-particle quantities
         const int g = fg.div(i);
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
         if (tape) { L.R1[i] = tape[MBX_RLEPSO_TAPE_RAND1(NP, D) + i]; L.R2[i] = tape[MBX_RLEPSO_TAPE_RAND2(NP, D) + i]; }
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     __syncthreads();
     MBX_PHASE(1);                                                 // ranking + per-particle draws
     // pbest positions are staged in RANK order (row r = particle ORDER[r]): the FDR scan below then walks LDS linearly
-    for (int e = tid; e < NE; e += kThreads) { const int i = fd.div(e), d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
+    for (int e = tid; e < NE; e += MBX_NT) { const int i = fd.div(e), d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
     __syncthreads();
     MBX_PHASE(2);                                                 // pbest rows -> LDS in rank order
 
@@ -445,14 +448,14 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     if ((D & 1) == 0) {
         const int HD = D >> 1, NI = NP * HD;
         const FastDiv fh(HD);
-        for (int base = 0, pass = 0; base < NI; base += kThreads, ++pass) {
-            const int lim = base + kThreads < NI ? base + kThreads : NI;
+        for (int base = 0, pass = 0; base < NI; base += MBX_NT, ++pass) {
+            const int lim = base + MBX_NT < NI ? base + MBX_NT : NI;
             const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
             if (ps >= base && ps < lim) { const int rk = fh.div(ps); rl_move<2>(mc, rk, 2 * (ps - rk * HD)); }
         }
     } else {
-        for (int base = 0, pass = 0; base < NE; base += kThreads, ++pass) {
-            const int lim = base + kThreads < NE ? base + kThreads : NE;
+        for (int base = 0, pass = 0; base < NE; base += MBX_NT, ++pass) {
+            const int lim = base + MBX_NT < NE ? base + MBX_NT : NE;
             const int es = (pass & 1) ? lim - 1 - tid : base + tid;
             if (es >= base && es < lim) { const int rk = fd.div(es); rl_move<1>(mc, rk, es - rk * D); }
         }
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
 
     // ---- re-initialisation (:238-239, 134-168): P(i) = u < c_mutation_i * 0.01 * per_no_improve_i
     int mine = 0;
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         double u;
         if (tape) u = tape[MBX_RLEPSO_TAPE_REINIT(NP, D) + i];
         else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_REINIT); u = u53(w.x, w.y); }
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
     const int n_reinit = __syncthreads_count(mine);               // NP <= 256: at most one particle per thread
     MBX_PHASE(6);                                                 // re-init draw
     if (n_reinit > 0) {
-        for (int e = tid; e < NE; e += kThreads) {
+        for (int e = tid; e < NE; e += MBX_NT) {
             const int i = fd.div(e);
             if (L.MASK[i]) {
                 double up, uv;
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void k_rlepso_step(BatchParams bp, const 
 
     MBX_PHASE(7);                                                 // re-init (move, evaluation, commit)
     // ---- write back what changed
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         S[MBX_RLEPSO_ST_PBEST(NP, D) + i] = L.PBC[i];
         S[MBX_RLEPSO_ST_PNI(NP, D) + i] = L.PNI[i];
     }

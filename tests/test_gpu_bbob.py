@@ -95,7 +95,7 @@ def test_abi_rejects_bad_arguments():
     h = C.c_void_p()
     assert lib.mbx_suite_create(None, 0, None, C.byref(h)) == -1
     assert b'bad arguments' in lib.mbx_last_error()
-    cfg = _abi.AlgoCfg(9, 100, 12, 1000, 200, 5, 1, 5)       # unknown algorithm id
+    cfg = _abi.AlgoCfg(99, 100, 12, 1000, 200, 5, 1, 5)      # unknown algorithm id
     assert lib.mbx_state_dim(C.byref(cfg)) == -3 and b'not implemented' in lib.mbx_last_error()
     cfg = _abi.AlgoCfg(1, 1000, 10, 20000, 400, 50, 1, 5)    # population larger than a workgroup
     assert lib.mbx_action_dim(C.byref(cfg)) == -1
