@@ -57,15 +57,15 @@ class QLPSO_Agent(Basic_Agent):
         return np.random.choice(self.__config.n_actions, size=1, p=weights / weights.sum())
 
     def train_episode(self, env):
-        """TD(0) updates along one rollout (qlpso_agent.py:40-64)."""
-        c = self.__config
-        state, done, ret = env.reset(), False, 0
-        while not done:
+        """TD(0) along one rollout (qlpso_agent.py:40-64): Q[s, a] += alpha (r + gamma max Q[s'] - Q[s, a]); alpha decays linearly
+        from alpha_max to 0.1 over max_learning_step updates; the episode is cut when that budget is reached."""
+        c, q = self.__config, self.__q_table
+        total, state, finished = 0, env.reset(), False
+        while not finished:
             action = self.__get_action(state)
-            nxt, reward, done = env.step(action)
-            ret += reward
-            td = reward + c.gamma * self.__q_table[nxt].max() - self.__q_table[state][action]
-            self.__q_table[state][action] += self.__alpha * td
+            successor, reward, finished = env.step(action)
+            total += reward
+            q[state][action] += self.__alpha * (reward + c.gamma * q[successor].max() - q[state][action])
             self.__global_ls += 1
             if self.__global_ls >= c.save_interval * self.__cur_checkpoint:
                 self.__checkpoint()
@@ -73,16 +73,16 @@ class QLPSO_Agent(Basic_Agent):
                 break
             if c.alpha_decay:
                 self.__alpha = c.alpha_max - (c.alpha_max - 0.1) * self.__global_ls / self.__max_learning_step
-            state = nxt
-        return self.__global_ls >= self.__max_learning_step, {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1],
-                                                              'return': ret, 'learn_steps': self.__global_ls}
+            state = successor
+        summary = {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1], 'return': total, 'learn_steps': self.__global_ls}
+        return self.__global_ls >= self.__max_learning_step, summary
 
     def rollout_episode(self, env):
-        state, done, ret = env.reset(), False, 0
-        while not done:
-            state, reward, done = env.step(self.__get_action(state))
-            ret += reward
-        return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': ret}
+        total, state, finished = 0, env.reset(), False
+        while not finished:
+            state, reward, finished = env.step(self.__get_action(state))
+            total += reward
+        return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': total}
 
     @torch.no_grad()
     def rollout_batch(self, env, max_steps=None, chunk=256):
