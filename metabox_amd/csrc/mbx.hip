@@ -398,9 +398,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     std::unique_ptr<mbx_batch, int (*)(mbx_batch*)> guard(new mbx_batch(), mbx_batch_destroy);   // freed on every error return
     mbx_batch* b = guard.get();
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
-    // More than half a CU's LDS per workgroup means one resident workgroup per CU: give it 8 waves instead of 4 (D >= 16 keeps the
+    // More than half a CU's LDS per workgroup means one resident workgroup per CU: give it 8 or 16 waves instead of 4 (D >= 16 / 32 keeps the
     // evaluator's per-wave scratch inside its T region).
-    if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = 512;
+    if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
 #endif
@@ -443,6 +443,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_LDE) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -505,6 +507,8 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 1, d_state_out,
                            (double*)nullptr, (uint8_t*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 1024)
+        hipLaunchKernelGGL(k_rlepso_reset<1024>, dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 512)
         hipLaunchKernelGGL(k_rlepso_reset<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
@@ -538,6 +542,9 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 0, d_state_out,
                            d_reward_out, d_done_out);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 1024)
+        hipLaunchKernelGGL(k_rlepso_step<1024>, dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 512)
         hipLaunchKernelGGL(k_rlepso_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
@@ -636,7 +643,10 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     if (!b || !d_table) return fail(MBX_E_ARG, "mbx_rlepso_act_step: bad arguments");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_act_step: the batch is not an RLEPSO batch");
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_act_step: a replay tape carries no policy draws; use mbx_step with recorded actions");
-    if (b->threads == 512)
+    if (b->threads == 1024)
+        hipLaunchKernelGGL(k_rlepso_step<1024>, dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
+    else if (b->threads == 512)
         hipLaunchKernelGGL(k_rlepso_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
     else

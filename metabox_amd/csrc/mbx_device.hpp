@@ -265,7 +265,7 @@ __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, 
     }
 }
 
-// sum of v over the block (all threads call; result to every thread).  red: >= 8 doubles of LDS.
+// sum of v over the block (all threads call; result to every thread).  red: >= 16 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
 #pragma unroll
@@ -273,8 +273,8 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
-    double s = (red[0] + red[1]) + (red[2] + red[3]);
-    if (MBX_NW == 8) s = s + ((red[4] + red[5]) + (red[6] + red[7]));
+    double s = (red[0] + red[1]) + (red[2] + red[3]);               // 4 waves: the association the oracle-pinned protein energy uses
+    for (int g = 4; g < MBX_NW; g += 4) s = s + ((red[g] + red[g + 1]) + (red[g + 2] + red[g + 3]));
     __syncthreads();
     return s;
 }
