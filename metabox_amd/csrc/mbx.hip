@@ -400,6 +400,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
     // More than half a CU's LDS per workgroup means one resident workgroup per CU: give it 8 or 16 waves instead of 4 (D >= 16 / 32 keeps the
     // evaluator's per-wave scratch inside its T region).
+    if (cfg->algo == MBX_ALGO_LDE && lds > 40 * 1024 && cfg->dim >= 16) b->threads = 512;   // objective-bound at D = 30: 8 waves per workgroup, -21 %
     if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
@@ -446,8 +447,10 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_LDE) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -524,8 +527,10 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
         hipLaunchKernelGGL(k_gleet_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
-        if (b->cfg.algo == MBX_ALGO_LDE)
-            hipLaunchKernelGGL(k_lde_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
+            hipLaunchKernelGGL(k_lde_reset<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        else if (b->cfg.algo == MBX_ALGO_LDE)
+            hipLaunchKernelGGL(k_lde_reset<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
         else
             hipLaunchKernelGGL(k_dq_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     }
@@ -573,8 +578,11 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
                            d_done_out, (float*)nullptr);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
-        if (b->cfg.algo == MBX_ALGO_LDE)
-            hipLaunchKernelGGL(k_lde_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+        if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
+            hipLaunchKernelGGL(k_lde_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                               (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+        else if (b->cfg.algo == MBX_ALGO_LDE)
+            hipLaunchKernelGGL(k_lde_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else
             hipLaunchKernelGGL(k_dq_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),

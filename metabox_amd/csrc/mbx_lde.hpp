@@ -70,7 +70,7 @@ __device__ __forceinline__ void lde_norm_hist(const double* F, int NP, double* N
     const double mn = F[0], mx = F[NP - 1];
     double first = 0., last = mx != mn ? (mx - mn) / (mx - mn) : 0.;
     if (first == last) { first -= 0.5; last += 0.5; }
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         const double v = mx != mn ? (F[i] - mn) / (mx - mn) : 0.;
         if (NORM) NORM[i] = v;
         atomicAdd(&HIST[lde_hist_bin(v, first, last)], 1);
@@ -84,7 +84,7 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
                                               double hcount, double* state_out)
 {
     const int tid = threadIdx.x;
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         const double fi = L.FIT[i];
         int rank = 0;
         for (int j = 0; j < NP; ++j) { const double fj = L.FIT[j]; rank += (fj < fi) || (fj == fi && j < i); }
@@ -95,7 +95,7 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
     __syncthreads();
     const int NE = NP * D;
     const FastDiv fd(D);
-    for (int e = tid; e < NE; e += kThreads) {
+    for (int e = tid; e < NE; e += MBX_NT) {
         const int i = fd.div(e), d = e - i * D;
         gPop[L.PIDX[i] * D + d] = L.P[e];
     }
@@ -107,7 +107,8 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
 }
 
 // ------------------------------------------------------------------------------------------------ reset
-__global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* __restrict__ state_out)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* 
     const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, (uint32_t)episode};
     const double lb = P.lb, ub = P.ub;
     stage_problem(P, L.eval());
-    for (int e = tid; e < NE; e += kThreads) {                     // pop = lb + U * (ub - lb)   (:65-71,133)
+    for (int e = tid; e < NE; e += MBX_NT) {                     // pop = lb + U * (ub - lb)   (:65-71,133)
         double u;
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
         else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* 
     }
     __syncthreads();
     population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
-    for (int e = tid; e < NE; e += kThreads) L.P[e] = L.X[e];      // T is free again: the population moves into P for the sort
-    for (int i = tid; i < NP; i += kThreads) L.FIT[i] = L.NC[i];
+    for (int e = tid; e < NE; e += MBX_NT) L.P[e] = L.X[e];      // T is free again: the population moves into P for the sort
+    for (int i = tid; i < NP; i += MBX_NT) L.FIT[i] = L.NC[i];
     if (tid < 8) { L.HS[tid] = tid < MBX_LDE_BINS ? (double)NP / MBX_LDE_BINS : 0.; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
     double gb; int gi;
     block_argmin(L.NC, NP, L.RED, gb, gi);
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(kThreads) void k_lde_reset(BatchParams bp, double* 
 }
 
 // ------------------------------------------------------------------------------------------------ step
-__global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const float* __restrict__ actions,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lde_step(BatchParams bp, const float* __restrict__ actions,
                                                        double* __restrict__ state_out, double* __restrict__ reward_out,
                                                        uint8_t* __restrict__ done_out)
 {
@@ -170,14 +172,14 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
     const double hcount = sc[MBX_SC_HCOUNT];
 
     const double* gPop = S + MBX_LDE_ST_POP(NP, D);
-    for (int e = tid; e < NE; e += kThreads) L.P[e] = gPop[e];
-    for (int i = tid; i < NP; i += kThreads) L.FIT[i] = S[MBX_LDE_ST_FIT(NP, D) + i];
+    for (int e = tid; e < NE; e += MBX_NT) L.P[e] = gPop[e];
+    for (int i = tid; i < NP; i += MBX_NT) L.FIT[i] = S[MBX_LDE_ST_FIT(NP, D) + i];
     if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
     stage_problem(P, L.eval());
     // p-best bound (:101-105): p = max(0, (P_MIN - P_INI) fes/maxFEs + P_INI), P_MIN = 2/NP, P_INI = 1
     const double p_rate = (2. / NP - 1) * fes / bp.max_fes + 1;
     const int bound = (int)ceil(NP * fmax(0., p_rate));
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         int pidx, r0, r1, jr;
         if (tape) {
             pidx = (int)tape[MBX_LDE_TAPE_PIDX(NP, D) + i]; r0 = (int)tape[MBX_LDE_TAPE_R0(NP, D) + i];
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
 
     // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
     const FastDiv fd(D);
-    for (int e = tid; e < NE; e += kThreads) {
+    for (int e = tid; e < NE; e += MBX_NT) {
         const int i = fd.div(e), d = e - i * D;
         double u;
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
@@ -227,14 +229,14 @@ __global__ __launch_bounds__(kThreads) void k_lde_step(BatchParams bp, const flo
 
     // ---- selection (:55-59): offspring survives when it is better than or equal to its parent
     const double bsf = L.FIT[0];                                   // population is sorted: minimum first
-    for (int i = tid; i < NP; i += kThreads) {
+    for (int i = tid; i < NP; i += MBX_NT) {
         const int surv = L.NC[i] <= L.FIT[i];
         L.R0[i] = surv;
         if (surv) L.FIT[i] = L.NC[i];
     }
     __syncthreads();
     // survivors take the trial vector; the other rows are re-read from HBM (P's storage served as evaluator scratch meanwhile)
-    for (int e = tid; e < NE; e += kThreads) L.P[e] = L.R0[fd.div(e)] ? L.X[e] : gPop[e];
+    for (int e = tid; e < NE; e += MBX_NT) L.P[e] = L.R0[fd.div(e)] ? L.X[e] : gPop[e];
     double bsf_next; int bi;
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
     if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
