@@ -269,6 +269,30 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
     }
     __syncthreads();
 
+    // ---- OM_W window (:178-187): when full, evict the first entry of the same operator, else the worst trial (first maximum), and
+    // close the gap.  Depends on the action only, so it is done here by the whole block instead of inside the one-lane section
+    // below (the serial search + 300-element shift were a quarter of the step's latency).
+    if (omw_len >= MBX_DQ_W) {
+        double* W = L.omw();
+        if (tid < 64) {
+            const bool in = tid < omw_len;
+            const bool same = in && (int)W[tid * 6] == action;
+            const unsigned long long m = __ballot(same);
+            double v = in ? -W[tid * 6 + 5] : INFINITY;
+            int idx = tid;
+            wave_argmin(v, idx);
+            if (tid == 0) L.MISC[5] = m ? (double)(__ffsll((long long)m) - 1) : (double)idx;
+        }
+        __syncthreads();
+        const int del = (int)L.MISC[5], last = (omw_len - 1) * 6;
+        const int k0 = del * 6 + tid, k1 = k0 + kThreads;
+        const double v0 = k0 < last ? W[k0 + 6] : 0., v1 = k1 < last ? W[k1 + 6] : 0.;
+        __syncthreads();
+        if (k0 < last) W[k0] = v0;
+        if (k1 < last) W[k1] = v1;
+        omw_len -= 1;
+        __syncthreads();
+    }
     // ---- sequential bookkeeping (:164-203) by one lane
     if (tid == 0) {
         double tc = L.NC[0];
@@ -292,14 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
                 L.nsucc()[k] += 1; L.omsum()[k] += om[m];
             }
         double* W = L.omw();
-        if (omw_len >= MBX_DQ_W) {                                  // evict: first entry of the same operator, else the worst trial
-            int del = -1;
-            for (int i = 0; i < omw_len; ++i) if ((int)W[i * 6] == action) { del = i; break; }
-            if (del < 0) { del = 0; for (int i = 1; i < omw_len; ++i) if (W[i * 6 + 5] > W[del * 6 + 5]) del = i; }
-            for (int k = del * 6; k < (omw_len - 1) * 6; ++k) W[k] = W[k + 6];
-            omw_len -= 1;
-        }
-        double* e = W + omw_len * 6;
+        double* e = W + omw_len * 6;                                // the window was already trimmed above
         e[0] = action; e[1] = om[0]; e[2] = om[1]; e[3] = om[2]; e[4] = om[3]; e[5] = tc;
         omw_len += 1;
         if (tc >= gbest) stag += 1;
