@@ -90,14 +90,37 @@ class DE_DDQN_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': total}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None):
+    def rollout_batch(self, env, max_steps=None, graph=False):
+        """Lock-step rollout: greedy action of the Q-network for the whole batch, then the fused DE-DDQN step kernel.  ``graph=True``
+        captures the Q-network forward (5 small GEMMs + element-wise ops) once into a hipGraph that reads the batch's persistent
+        state tensor and replays it every step; measured on config 4's share it is not faster than the eager ops (181 vs 175 us per
+        step: the step is bound by GPU time, not by launches), so eager stays the default."""
         if max_steps is None:
             bc = env.batch.cfg
             max_steps = bc.max_fes - bc.np                # one evaluation per step
         state = env.reset()
+        net = self.__pred_func
+
+        def greedy_of(st):
+            return net(st.to(torch.float32)).argmax(dim=1).to(torch.int32)
+
+        replay, static_action = None, None
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    greedy_of(state)
+            torch.cuda.current_stream().wait_stream(side)
+            replay = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(replay):
+                static_action = greedy_of(state)             # `state` is the batch's own tensor: later steps overwrite it in place
         for _ in range(max_steps):
-            greedy = self.__pred_func(state.to(torch.float32)).argmax(dim=1).to(torch.int32)
-            state, _, _ = env.step(greedy.contiguous())
+            if replay is not None:
+                replay.replay()
+                env.step(static_action)
+            else:
+                state, _, _ = env.step(greedy_of(state).contiguous())
         res = env.results()
         return {k: res[k] for k in ('cost', 'fes', 'return', 'steps', 'cost_len')}
 

@@ -48,6 +48,18 @@ if 'ddqn' in which:
             for _ in range(n):
                 a = torch.argmax(agent.q_net(state.to(torch.float32)), dim=1).to(torch.int32)
                 state, _, _ = env.step(a.contiguous())
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(3): torch.argmax(agent.q_net(state.to(torch.float32)), dim=1).to(torch.int32)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        ga = torch.argmax(agent.q_net(state.to(torch.float32)), dim=1).to(torch.int32)
+    def run_graph(n):
+        for _ in range(n):
+            g.replay(); env.step(ga)
+    run_graph(5); dg = timed(run_graph, 200)
+    print(json.dumps({'path': 'DE-DDQN protein, Q-net replayed as a hipGraph (rollout_batch default)', 'ms_per_step': dg / 200 * 1e3, 'env_steps_per_s': B * 200 / dg}))
     run(5); dt = timed(run, 200)
     print(json.dumps({'path': 'DE-DDQN protein d=12 NP=100, 2240 instances (35 problems x 64 runs), Q-net via PyTorch', 'ms_per_step': dt / 200 * 1e3, 'env_steps_per_s': B * 200 / dt}))
     env.close()
