@@ -92,11 +92,14 @@ def pmc_traffic_per_launch(live_per_launch):
     (2 x FETCH_SIZE + WRITE_SIZE, calibration in profiles/*_pmc_hbm_traffic.json; collected with every instance
     live), scaled to this run's average number of live instances per launch.  None when no profile is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
-    if not files:
-        return None
-    prof = json.load(open(files[-1]))
-    return prof['calibration']['hbm_bytes_per_launch'] / INSTANCES_PER_GPU * live_per_launch
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                per_launch = json.load(f)['calibration']['hbm_bytes_per_launch']
+        except (OSError, ValueError, KeyError, TypeError):
+            continue                                   # an incomplete profile must never take the bench line down
+        return per_launch / INSTANCES_PER_GPU * live_per_launch
+    return None
 
 
 def main():

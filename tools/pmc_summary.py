@@ -5,6 +5,7 @@ HBM bytes per launch follow MI355X_MICROARCH.md's gfx950 recipe: FETCH_SIZE and 
 under-reports these 8-byte coalesced loads by x2 on gfx950 (calibrated in profiles/README.md), WRITE_SIZE is 1:1:
 hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
 import csv
+import re
 import glob
 import json
 import os
@@ -16,7 +17,7 @@ vals = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row['Kernel_Name'].split('(')[0]
+            name = re.sub(r'<[^>]*>', '', row['Kernel_Name'].split('(')[0]).replace('void ', '').strip()     # templated kernels: 'void mbx::k<256>'
             if 'mbx::' in name:
                 vals[name][row['Counter_Name']].append(float(row['Counter_Value']))
 out = {'command': 'python bench.py --steps 20 --warmup 2 --no-cpu-baseline under rocprofv3 --pmc <counters> '
