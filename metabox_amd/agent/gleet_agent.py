@@ -285,6 +285,89 @@ class GLEET_Agent(Basic_Agent):
                     return True, info()
         return self.__learning_time >= c.max_learning_step, info()
 
+    # ---- batched training (SURVEY §8 N3 applied to GLEET) -----------------------------------------------------------------
+    def train_batch(self, env, max_updates=None):
+        """PPO over a lock-step BatchedPBO_Env: the reference's n_step = 10 segments / K_epochs = 3 / clipped surrogate + clipped value
+        loss / per-group gradient-norm clipping (gleet_agent.py:113-290) with a leading batch axis; losses are averaged over the
+        (step, swarm) pairs still running.  By construction one optimizer step consumes B trajectories instead of one.  Gradients are
+        averaged across ranks when torch.distributed is initialised.
+        Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'}) with per-batch means."""
+        from ..distributed import average_gradients
+        c = self.__config
+        actor, critic = self.actor, self.critic
+        params = list(actor.parameters()) + list(critic.parameters())
+        B = env.B
+
+        def as_input(st):
+            return st.view(B, -1, 27).to(torch.float32).clone()
+
+        def evaluate(x, action):
+            z = actor.features(x)
+            mu, sigma = actor.distribution(z)
+            return Normal(mu, sigma).log_prob(action).sum(dim=(1, 2)), critic.value_head(z.mean(dim=-2)).squeeze(-1)
+
+        state = as_input(env.reset())
+        alive = torch.ones(B, dtype=torch.bool, device=state.device)
+        ret_sum = torch.zeros(B, dtype=torch.float64, device=state.device)
+        updates, exceed = 0, False
+        while bool(alive.any()) and not exceed:
+            S, A, LP, V, R, M = [], [], [], [], [], []
+            for _ in range(c.n_step):
+                with torch.no_grad():
+                    mu, sigma = actor.distribution(actor.features(state))
+                    action = torch.clamp(mu + sigma * torch.randn_like(mu), 0, 1)
+                logp, val = evaluate(state, action)
+                S.append(state); A.append(action); LP.append(logp); V.append(val); M.append(alive.clone())
+                nstate, reward, done = env.step(action.squeeze(-1).contiguous())
+                R.append(reward.to(torch.float32).clone())
+                ret_sum += reward * alive
+                alive = alive & (done == 0)
+                state = as_input(nstate)
+                if not bool(alive.any()):
+                    break
+            T = len(S)
+            M = torch.stack(M).to(torch.float32)
+            R = torch.stack(R) * M
+            old_logp = torch.stack(LP).detach()
+            n_live = M.sum().clamp_min(1.)
+            old_value = None
+            for k in range(c.K_epochs):
+                if k == 0:
+                    logp, val = torch.stack(LP), torch.stack(V)
+                else:
+                    pairs = [evaluate(S[t], A[t]) for t in range(T)]
+                    logp, val = torch.stack([q[0] for q in pairs]), torch.stack([q[1] for q in pairs])
+                with torch.no_grad():
+                    Rt = critic.value_head(actor.features(state).mean(dim=-2)).squeeze(-1)
+                    returns = []
+                    for t in reversed(range(T)):
+                        Rt = torch.where(M[t] > 0, Rt * c.gamma + R[t], Rt)
+                        returns.append(Rt)
+                    returns = torch.stack(returns[::-1])
+                ratio = torch.exp(logp - old_logp)
+                adv = returns - val.detach()
+                policy_loss = -(torch.min(ratio * adv, torch.clamp(ratio, 1 - c.eps_clip, 1 + c.eps_clip) * adv) * M).sum() / n_live
+                if old_value is None:
+                    value_loss = (((val - returns) ** 2) * M).sum() / n_live
+                    old_value = val.detach()
+                else:
+                    v_clip = old_value + torch.clamp(val - old_value, -c.eps_clip, c.eps_clip)
+                    value_loss = (torch.max((val - returns) ** 2, (v_clip - returns) ** 2) * M).sum() / n_live
+                self.optimizer.zero_grad()
+                (value_loss + policy_loss).backward()
+                average_gradients(params)
+                for group in self.optimizer.param_groups:
+                    torch.nn.utils.clip_grad_norm_(group['params'], c.max_grad_norm if c.max_grad_norm > 0 else math.inf, norm_type=2)
+                self.optimizer.step()
+                updates += 1
+                if self.__after_update() or (max_updates is not None and updates >= max_updates):
+                    exceed = True
+                    break
+        res = env.results()
+        return self.__learning_time >= c.max_learning_step, {
+            'normalizer': float(res['cost'][:, 0].mean()), 'gbest': float(res['cost'][:, -1].mean()),
+            'return': float(ret_sum.mean()), 'learn_steps': self.__learning_time}
+
     @torch.no_grad()
     def rollout_episode(self, env):
         done, ret = False, 0

@@ -238,3 +238,34 @@ def test_gleet_policy_kernel_equals_attention_modules():
     env.close()
     out = agent.rollout_batch(BatchedPBO_Env(ps, GLEET_Optimizer(cfg), np.arange(B) % 3, np.arange(B, dtype=np.uint64) + 3))
     assert bool((out['cost'][:, 0] >= out['cost'][:, -1]).all()) and float(out['fes'].max()) == 20000
+
+
+@pytest.mark.gpu
+def test_gleet_batched_ppo_updates_the_policy(tmp_path):
+    """train_batch: PPO over a lock-step batch of swarms (n_step = 10, K_epochs = 3) -- losses finite, parameters move, the
+    learning-step / checkpoint bookkeeping of the reference is kept, and Trainer.train_batched can drive it."""
+    import copy
+    import torch
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import GLEET_Optimizer
+    agent, cfg = _agent('cuda')
+    agent.to('cuda')
+    small = copy.deepcopy(cfg)
+    small.maxFEs, small.log_interval, small.n_logpoint = 2600, 100, 26
+    tcfg = copy.deepcopy(small)
+    tcfg.max_learning_step, tcfg.save_interval, tcfg.agent_save_dir = 1000, 4, str(tmp_path) + '/'
+    agent.update_setting(tcfg)
+    ps = [problems('bbob', 10)[f] for f in (1, 8, 15)]
+    B = 48
+    env = BatchedPBO_Env(ps, GLEET_Optimizer(small), np.arange(B) % 3, np.arange(B, dtype=np.uint64) + 9)
+    before = [q.detach().clone() for q in agent.actor.parameters()]
+    torch.manual_seed(0)
+    with torch.enable_grad():
+        exceed, info = agent.train_batch(env, max_updates=6)
+    assert not exceed and info['learn_steps'] == 6 and np.isfinite(info['return']) and info['return'] >= 0
+    assert info['normalizer'] >= info['gbest'] > 0
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.actor.parameters()))
+    assert all(torch.isfinite(q).all() for q in agent.actor.parameters())
+    import os
+    assert os.path.exists(str(tmp_path / 'checkpoint1.pkl'))            # save_interval = 4 learning steps
+    env.close()
