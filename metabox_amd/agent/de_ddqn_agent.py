@@ -66,6 +66,11 @@ class DE_DDQN_Agent(Basic_Agent):
         self.__target_func.to(device)
         return self
 
+    def __getstate__(self):
+        """Checkpoints carry the networks and the host-side replay like the reference's; the device-resident replay of train_batch
+        (up to 80 MB) is rebuilt on demand."""
+        return {k: v for k, v in self.__dict__.items() if k != '_dev_replay'}
+
     def update_setting(self, config):
         self.__max_learning_step = config.max_learning_step
         self.__config.agent_save_dir = config.agent_save_dir
@@ -137,6 +142,70 @@ class DE_DDQN_Agent(Basic_Agent):
         self.__global_ls += 1
         if self.__global_ls >= cfg.save_interval * self.__cur_checkpoint:
             self.__checkpoint()
+
+    def train_batch(self, env, max_updates=None, updates_per_step=1):
+        """Double-DQN training over a lock-step BatchedPBO_Env.  Every env step all B instances act epsilon-greedily on the device,
+        their B transitions go into a device-resident FIFO replay (capacity memory_size, the oldest rows are overwritten), and once
+        it holds warm_up_size transitions `updates_per_step` mini-batch updates (batch_size = 64, Huber-free MSE on the TD target with
+        the target network, refreshed every update_target_steps updates) follow -- the reference's loop (de_ddqn_agent.py:70-106)
+        with a batch axis.  By construction the data : update ratio is B times the reference's.  Gradients are averaged across ranks.
+        Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'})."""
+        from ..distributed import average_gradients
+        cfg, dev = self.__config, env.batch.device
+        net, tgt = self.__pred_func, self.__target_func
+        B, S = env.B, cfg.state_size
+        cap = (cfg.memory_size // B) * B if cfg.memory_size >= B else B
+        if getattr(self, '_dev_replay', None) is None or self._dev_replay['obs'].shape[0] != cap or self._dev_replay['obs'].device != dev:
+            self._dev_replay = dict(obs=torch.empty(cap, S, device=dev), nxt=torch.empty(cap, S, device=dev),
+                                    act=torch.empty(cap, dtype=torch.int64, device=dev), rew=torch.empty(cap, device=dev),
+                                    done=torch.empty(cap, device=dev), size=0, head=0)
+        rb = self._dev_replay
+        params = list(net.parameters())
+        state = env.reset().to(torch.float32).clone()
+        alive = torch.ones(B, dtype=torch.bool, device=dev)
+        ret_sum = torch.zeros(B, dtype=torch.float64, device=dev)
+        updates, exceed = 0, False
+        while bool(alive.any()) and not exceed:
+            with torch.no_grad():
+                greedy = net(state).argmax(dim=1)
+                explore = torch.rand(B, device=dev) < cfg.epsilon
+                action = torch.where(explore, torch.randint(0, cfg.n_act, (B,), device=dev), greedy)
+            nstate, reward, done = env.step(action.to(torch.int32).contiguous())
+            nstate = nstate.to(torch.float32).clone()
+            ret_sum += reward * alive
+            live = alive.nonzero(as_tuple=True)[0]                  # finished instances contribute no transitions
+            n = int(live.numel())
+            if n:
+                slots = (rb['head'] + torch.arange(n, device=dev)) % cap
+                rb['obs'][slots] = state[live]; rb['nxt'][slots] = nstate[live]; rb['act'][slots] = action[live]
+                rb['rew'][slots] = reward[live].to(torch.float32); rb['done'][slots] = (done[live] != 0).to(torch.float32)
+                rb['head'] = (rb['head'] + n) % cap
+                rb['size'] = min(cap, rb['size'] + n)
+            alive = alive & (done == 0)
+            state = nstate
+            if rb['size'] >= min(cfg.warm_up_size, cap):
+                for _ in range(updates_per_step):
+                    idx = torch.randint(0, rb['size'], (cfg.batch_size,), device=dev)
+                    q_taken = net(rb['obs'][idx]).gather(1, rb['act'][idx].view(-1, 1)).squeeze(1)
+                    with torch.no_grad():
+                        target = rb['rew'][idx] + (1 - rb['done'][idx]) * cfg.gamma * tgt(rb['nxt'][idx]).max(1)[0]
+                    self.__optimizer.zero_grad()
+                    self.__criterion(q_taken, target).backward()
+                    average_gradients(params)
+                    self.__optimizer.step()
+                    self.__global_ls += 1
+                    updates += 1
+                    if getattr(cfg, 'agent_save_dir', None) and self.__global_ls >= cfg.save_interval * self.__cur_checkpoint:
+                        self.__checkpoint()
+                    if self.__global_ls % cfg.update_target_steps == 0:
+                        tgt.load_state_dict(net.state_dict())
+                    if self.__global_ls >= self.__max_learning_step or (max_updates is not None and updates >= max_updates):
+                        exceed = True
+                        break
+        res = env.results()
+        return self.__global_ls >= self.__max_learning_step, {
+            'normalizer': float(res['cost'][:, 0].mean()), 'gbest': float(res['cost'][:, -1].mean()),
+            'return': float(ret_sum.mean()), 'learn_steps': self.__global_ls}
 
     def train_episode(self, env):
         """One episode of epsilon-greedy interaction with a replay update after every step once the buffer holds

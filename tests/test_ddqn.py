@@ -127,3 +127,34 @@ def test_hip_ddqn_philox_parity_with_oracle():
         assert close(got['extra'][:2], want['extra'][:2])                       # c_gworst, c_prebest (floating point)
         assert np.array_equal(got['extra'][2:], want['extra'][2:]), ids[k]      # pointer, gen, stagcount, |OM_W|, aliases
     b.close()
+
+
+@pytest.mark.gpu
+def test_ddqn_batched_replay_training(tmp_path):
+    """train_batch: epsilon-greedy lock-step interaction, device-resident replay, double-DQN updates with target refresh."""
+    import copy
+    import os
+    import torch
+    from metabox_amd.agent import DE_DDQN_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import DE_DDQN_Optimizer
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    agent = DE_DDQN_Agent(cfg).load_exported_weights(load('ddqn_policy.npz')).to('cuda')
+    cfg.warm_up_size, cfg.update_target_steps = 512, 8
+    cfg.maxFEs, cfg.log_interval = 400, 8
+    tcfg = copy.deepcopy(cfg)
+    tcfg.max_learning_step, tcfg.save_interval, tcfg.agent_save_dir = 10 ** 6, 10, str(tmp_path) + '/'
+    agent.update_setting(tcfg)
+    ps = [problems('bbob', 10)[f] for f in (1, 15)]
+    env = BatchedPBO_Env(ps, DE_DDQN_Optimizer(cfg), np.arange(64) % 2, np.arange(64, dtype=np.uint64) + 1)
+    before = [q.detach().clone() for q in agent.q_net.parameters()]
+    torch.manual_seed(1)
+    with torch.enable_grad():
+        exceed, info = agent.train_batch(env, max_updates=25)
+    assert not exceed and info['learn_steps'] == 25 and np.isfinite(info['return']) and info['normalizer'] >= info['gbest']
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.q_net.parameters()))
+    assert all(torch.isfinite(q).all() for q in agent.q_net.parameters())
+    assert os.path.exists(str(tmp_path / 'checkpoint2.pkl')) and os.path.getsize(str(tmp_path / 'checkpoint2.pkl')) < 2_000_000
+    env.close()
