@@ -15,8 +15,9 @@ timed region.
 Also reported on the same JSON line:
   roofline     — fused generation kernel: algorithmic bytes (54.0 KB per env-step) x live instances
                  per launch / average kernel duration measured with HIP events on the launch stream, vs 8 TB/s.
-  cpu_baseline — the C oracle (a float64 port of the reference path, oracle/mbx_oracle.c) on one host core,
-                 on a bounded sample of the same workload (rank 0, N = 1 only).
+  cpu_baseline — the C oracle (a float64 port of the reference path, oracle/mbx_oracle.c) on all host cores (one
+                 single-threaded worker per core) and on one core, on a bounded sample of the same workload
+                 (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -56,35 +57,58 @@ def load_agent(config, device):
 
 
 def cpu_baseline(seconds_budget=20.0):
-    """The oracle (port of the reference path) timed on one host core over whole episodes of the same workload."""
-    from metabox_amd.problem.bbob import BBOB_Dataset
-    from oracle import oracle
+    """The oracle (C port of the reference path, oracle/mbx_oracle.c) timed on the host over whole episodes of the same workload:
+    one worker process per host core (oracle/cpu_workload.py; actions sampled from the actor's (mu, sigma) table), and the
+    same worker alone for the single-core figure."""
+    import subprocess
+    import tempfile
+    from metabox_amd.agent.rlepso_agent import ActorTable
     torch.set_num_threads(1)
     config = make_config()
     config.device = 'cpu'
     agent = load_agent(config, 'cpu')
-    tr, te = BBOB_Dataset.get_datasets('bbob', DIM, 5.0)
-    ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
-    cfg = oracle.make_cfg(1, NP_, DIM, MAXFES, LOGI, NLOG)
-    steps, t0, episodes = 0, time.perf_counter(), 0
-    run = 0
-    while time.perf_counter() - t0 < seconds_budget:
-        for p in ps:
-            o = oracle.RlepsoOracle(p.desc(), p.bias, cfg, seed=1000 + run)
-            s = o.reset()
-            done = False
-            while not done:
-                a = agent.actor.act_batch(torch.tensor([[s]], dtype=torch.float32))[0].numpy()
-                s, r, done = o.step(a)
-                steps += 1
-            episodes += 1
-            if time.perf_counter() - t0 >= seconds_budget:
-                break
-        run += 1
-    dt = time.perf_counter() - t0
-    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{episodes} whole RLEPSO episodes (bbob d=10 pop=100, functions round-robin, same policy), '
-                      f'{steps} env-steps in {dt:.1f} s, C float64 oracle + torch-CPU actor, 1 thread'}
+    table = ActorTable(agent.actor, MAXFES, NP_, 'cpu').table.numpy()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:                                                       # a cgroup CPU quota (cpu.max = "<quota> <period>") bounds the useful workers
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            cores = min(cores, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, 128))
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    script = os.path.join(ROOT, 'oracle', 'cpu_workload.py')
+
+    def leg(n, seconds):
+        procs = [subprocess.Popen([sys.executable, script, '--table', path, '--seconds', str(seconds), '--worker', str(k)],
+                                  stdout=subprocess.PIPE, env=env, cwd=ROOT) for k in range(n)]
+        outs = []
+        for pr in procs:
+            out, _ = pr.communicate(timeout=seconds * 6 + 120)
+            if pr.returncode != 0:
+                raise RuntimeError('cpu_baseline worker failed')
+            outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+        return outs
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'actor_table.npy')
+        np.save(path, table)
+        one = leg(1, 0.4 * seconds_budget)[0]
+        many = leg(cores, 0.6 * seconds_budget) if cores > 1 else [one]
+    single = one['steps'] / one['seconds']
+    # every worker runs for the same wall time; the aggregate rate is the sum of the workers' own rates
+    value = sum(w['steps'] / w['seconds'] for w in many)
+    steps, episodes = sum(w['steps'] for w in many), sum(w['episodes'] for w in many)
+    wall = max(w['seconds'] for w in many)
+    return {'value': value, 'unit': 'env-steps/s', 'cores': len(many), 'kind': 'port', 'single_core_value': single,
+            'sample': f'{episodes} whole RLEPSO episodes (bbob d=10 pop=100, functions round-robin, same policy as the GPU run: '
+                      f'actions drawn from the actor\'s (mu, sigma) table), {steps} env-steps in {wall:.1f} s on {len(many)} '
+                      f'single-threaded worker processes (one per host core the container may use), C float64 oracle; one worker alone: '
+                      f'{one["steps"]} env-steps in {one["seconds"]:.1f} s'}
 
 
 def pmc_traffic_per_launch(live_per_launch):
