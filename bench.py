@@ -133,6 +133,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--functions', default='all24',
+                    help="all24 (default: every bbob function round-robin), train18 (the bbob-easy train split), or a comma list of "
+                         "function ids (SURVEY §8(d) C2 asks for the split and per-function figures next to the headline)")
+    ap.add_argument('--fixed-horizon', action='store_true',
+                    help='disable the reference stop rule gbest <= 1e-8: every instance runs all 199 generations')
     ap.add_argument('--policy', choices=['fused', 'hip', 'torch', 'table'], default='fused',
                     help='fused: the generation kernel draws its own action from the actor table (mbx_rlepso_act_step, default); '
                          'hip: mbx_gauss_policy + mbx_step; torch: the two MLPs as batched PyTorch ops; table: (mu, sigma) gathered '
@@ -170,11 +175,18 @@ def main():
     optimizer = RLEPSO_Optimizer(config)
     tr, te = BBOB_Dataset.get_datasets('bbob', DIM, 5.0)
     ps = sorted(tr.data + te.data, key=lambda p: p.func_id)          # all 24 functions, every branch exercised
+    if args.functions == 'train18':
+        ps = sorted(tr.data, key=lambda p: p.func_id)
+    elif args.functions != 'all24':
+        want = [int(x) for x in args.functions.split(',')]
+        ps = [p for p in ps if p.func_id in want]
+        if len(ps) != len(set(want)):
+            raise SystemExit(f'--functions: unknown bbob function id in {want}')
     B = args.instances
     gid = np.arange(B, dtype=np.int64) + rank * B                       # global instance ids: weak scaling
     pidx = (gid % len(ps)).astype(np.int32)
     seeds = (gid // len(ps)).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
-    env = BatchedPBO_Env(ps, optimizer, pidx, seeds, early_stop=True)
+    env = BatchedPBO_Env(ps, optimizer, pidx, seeds, early_stop=not args.fixed_horizon)
     actor = agent.actor
     table = agent.actor_table(MAXFES, NP_, dev)
 
@@ -265,6 +277,9 @@ def main():
     live_all, kern_ms_all, elapsed_max = float(tot[0]), float(tot[1]), float(tmax[0])
 
     if rank == 0:
+        fn_desc = {'all24': '24 bbob functions', 'train18': 'the 18 bbob-easy train functions'}.get(
+            args.functions, 'bbob function(s) ' + args.functions)
+        stop_desc = 'fixed horizon (stop rule disabled)' if args.fixed_horizon else 'reference stop rule'
         value = live_all / elapsed_max
         avg_kernel_s = (kern_ms_all / world) / K / 1e3
         live_per_launch = live_all / world / K
@@ -276,8 +291,8 @@ def main():
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed_max / K * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'RLEPSO_Agent + RLEPSO_Optimizer, bbob dim=10 pop=100, {B} lock-step instances per GPU '
-                                   f'(24 bbob functions round-robin x seeds), maxFEs=20000 (199 generations/episode), '
-                                   f'reference stop rule, policy = exported bbob_easy RLEPSO weights sampled on device',
+                                   f'({fn_desc} round-robin x seeds), maxFEs=20000 (199 generations/episode), '
+                                   f'{stop_desc}, policy = exported bbob_easy RLEPSO weights sampled on device',
                        'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}',
                        'policy': {'fused': 'act + step in one launch (mbx_rlepso_act_step): the generation kernel draws its action from the '
                                            'actor (mu, sigma) table built by mbx_rlepso_policy_table (actor evaluated at every reachable '

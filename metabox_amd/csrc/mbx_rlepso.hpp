@@ -175,6 +175,26 @@ __device__ unsigned long long g_phase_cycles[8192 * 16];         // [block][phas
 #define MBX_FDR_UNROLL 4
 #endif
 
+// if (lhs < rhs) { ab = a; bb = b; kb = k; } as three EXEC-masked moves (v_cmpx + v_mov_b64 x2 + v_mov_b32) instead of the five
+// v_cndmask_b32 the compiler's if-conversion produces: the FDR scan below is VALU-issue bound and this is its innermost statement.
+__device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, double& bb, int& kb, double a, double b, int k)
+{
+#ifdef MBX_FDR_SELECT
+    if (lhs < rhs) { ab = a; bb = b; kb = k; }
+#else
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_lt_f64_e32 %[l], %[r]\n\t"
+                 "v_mov_b64 %[ab], %[a]\n\t"
+                 "v_mov_b64 %[bb], %[b]\n\t"
+                 "v_mov_b32 %[kb], %[k]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [ab] "+v"(ab), [bb] "+v"(bb), [kb] "+v"(kb), [sv] "=&s"(saved)
+                 : [l] "v"(lhs), [r] "v"(rhs), [a] "v"(a), [b] "v"(b), [k] "s"(k)
+                 : "vcc");
+#endif
+}
+
 // Move W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk (rlepso_optimizer.py:179-195).
 template <int W>
 __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
@@ -224,13 +244,33 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
 #pragma unroll
         for (int q = 0; q < W; ++q) { kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
         const double* col = L.PB + d0;
-#pragma unroll MBX_FDR_UNROLL
-        for (int k = 1; k < nless; ++k) {
-            const double a = L.NC[k] - fi;                        // shared by the W coordinates
+        // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
+        // issued before its first comparison
+        int k = 1;
+        for (; k + MBX_FDR_UNROLL <= nless; k += MBX_FDR_UNROLL) {
+            double a[MBX_FDR_UNROLL], x[MBX_FDR_UNROLL][W];
+#pragma unroll
+            for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
+                a[u] = L.NC[k + u];
+#pragma unroll
+                for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
+            }
+#pragma unroll
+            for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
+                const double au = a[u] - fi;                      // shared by the W coordinates
+#pragma unroll
+                for (int q = 0; q < W; ++q) {
+                    const double b = fabs(x[u][q] - pp[q]) + 1e-5;
+                    fdr_take(au * bb[q], ab[q] * b, ab[q], bb[q], kb[q], au, b, k + u);
+                }
+            }
+        }
+        for (; k < nless; ++k) {
+            const double a = L.NC[k] - fi;
 #pragma unroll
             for (int q = 0; q < W; ++q) {
                 const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
-                if (a * bb[q] < ab[q] * b) { ab[q] = a; bb[q] = b; kb[q] = k; }
+                fdr_take(a * bb[q], ab[q] * b, ab[q], bb[q], kb[q], a, b, k);
             }
         }
     }
