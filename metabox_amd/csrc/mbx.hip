@@ -70,6 +70,7 @@ struct mbx_batch {
     int64_t tape_stride = 0;
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
+    bool fixed_geometry = false; // RLEPSO at NP = 100, D = 10, 5 groups: the compile-time-geometry instantiation of k_rlepso_step
 };
 
 // per-algorithm geometry
@@ -402,6 +403,12 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     // evaluator's per-wave scratch inside its T region).
     if (cfg->algo == MBX_ALGO_LDE && lds > 40 * 1024 && cfg->dim >= 16) b->threads = 512;   // objective-bound at D = 30: 8 waves per workgroup, -21 %
     if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
+    // MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
+    {
+        const char* g = getenv("MBX_GENERIC_GEOMETRY");
+        b->fixed_geometry = cfg->algo == MBX_ALGO_RLEPSO && b->threads == kThreads && cfg->np == 100 && cfg->dim == 10 && cfg->n_group == 5 &&
+                            !(g && g[0] == '1');
+    }
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
 #endif
@@ -442,6 +449,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -504,6 +512,21 @@ static BatchParams make_params(const mbx_batch* b)
     return p;
 }
 
+// one RLEPSO generation: the instantiation of k_rlepso_step that fits the batch (workgroup size by LDS footprint, compile-time
+// geometry for the reference's NP = 100 / D = 10 / 5 groups)
+static void launch_rlepso_step(mbx_batch* b, hipStream_t stream, const float* d_actions, double* d_state_out, double* d_reward_out,
+                               uint8_t* d_done_out, const float* d_table, int table_rows, float* d_actions_out)
+{
+#define MBX_RLEPSO_LAUNCH(...)                                                                                                   \
+    hipLaunchKernelGGL((k_rlepso_step<__VA_ARGS__>), dim3(b->B), dim3(b->threads), b->lds_bytes, stream, make_params(b), d_actions, \
+                       d_state_out, d_reward_out, d_done_out, d_table, table_rows, d_actions_out)
+    if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024);
+    else if (b->threads == 512) MBX_RLEPSO_LAUNCH(512);
+    else if (b->fixed_geometry) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
+    else MBX_RLEPSO_LAUNCH(kThreads);
+#undef MBX_RLEPSO_LAUNCH
+}
+
 extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
 {
     if (!b) return fail(MBX_E_ARG, "null batch");
@@ -547,15 +570,8 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 0, d_state_out,
                            d_reward_out, d_done_out);
-    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 1024)
-        hipLaunchKernelGGL(k_rlepso_step<1024>, dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
-    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 512)
-        hipLaunchKernelGGL(k_rlepso_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO)
-        hipLaunchKernelGGL(k_rlepso_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out, (const float*)nullptr, 0, (float*)nullptr);
+        launch_rlepso_step(b, (hipStream_t)stream, (const float*)d_actions, d_state_out, d_reward_out, d_done_out, nullptr, 0, nullptr);
     else if (b->cfg.algo == MBX_ALGO_DE)
         hipLaunchKernelGGL(k_de_sweep, dim3(b->B), dim3(kThreads), (size_t)cl_lds_doubles(1, b->cfg.np, b->cfg.dim, 1, 0) * sizeof(double),
                            (hipStream_t)stream, make_params(b), d_state_out, d_reward_out, d_done_out);
@@ -651,15 +667,7 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     if (!b || !d_table) return fail(MBX_E_ARG, "mbx_rlepso_act_step: bad arguments");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_act_step: the batch is not an RLEPSO batch");
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_act_step: a replay tape carries no policy draws; use mbx_step with recorded actions");
-    if (b->threads == 1024)
-        hipLaunchKernelGGL(k_rlepso_step<1024>, dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
-    else if (b->threads == 512)
-        hipLaunchKernelGGL(k_rlepso_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
-    else
-        hipLaunchKernelGGL(k_rlepso_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
-                           (const float*)nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
+    launch_rlepso_step(b, (hipStream_t)stream, nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

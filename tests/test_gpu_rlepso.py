@@ -440,3 +440,27 @@ def test_odd_dimension_single_coordinate_work_items(dim):
         st1, r, d = bt.step(torch.rand(B, adim, device='cuda'))
         assert torch.isfinite(st1).all() and torch.isfinite(r).all() and not torch.equal(st0, st1)
         bt.close()
+
+
+def test_compile_time_geometry_kernel_equals_generic_kernel(env, monkeypatch):
+    """NP = 100 / D = 10 / 5 groups runs an instantiation of k_rlepso_step with the geometry fixed at compile time; with
+    MBX_GENERIC_GEOMETRY=1 the batch keeps the run-time-geometry kernel.  Same arithmetic: every state word must be identical after
+    60 generations on all 24 functions (bbob) and on the noisy suite."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_RLEPSO
+    for suite in ('bbob', 'bbob-noisy'):
+        s, ids = env[suite]
+        B, G = 2 * len(ids), 60
+        pidx = np.arange(B) % len(ids)
+        seeds = np.arange(B, dtype=np.uint64) * 7919 + 11
+        actions = torch.rand(G, B, 35, generator=torch.Generator().manual_seed(3)).cuda()
+        states = []
+        for generic in ('0', '1'):
+            monkeypatch.setenv('MBX_GENERIC_GEOMETRY', generic)
+            batch = Batch(s, ALGO_RLEPSO, pidx, seeds, NP, MAXFES, LOGI, NLOG)
+            batch.reset()
+            for g in range(G):
+                batch.step(actions[g])
+            states.append(np.stack([batch.read_state(b) for b in range(B)]))
+            batch.close()
+        assert np.array_equal(states[0], states[1], equal_nan=True), suite
