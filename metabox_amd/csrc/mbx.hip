@@ -70,7 +70,8 @@ struct mbx_batch {
     int64_t tape_stride = 0;
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
-    bool fixed_geometry = false; // RLEPSO at NP = 100, D = 10, 5 groups: the compile-time-geometry instantiation of k_rlepso_step
+    int fixed_geometry = 0;      // RLEPSO: 1 = NP 100 / D 10 / 5 groups, 2 = NP 128 / D 40 / 5 groups (BASELINE configs 1-2 and 5): compile-time-geometry
+                                 // instantiations of k_rlepso_step; 0 = geometry read from the batch
 };
 
 // per-algorithm geometry
@@ -406,8 +407,10 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     // MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
     {
         const char* g = getenv("MBX_GENERIC_GEOMETRY");
-        b->fixed_geometry = cfg->algo == MBX_ALGO_RLEPSO && b->threads == kThreads && cfg->np == 100 && cfg->dim == 10 && cfg->n_group == 5 &&
-                            !(g && g[0] == '1');
+        if (cfg->algo == MBX_ALGO_RLEPSO && cfg->n_group == 5 && !(g && g[0] == '1')) {
+            if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 10) b->fixed_geometry = 1;
+            if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
+        }
     }
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
@@ -450,6 +453,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -520,9 +524,10 @@ static void launch_rlepso_step(mbx_batch* b, hipStream_t stream, const float* d_
 #define MBX_RLEPSO_LAUNCH(...)                                                                                                   \
     hipLaunchKernelGGL((k_rlepso_step<__VA_ARGS__>), dim3(b->B), dim3(b->threads), b->lds_bytes, stream, make_params(b), d_actions, \
                        d_state_out, d_reward_out, d_done_out, d_table, table_rows, d_actions_out)
-    if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024);
+    if (b->fixed_geometry == 1) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
+    else if (b->fixed_geometry == 2) MBX_RLEPSO_LAUNCH(1024, 128, 40, 5);
+    else if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024);
     else if (b->threads == 512) MBX_RLEPSO_LAUNCH(512);
-    else if (b->fixed_geometry) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
     else MBX_RLEPSO_LAUNCH(kThreads);
 #undef MBX_RLEPSO_LAUNCH
 }

@@ -443,24 +443,27 @@ def test_odd_dimension_single_coordinate_work_items(dim):
 
 
 def test_compile_time_geometry_kernel_equals_generic_kernel(env, monkeypatch):
-    """NP = 100 / D = 10 / 5 groups runs an instantiation of k_rlepso_step with the geometry fixed at compile time; with
-    MBX_GENERIC_GEOMETRY=1 the batch keeps the run-time-geometry kernel.  Same arithmetic: every state word must be identical after
-    60 generations on all 24 functions (bbob) and on the noisy suite."""
-    from metabox_amd.suite import Batch
+    """NP = 100 / D = 10 / 5 groups (BASELINE configs 1-2) and NP = 128 / D = 40 / 5 groups (config 5) run instantiations of
+    k_rlepso_step with the geometry fixed at compile time; with MBX_GENERIC_GEOMETRY=1 the batch keeps the run-time-geometry kernel.
+    Same arithmetic: every state word must be identical (60 generations on bbob and bbob-noisy at D = 10, 8 at D = 40)."""
+    from metabox_amd.suite import Batch, Suite
     from metabox_amd._abi import ALGO_RLEPSO
-    for suite in ('bbob', 'bbob-noisy'):
-        s, ids = env[suite]
-        B, G = 2 * len(ids), 60
-        pidx = np.arange(B) % len(ids)
+    c5 = [problems('bbob', 40)[k] for k in sorted(problems('bbob', 40))] + \
+         [problems('bbob-noisy', 40)[k] for k in sorted(problems('bbob-noisy', 40))]
+    cases = [(env['bbob'][0], 24, 2, 60, NP, MAXFES, LOGI), (env['bbob-noisy'][0], 30, 2, 60, NP, MAXFES, LOGI),
+             (Suite(c5), len(c5), 1, 8, 128, 80000, 1600)]
+    for s, n, reps, G, np_, maxfes, logi in cases:
+        B = reps * n
+        pidx = np.arange(B) % n
         seeds = np.arange(B, dtype=np.uint64) * 7919 + 11
         actions = torch.rand(G, B, 35, generator=torch.Generator().manual_seed(3)).cuda()
         states = []
         for generic in ('0', '1'):
             monkeypatch.setenv('MBX_GENERIC_GEOMETRY', generic)
-            batch = Batch(s, ALGO_RLEPSO, pidx, seeds, NP, MAXFES, LOGI, NLOG)
+            batch = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, logi, NLOG)
             batch.reset()
             for g in range(G):
                 batch.step(actions[g])
             states.append(np.stack([batch.read_state(b) for b in range(B)]))
             batch.close()
-        assert np.array_equal(states[0], states[1], equal_nan=True), suite
+        assert np.array_equal(states[0], states[1], equal_nan=True), (np_, n)
