@@ -70,8 +70,8 @@ struct mbx_batch {
     int64_t tape_stride = 0;
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
-    int fixed_geometry = 0;      // RLEPSO: 1 = NP 100 / D 10 / 5 groups, 2 = NP 128 / D 40 / 5 groups (BASELINE configs 1-2 and 5): compile-time-geometry
-                                 // instantiations of k_rlepso_step; 0 = geometry read from the batch
+    int fixed_geometry = 0;      // compile-time-geometry instantiation of the generation kernel for the BASELINE.json configs: 1 = RLEPSO NP 100 / D 10 /
+                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12; 0 = geometry read from the batch
 };
 
 // per-algorithm geometry
@@ -411,6 +411,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 10) b->fixed_geometry = 1;
             if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
         }
+        // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
+        if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
+        if (cfg->algo == MBX_ALGO_DEDDQN && cfg->np == 100 && cfg->dim == 12 && !(g && g[0] == '1')) b->fixed_geometry = 4;
     }
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
@@ -463,9 +466,11 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step<>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step<100, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_DE || cfg->algo == MBX_ALGO_PSO || cfg->algo == MBX_ALGO_CMAES) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_classic_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_de_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -599,14 +604,20 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
                            d_done_out, (float*)nullptr);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
-        if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
+        if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 3)
+            hipLaunchKernelGGL((k_lde_step<512, 50, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                               (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+        else if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
             hipLaunchKernelGGL(k_lde_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->cfg.algo == MBX_ALGO_LDE)
             hipLaunchKernelGGL(k_lde_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+        else if (b->fixed_geometry == 4)
+            hipLaunchKernelGGL((k_dq_step<100, 12>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                               (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
         else
-            hipLaunchKernelGGL(k_dq_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL(k_dq_step<>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
     }
     HIP_TRY(hipGetLastError());

@@ -185,12 +185,14 @@ __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ step
+// NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
+template <int NPC = 0, int DC = 0>
 __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int32_t* __restrict__ actions, double* __restrict__ state_out,
                                                       double* __restrict__ reward_out, uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
-    const int NP = bp.NP, D = bp.D;
+    const int NP = NPC ? NPC : bp.NP, D = DC ? DC : bp.D;
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_DQ_ST_SCALARS(NP, D);
     double* ex = S + MBX_DQ_ST_EXTRA(NP, D);

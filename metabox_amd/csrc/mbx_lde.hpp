@@ -146,14 +146,15 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ step
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_lde_step(BatchParams bp, const float* __restrict__ actions,
+// NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
+template <int THREADS, int NPC = 0, int DC = 0>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_lde_step(BatchParams bp, const float* __restrict__ actions,
                                                        double* __restrict__ state_out, double* __restrict__ reward_out,
                                                        uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
-    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    const int NP = NPC ? NPC : bp.NP, D = DC ? DC : bp.D, NE = NP * D;
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
     if (sc[MBX_SC_DONE] != 0.) {                                  // finished: state_out keeps the last features

@@ -158,3 +158,28 @@ def test_ddqn_batched_replay_training(tmp_path):
     assert all(torch.isfinite(q).all() for q in agent.q_net.parameters())
     assert os.path.exists(str(tmp_path / 'checkpoint2.pkl')) and os.path.getsize(str(tmp_path / 'checkpoint2.pkl')) < 2_000_000
     env.close()
+
+
+@pytest.mark.gpu
+def test_ddqn_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch):
+    """BASELINE config 4 (protein docking, NP = 100, D = 12) runs k_dq_step with the geometry fixed at compile time;
+    MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel.  Every state word must be identical after 300 steps."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_DEDDQN
+    from test_protein import protein
+    ps = list(protein()[0].values())[:6]
+    s = Suite(ps)
+    B, G = 2 * len(ps), 300
+    actions = torch.randint(0, 4, (G, B), generator=torch.Generator().manual_seed(4), dtype=torch.int32).cuda()
+    seeds = np.arange(B, dtype=np.uint64) * 17 + 2
+    states = []
+    for generic in ('0', '1'):
+        monkeypatch.setenv('MBX_GENERIC_GEOMETRY', generic)
+        b = Batch(s, ALGO_DEDDQN, np.arange(B) % len(ps), seeds, NP, 1000, 200, 5)
+        b.reset()
+        for g in range(G):
+            b.step(actions[g])
+        states.append(np.stack([b.read_state(k) for k in range(B)]))
+        b.close()
+    assert np.array_equal(states[0], states[1], equal_nan=True)

@@ -188,3 +188,24 @@ def test_lde_end_to_end_statistics_match_the_reference():
             assert sps.mannwhitneyu(fes[k], rf).pvalue > 1e-3, (f, fes[k].mean(), rf.mean())
         else:
             assert np.all(fes[k] == 20000)
+
+
+def test_lde_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch):
+    """BASELINE config 3 (NP = 50, D = 30) runs k_lde_step with the geometry fixed at compile time; MBX_GENERIC_GEOMETRY=1 keeps
+    the run-time-geometry kernel.  Every state word must be identical after 40 generations on the 30 noisy functions."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_LDE
+    s, ids = _suite('bbob-noisy', 30)
+    B, G, maxfes = len(ids), 40, 60000
+    actions = torch.rand(G, B, 2 * NP, generator=torch.Generator().manual_seed(8)).cuda()
+    seeds = np.arange(B, dtype=np.uint64) * 131 + 9
+    states = []
+    for generic in ('0', '1'):
+        monkeypatch.setenv('MBX_GENERIC_GEOMETRY', generic)
+        batch = Batch(s, ALGO_LDE, np.arange(B), seeds, NP, maxfes, maxfes // 50, 50)
+        batch.reset()
+        for g in range(G):
+            batch.step(actions[g])
+        states.append(np.stack([batch.read_state(b) for b in range(B)]))
+        batch.close()
+    assert np.array_equal(states[0], states[1], equal_nan=True)
