@@ -51,39 +51,45 @@ struct RlLds {
 
 __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_t)1; }
 
+// evaluator scratch Z: n*D doubles, at least 2 per thread for the block reductions, and room for the move phase's R1 | R2 | COEF
+__host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
+{
+    const int64_t NE = align2((int64_t)NP * D), need = 2 * kThreads > 2 * align2(NP) + 96 ? 2 * kThreads : 2 * align2(NP) + 96;
+    return align2(NE > need ? NE : need);
+}
+
 __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = align2((int64_t)D * D),
                   P = align2(NP), TS = eval_t_doubles(NP, D);
-    // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC; M1T, M2T;
-    // DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT, R1, R2: P each; COEF: 6*16; RED: 16; 3 int arrays
-    // (32.4 KB at NP = 100, D = 10: room for five workgroups per CU; the 99 VGPRs of k_rlepso_step make it four)
-    return TS + NE + SC + 2 * DD + 6 * P + 5 * align2(D) + 96 + 16 + 3 * align2((P + 1) / 2);
+    // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC (R1, R2 and COEF, which are
+    // dead before the first evaluation, live in it); M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT: P each; RED: 16;
+    // 3 int arrays  (29.8 KB at NP = 100, D = 10: five workgroups per CU)
+    return TS + NE + SC + 2 * DD + 4 * P + 5 * align2(D) + 16 + 3 * align2((P + 1) / 2);
 }
 
 __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = align2((int64_t)D * D),
                   P = align2(NP), TS = eval_t_doubles(NP, D);
     RlLds L;
     double* p = base;
     L.PB = p; L.T = p; p += TS;      // T reuses PB's storage (see rl_commit)
     L.X = p; p += NE;
-    L.Z = p; p += SC;
+    L.Z = p;
+    L.R1 = p; L.R2 = p + P; L.COEF = p + 2 * P;   // per-particle draws and group coefficients: last read in the move phase, Z first written by the evaluator
+    p += SC;
     L.M1T = p; p += DD;
     L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);
     L.V0 = p; p += align2(D);
     L.V1 = p; p += align2(D);
     L.V2 = p; p += align2(D);
-    L.R1 = p; p += P;
-    L.R2 = p; p += P;
     L.PBC = p; p += P;
     L.NC = p; p += P;
     L.PNI = p; p += P;
     L.CMUT = p; p += P;
     L.GB = p; p += align2(D);
-    L.COEF = p; p += 96;
     L.RED = p; p += 16;
     L.IMPR = (int*)p; p += align2((P + 1) / 2);
     L.MASK = (int*)p; p += align2((P + 1) / 2);
@@ -171,6 +177,11 @@ __device__ unsigned long long g_phase_cycles[8192 * 16];         // [block][phas
 #define MBX_PHASE(k)
 #endif
 
+// 256-thread workgroups: 29.8 KB of LDS lets five of them share a CU, so cap the registers at 96 for five waves per SIMD (-5.7 % against
+// four; two VGPRs spill).  The 512- / 1024-thread instantiations own their CU and only need the four waves per SIMD a 1024-thread workgroup is.
+#ifndef MBX_RL_WAVES
+#define MBX_RL_WAVES __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 5 : 4)))
+#endif
 #ifndef MBX_FDR_UNROLL
 #define MBX_FDR_UNROLL 4
 #endif
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double
 // geometry (NP = 100 hard-coded in rlepso_optimizer.py:9, n_group = 5, and the D = 10 of its bbob configs) gets an instantiation of
 // its own: index arithmetic, the divisions by D and the short D-loops of the evaluator fold into constants (-8 % per generation).
 template <int THREADS, int NPC = 0, int DC = 0, int GC = 0>
-__global__ __launch_bounds__(THREADS) void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
+__global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
                                                           double* __restrict__ state_out, double* __restrict__ reward_out,
                                                           uint8_t* __restrict__ done_out, const float* __restrict__ policy_table,
                                                           int table_rows, float* __restrict__ actions_out)
