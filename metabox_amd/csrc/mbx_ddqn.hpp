@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
     // ---- stage records, cost vector, problem constants
     for (int k = tid; k < kDqRec; k += kThreads) L.REC[k] = S[MBX_DQ_ST_NTOT(NP, D) + k];
     for (int i = tid; i < NP; i += kThreads) L.COST[i] = S[MBX_DQ_ST_COST(NP, D) + i];
-    stage_problem(P, L.eval());
+    stage_problem<eval_dc(DC)>(P, L.eval());
     double* PRE = L.MISC + 8;            // prebest position used by the features (after a possible re-bind)
     double* GBP = PRE + align2(D) ;      // gbest position used by mutation / features
     __syncthreads();
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
         L.X[d] = fmin(fmax(v, lb), ub);
     }
     __syncthreads();
-    eval_rows(P, L.eval(), 1);
+    eval_rows<eval_dc(DC)>(P, L.eval(), 1);
     // ---- median of the current costs (:171) by rank counting
     for (int i = tid; i < NP; i += kThreads) {
         const double ci = L.COST[i];

@@ -232,9 +232,13 @@ struct EvalLds {
 
 // Stage the per-problem constants (two D x D maps, transposed so that lanes differing in d read consecutive
 // LDS words, and the four D-vectors) from global memory into LDS.  Caller synchronises afterwards.
+// DC: the dimension as a compile-time constant (0 = P.dim), for the compile-time-geometry instantiations of the generation kernels
+// (only small dimensions are handed down: with D = 30 / 40 the fully unrolled D-loops of the evaluator spill registers)
+constexpr int eval_dc(int dc) { return dc <= 16 ? dc : 0; }
+template <int DC = 0>
 __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds& L)
 {
-    const int D = P.dim;
+    const int D = DC ? DC : P.dim;
     const FastDiv fd(D);
     for (int t = threadIdx.x; t < D * D; t += MBX_NT) {
         const int d = fd.div(t), k = t - d * D;
@@ -284,9 +288,10 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // n^2 atom pairs are spread over the block (pair index == address in the [n,n] tables: coalesced L2 reads) and the
 // energy mean_j sum_i term_ij = (sum of all terms)/n is reduced with wave shuffles.
 // P.v0 = 1/sqrt(eigval), P.py = basis [D,3n], P.pc = coor_init [3n], P.pw = sqrt(e) | q | r tables.
+template <int DC = 0>
 __device__ void eval_rows_protein(const DevProblem& P, const EvalLds& L, int n_rows)
 {
-    const int D = P.dim, n = P.n_peaks, m3 = 3 * n, tid = threadIdx.x;
+    const int D = DC ? DC : P.dim, n = P.n_peaks, m3 = 3 * n, tid = threadIdx.x;
     double* COOR = L.Z;
     double* P2 = L.Z + ((m3 + 1) & ~1);
     double* RED = P2 + ((n + 1) & ~1);
@@ -327,10 +332,11 @@ __device__ void eval_rows_protein(const DevProblem& P, const EvalLds& L, int n_r
 // (the value F*.func returns).  All arrays of `L` live in LDS; stage_problem() must have been called.
 // Must be called by every thread of the block.
 // ------------------------------------------------------------------------------------------------
+template <int DC = 0>
 __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
 {
-    if (P.kind == MBX_KIND_PROTEIN) { eval_rows_protein(P, L, n); return; }
-    const int D = P.dim, NE = n * D, kind = P.kind, tid = threadIdx.x;
+    if (P.kind == MBX_KIND_PROTEIN) { eval_rows_protein<DC>(P, L, n); return; }
+    const int D = DC ? DC : P.dim, NE = n * D, kind = P.kind, tid = threadIdx.x;
     const double ub = P.ub, bias = P.bias;
     const double* X = L.X;
     double* Z = L.Z;
@@ -618,6 +624,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
 // cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
 // rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
 // (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
+template <int DC = 0>
 __device__ __forceinline__ void population_costs(const DevProblem& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
@@ -625,7 +632,7 @@ __device__ __forceinline__ void population_costs(const DevProblem& P, const Eval
     for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
     __syncthreads();
 #else
-    eval_rows(P, L, n);
+    eval_rows<DC>(P, L, n);
 #endif
     for (int i = threadIdx.x; i < n; i += MBX_NT) {
         double f = L.F[i];

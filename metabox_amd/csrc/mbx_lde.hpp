@@ -176,7 +176,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     for (int e = tid; e < NE; e += MBX_NT) L.P[e] = gPop[e];
     for (int i = tid; i < NP; i += MBX_NT) L.FIT[i] = S[MBX_LDE_ST_FIT(NP, D) + i];
     if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
-    stage_problem(P, L.eval());
+    stage_problem<eval_dc(DC)>(P, L.eval());
     // p-best bound (:101-105): p = max(0, (P_MIN - P_INI) fes/maxFEs + P_INI), P_MIN = 2/NP, P_INI = 1
     const double p_rate = (2. / NP - 1) * fes / bp.max_fes + 1;
     const int bound = (int)ceil(NP * fmax(0., p_rate));
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         L.X[e] = c;
     }
     __syncthreads();
-    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
 
     // ---- selection (:55-59): offspring survives when it is better than or equal to its parent

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
-    stage_problem(P, L.eval());
+    stage_problem<eval_dc(DC)>(P, L.eval());
     // __get_coe (:112-132): float32 arithmetic (numpy >= 2 keeps float32 for scalar*python-float), group g
     // reads actions[g*n_group : g*n_group+7]
     auto get_coe = [&](const float* a) {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
     MBX_PHASE(3);                                                 // move (draws, exemplars, FDR scan, velocity)
 
     // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
-    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     MBX_PHASE(4);                                                 // evaluation
     fes += NP;
     rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         }
         __syncthreads();
         // the whole population is re-evaluated but only the re-initialised particles are billed (:141-143)
-        population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+        population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
         fes += n_reinit;
         rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
     }
