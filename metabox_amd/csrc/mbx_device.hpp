@@ -377,6 +377,31 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         double bkey[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bk[4] = {0, 0, 0, 0};
         double* TY = T; double* TC = T + CH * D; double* TW = T + 2 * CH * D;
+        if constexpr (DC > 0) {
+            // compile-time dimension: a row of z stays in registers and the peak tables never touch LDS -- the peak index is
+            // wave-uniform, so y_k, C_k and log w_k are read from the constant address space, i.e. as scalar loads into SGPRs
+            // that the vector ALU takes as operands (the LDS route above spends 10 broadcast ds_read_b128 per (row, peak) and is
+            // LDS-bandwidth bound).  Same visiting order, same arithmetic, same tie rule.
+            typedef const double __attribute__((address_space(4)))* kptr;
+            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                if (i < n) {
+                    double rx[DC > 0 ? DC : 1];
+#pragma unroll
+                    for (int d = 0; d < DC; ++d) rx[d] = Z[i * DC + d];
+                    for (int kk = wv; kk < npk; kk += MBX_NW) {
+                        double acc = 0.;
+#pragma unroll
+                        for (int d = 0; d < DC; ++d) { const double zd = rx[d] - py[kk * DC + d]; acc += pcc[kk * DC + d] * (zd * zd); }
+                        const double key = plw[kk] + cexp * acc;
+                        if (key > bkey[q]) { bkey[q] = key; bk[q] = kk; }
+                    }
+                }
+            }
+        } else
         for (int c0 = 0; c0 < npk; c0 += CH) {
             const int cn = npk - c0 < CH ? npk - c0 : CH;
             for (int t = tid; t < cn * D; t += MBX_NT) { TY[t] = P.pyr[c0 * D + t]; TC[t] = P.pc[c0 * D + t]; }
