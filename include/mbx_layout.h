@@ -73,7 +73,7 @@
  *
  *   site                 index        words
  *   MBX_SITE_ELEM_A      e = i*D+d    u53(w0,w1) = clpso_u[e];  mulhi(w2,NP), mulhi(w3,NP) = tournament pair
- *   MBX_SITE_ELEM_B      e            u53(w0,w1) = fdr_u[e]
+ *   MBX_SITE_ELEM_B      e >> 1       u53(w0,w1) = fdr_u[e] for even e, u53(w2,w3) = fdr_u[e] for odd e (one call per element pair)
  *   MBX_SITE_PART        i            u53(w0,w1) = rand1[i];    u53(w2,w3) = rand2[i]
  *   MBX_SITE_REINIT      i            u53(w0,w1) = reinit_u[i]
  *   MBX_SITE_ELEM_R      e            u53(w0,w1) = pos_u[e];    u53(w2,w3) = vel_u[e]   (init + reinit)

@@ -66,8 +66,11 @@ struct U4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
+#ifndef MBX_PHILOX_ROUNDS
+#define MBX_PHILOX_ROUNDS 10      // anything else is a timing experiment (tools/kbench.py), never a shipped build
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MBX_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)MBX_PHILOX_M0 * c0, p1 = (uint64_t)MBX_PHILOX_M1 * c2;   // one v_mad_u64_u32 each
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;

@@ -216,6 +216,13 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
     const double r1 = L.R1[i], r2 = L.R2[i], fi = L.PBC[i], pci = c.bp.pci[i];
     double uc[W], uf[W], cur[W], vel[W], pp[W], v_clpso[W];
     int t1[W], t2[W];
+    if (!c.tape) {
+        // one Philox call carries the FDR weights of an element PAIR (site ELEM_B, index e >> 1: words 0-1 for the even element,
+        // 2-3 for the odd one); a two-coordinate work item starts on an even element (D even, d0 even)
+        const U4 w = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_ELEM_B);
+        if (W == 2) { uf[0] = u53(w.x, w.y); uf[W - 1] = u53(w.z, w.w); }
+        else uf[0] = (e0 & 1) ? u53(w.z, w.w) : u53(w.x, w.y);
+    }
 #pragma unroll
     for (int q = 0; q < W; ++q) {
         const int e = e0 + q;
@@ -224,9 +231,8 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
             t1[q] = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2[q] = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1];
             uf[q] = c.tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e];
         } else {
-            U4 w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc[q] = u53(w.x, w.y);
+            const U4 w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc[q] = u53(w.x, w.y);
             t1[q] = (int)__umulhi(w.z, (uint32_t)NP); t2[q] = (int)__umulhi(w.w, (uint32_t)NP);
-            w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_B); uf[q] = u53(w.x, w.y);
         }
         // position and velocity come straight from HBM: the loads are issued here and first used after the FDR scan below, which
         // hides their latency (they are no longer staged through LDS by the prologue)
