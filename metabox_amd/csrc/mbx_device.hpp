@@ -236,8 +236,11 @@ struct EvalLds {
 // Stage the per-problem constants (two D x D maps, transposed so that lanes differing in d read consecutive
 // LDS words, and the four D-vectors) from global memory into LDS.  Caller synchronises afterwards.
 // DC: the dimension as a compile-time constant (0 = P.dim), for the compile-time-geometry instantiations of the generation kernels
+#ifndef MBX_EVAL_DC_MAX
+#define MBX_EVAL_DC_MAX 16
+#endif
 // (only small dimensions are handed down: with D = 30 / 40 the fully unrolled D-loops of the evaluator spill registers)
-constexpr int eval_dc(int dc) { return dc <= 16 ? dc : 0; }
+constexpr int eval_dc(int dc) { return dc <= MBX_EVAL_DC_MAX ? dc : 0; }
 template <int DC = 0>
 __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds& L)
 {
@@ -380,7 +383,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         double bkey[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bk[4] = {0, 0, 0, 0};
         double* TY = T; double* TC = T + CH * D; double* TW = T + 2 * CH * D;
-        if constexpr (DC > 0) {
+        if constexpr (DC > 0 && DC <= 16) {
             // compile-time dimension: a row of z stays in registers and the peak tables never touch LDS -- the peak index is
             // wave-uniform, so y_k, C_k and log w_k are read from the constant address space, i.e. as scalar loads into SGPRs
             // that the vector ALU takes as operands (the LDS route above spends 10 broadcast ds_read_b128 per (row, peak) and is
