@@ -71,7 +71,7 @@ struct mbx_batch {
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
     int fixed_geometry = 0;      // compile-time-geometry instantiation of the generation kernel for the BASELINE.json configs: 1 = RLEPSO NP 100 / D 10 /
-                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12; 0 = geometry read from the batch
+                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10; 0 = geometry read from the batch
 };
 
 // per-algorithm geometry
@@ -414,6 +414,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
         if (cfg->algo == MBX_ALGO_DEDDQN && cfg->np == 100 && cfg->dim == 12 && !(g && g[0] == '1')) b->fixed_geometry = 4;
+        if (cfg->algo == MBX_ALGO_GLEET && cfg->np == 100 && cfg->dim == 10 && !(g && g[0] == '1')) b->fixed_geometry = 5;
     }
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
@@ -482,7 +483,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_qlpso_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_GLEET) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_step<>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gleet_step<100, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_RLPSO) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlpso_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -595,8 +597,11 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
         hipLaunchKernelGGL(k_qlpso_step<false>, dim3(b->B), dim3(kThreads), (size_t)ql_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double),
                            (hipStream_t)stream, make_params(b), (const int32_t*)d_actions, (const double*)nullptr, 1, d_state_out,
                            d_reward_out, d_done_out, (int32_t*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_GLEET && b->fixed_geometry == 5)
+        hipLaunchKernelGGL((k_gleet_step<100, 10>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                           (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
     else if (b->cfg.algo == MBX_ALGO_GLEET)
-        hipLaunchKernelGGL(k_gleet_step, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+        hipLaunchKernelGGL(k_gleet_step<>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                            (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
     else if (b->cfg.algo == MBX_ALGO_RLPSO)
         hipLaunchKernelGGL(k_rlpso_step<false>, dim3(b->B), dim3(kThreads), (size_t)rp_lds_doubles(1, b->cfg.dim, 0) * sizeof(double),

@@ -116,12 +116,14 @@ __global__ __launch_bounds__(kThreads) void k_gleet_reset(BatchParams bp, double
 }
 
 // ------------------------------------------------------------------------------------------------ step (update :187-314)
+// NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
+template <int NPC = 0, int DC = 0>
 __global__ __launch_bounds__(kThreads) void k_gleet_step(BatchParams bp, const float* __restrict__ actions, double* __restrict__ state_out,
                                                          double* __restrict__ reward_out, uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
-    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    const int NP = NPC ? NPC : bp.NP, D = DC ? DC : bp.D, NE = NP * D;
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_GLEET_ST_SCALARS(NP, D);
     if (sc[MBX_SC_DONE] != 0.) {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void k_gleet_step(BatchParams bp, const f
     double no_improve = sc[MBX_SC_GLEET_NOIMPROVE];
     const double fes = sc[MBX_SC_FES] + NP;
 
-    stage_problem(P, L.eval());
+    stage_problem<eval_dc(DC)>(P, L.eval());
     if (tid < D) L.GB[tid] = S[MBX_GLEET_ST_GBPOS(NP, D) + tid];
     if (tid < NP) {                                                 // :200-201, 206-210: float32 products c*a and c*(1-a), then float64
         double r1, r2;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void k_gleet_step(BatchParams bp, const f
         gVel[e] = nv; gPos[e] = nx; L.X[e] = nx;
     }
     __syncthreads();
-    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_GLEET_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_GLEET_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
 
     // ---- pbest / stagnation per particle (:236-266); thread i owns particle i
     double ccost = 0., pbest = 0., pni = 0.;

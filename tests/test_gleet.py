@@ -269,3 +269,28 @@ def test_gleet_batched_ppo_updates_the_policy(tmp_path):
     import os
     assert os.path.exists(str(tmp_path / 'checkpoint1.pkl'))            # save_interval = 4 learning steps
     env.close()
+
+
+@pytest.mark.gpu
+def test_gleet_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch):
+    """NP = 100 / D = 10 runs k_gleet_step with the geometry fixed at compile time; MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry
+    kernel.  Every state word (and every feature row handed to the policy) must be identical after 40 generations on the noisy suite."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    ps = problems('bbob-noisy', 10)
+    ids = sorted(ps)
+    s = Suite([ps[i] for i in ids])
+    B, G = len(ids), 40
+    actions = torch.rand(G, B, NP, generator=torch.Generator().manual_seed(6)).cuda()
+    seeds = np.arange(B, dtype=np.uint64) * 29 + 3
+    states, feats = [], []
+    for generic in ('0', '1'):
+        monkeypatch.setenv('MBX_GENERIC_GEOMETRY', generic)
+        b = Batch(s, ALGO_GLEET, np.arange(B), seeds, NP, 20000, 400, 50)
+        b.reset()
+        for g in range(G):
+            st, _, _ = b.step(actions[g])
+        feats.append(st.cpu().numpy().copy())
+        states.append(np.stack([b.read_state(k) for k in range(B)]))
+        b.close()
+    assert np.array_equal(states[0], states[1], equal_nan=True) and np.array_equal(feats[0], feats[1], equal_nan=True)
