@@ -262,6 +262,29 @@ __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds
 // Out[i][d] = sum_k M[d][k] * In[i][k]   (the matmul of sr_func, bbob.py:6-8), k ascending, no FMA contraction
 __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, int n, int D, double* Out)
 {
+    if ((D & 1) == 0) {
+        // Register tile of 2 rows x 2 dimensions per thread: the plain loop below reads 16 bytes of LDS per multiply-add (M[d][k] and
+        // In[i][k]) and is LDS-bandwidth bound (128 B/clk per CU feed 8 MAC/clk, the four SIMDs could issue 32); the tile reads one
+        // 16-byte pair of M and two row values per four multiply-adds, 8 bytes each.  Every output keeps its own k-ascending sum.
+        const int HD = D >> 1, tiles = ((n + 1) >> 1) * HD;
+        const FastDiv fh(HD);
+        for (int t = threadIdx.x; t < tiles; t += MBX_NT) {
+            const int rp = fh.div(t), d = 2 * (t - rp * HD), i0 = 2 * rp;
+            const bool two = i0 + 1 < n;
+            const double* r0 = In + i0 * D;
+            const double* r1 = two ? r0 + D : r0;
+            const double* col = MT + d;
+            double s00 = 0., s01 = 0., s10 = 0., s11 = 0.;
+#pragma unroll 5
+            for (int k = 0; k < D; ++k) {
+                const double m0 = col[k * D], m1 = col[k * D + 1], y0 = r0[k], y1 = r1[k];
+                s00 += m0 * y0; s01 += m1 * y0; s10 += m0 * y1; s11 += m1 * y1;
+            }
+            Out[i0 * D + d] = s00; Out[i0 * D + d + 1] = s01;
+            if (two) { Out[(i0 + 1) * D + d] = s10; Out[(i0 + 1) * D + d + 1] = s11; }
+        }
+        return;
+    }
     const int NE = n * D;
     const FastDiv fd(D);
     for (int e = threadIdx.x; e < NE; e += MBX_NT) {
