@@ -146,9 +146,12 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ step
+#ifndef MBX_LDE_WAVES
+#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int THREADS, int NPC = 0, int DC = 0>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_lde_step(BatchParams bp, const float* __restrict__ actions,
+__global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams bp, const float* __restrict__ actions,
                                                        double* __restrict__ state_out, double* __restrict__ reward_out,
                                                        uint8_t* __restrict__ done_out)
 {
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         return;
     }
     const DevProblem P = bp.problems[bp.problem_idx[b]];
+    MBX_PHASE_BEGIN
     const LdeLds L = lde_carve(smem, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const float* act = actions + (int64_t)b * (2 * NP);
@@ -200,10 +204,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         L.SF[i] = (double)sf32; L.CR[i] = (double)act[NP + i];
     }
     __syncthreads();
+    MBX_PHASE(0);                                                 // staging + per-individual draws
     // histogram of the pre-update (sorted) fitness: appended to past_histo at :186
     lde_norm_hist(L.FIT, NP, nullptr, L.HIST);
     int my_hist = tid < MBX_LDE_BINS ? L.HIST[tid] : 0;
 
+    MBX_PHASE(1);                                                 // histogram of the parents
     // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
     const FastDiv fd(D);
     for (int e = tid; e < NE; e += MBX_NT) {
@@ -225,8 +231,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         L.X[e] = c;
     }
     __syncthreads();
+    MBX_PHASE(2);                                                 // mutation + crossover
     population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
+    MBX_PHASE(3);                                                 // evaluation
 
     // ---- selection (:55-59): offspring survives when it is better than or equal to its parent
     const double bsf = L.FIT[0];                                   // population is sorted: minimum first
@@ -242,8 +250,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
     if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
     __syncthreads();
+    MBX_PHASE(4);                                                 // selection, survivors, argmin
     lde_sort_emit(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, hcount + 1, state_out + (int64_t)b * (NP + 10));
 
+    MBX_PHASE(5);                                                 // sort + write-back + features
     if (tid == 0) {
         const double reward = (bsf - bsf_next) / bsf;             // :170
         int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
