@@ -84,11 +84,25 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
                                               double hcount, double* state_out)
 {
     const int tid = threadIdx.x;
+    // stable rank of every individual; the NP x NP comparisons are spread over the whole workgroup (thread (i, part) counts over a
+    // slice of j, partial counts meet in LDS) instead of NP threads walking NP entries each
+    for (int i = tid; i < NP; i += MBX_NT) L.PIDX[i] = 0;
+    __syncthreads();
+    {
+        const int parts = MBX_NT / NP > 0 ? MBX_NT / NP : 1;
+        for (int w = tid; w < parts * NP; w += MBX_NT) {
+            const int part = w / NP, i = w - part * NP;
+            const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
+            const double fi = L.FIT[i];
+            int cnt = 0;
+            for (int j = j0; j < j1; ++j) { const double fj = L.FIT[j]; cnt += (fj < fi) || (fj == fi && j < i); }
+            if (cnt) atomicAdd(&L.PIDX[i], cnt);
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < NP; i += MBX_NT) {
         const double fi = L.FIT[i];
-        int rank = 0;
-        for (int j = 0; j < NP; ++j) { const double fj = L.FIT[j]; rank += (fj < fi) || (fj == fi && j < i); }
-        L.PIDX[i] = rank;
+        const int rank = L.PIDX[i];
         L.SORTED[rank] = fi;
         gFit[rank] = fi;
     }
@@ -212,13 +226,18 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     MBX_PHASE(1);                                                 // histogram of the parents
     // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
     const FastDiv fd(D);
-    for (int e = tid; e < NE; e += MBX_NT) {
+    // The parents' storage doubles as evaluator scratch; a thread's own (up to four) parent coordinates stay in registers across the
+    // evaluation, so the rows that lose the selection need no second trip to HBM (larger populations re-read them).
+    const bool kept = NE <= 4 * MBX_NT;
+    double keep[4] = {0., 0., 0., 0.};
+    for (int e = tid, q = 0; e < NE; e += MBX_NT, ++q) {
         const int i = fd.div(e), d = e - i * D;
         double u;
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
         else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
         if (d == L.JR[i]) u = 0.;
         const double xi = L.P[e], sf = L.SF[i], om = (double)(1.f - (float)sf);      // 1 - sf in float32, like the policy's tensor
+        if (kept) { if (q == 0) keep[0] = xi; else if (q == 1) keep[1] = xi; else if (q == 2) keep[2] = xi; else keep[3] = xi; }
         const int pidx = L.PIDX[i];
         double m;
         if (pidx == i) m = xi;
@@ -244,8 +263,11 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
         if (surv) L.FIT[i] = L.NC[i];
     }
     __syncthreads();
-    // survivors take the trial vector; the other rows are re-read from HBM (P's storage served as evaluator scratch meanwhile)
-    for (int e = tid; e < NE; e += MBX_NT) L.P[e] = L.R0[fd.div(e)] ? L.X[e] : gPop[e];
+    // survivors take the trial vector; the other rows come back from the registers above (P's storage served as evaluator scratch meanwhile)
+    for (int e = tid, q = 0; e < NE; e += MBX_NT, ++q) {
+        const double parent = !kept ? gPop[e] : q == 0 ? keep[0] : q == 1 ? keep[1] : q == 2 ? keep[2] : keep[3];
+        L.P[e] = L.R0[fd.div(e)] ? L.X[e] : parent;
+    }
     double bsf_next; int bi;
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
     if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }

@@ -18,7 +18,9 @@ PH = '--phases' in sys.argv
 groups = {'all 30': ids, 'F128-130 Gallagher': [128, 129, 130], 'without Gallagher': [i for i in ids if i < 128]}
 for k in range(101, 128, 3):
     groups[f'F{k}-{k + 2} {ps[ids.index(k)]}'] = [k, k + 1, k + 2]
+only = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--only=')]
 for name, grp in groups.items():
+    if only and not any(o in name for o in only): continue
     sel = [ids.index(f) for f in grp]
     pidx = np.array([sel[i % len(sel)] for i in range(B)], dtype=np.int32)
     b = Batch(suite, ALGO_LDE, pidx, np.arange(B, dtype=np.uint64) + 7, NP, 60000, 1200, 50, early_stop=False)
