@@ -22,7 +22,7 @@ __host__ __device__ inline int64_t lde_lds_doubles(int NP, int D)
     const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
                   P = align2(NP), PI = align2((P + 1) / 2);
     const int64_t TS = eval_t_doubles(NP, D), PT = NE > TS ? NE : TS;     // parents and the evaluator's scratch T share storage
-    return NE + PT + SC + 2 * DD + 4 * align2(D) + 4 * P + 16 + 8 + 4 * PI + 8;
+    return NE + PT + SC + 2 * DD + 4 * align2(D) + 2 * P + 16 + 8 + 4 * PI + 8;      // SF and CR live in Z (SC >= 512 >= 2 P)
 }
 
 __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
@@ -38,7 +38,8 @@ __device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
     L.P = p; L.T = p; p += NE > TS ? NE : TS;  L.X = p; p += NE;  L.Z = p; p += SC;
     L.M1T = p; p += DD;  L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
-    L.FIT = p; p += P;  L.NC = p; p += P;  L.SF = p; p += P;  L.CR = p; p += P;
+    L.FIT = p; p += P;  L.NC = p; p += P;
+    L.SF = L.Z;  L.CR = L.Z + P;                                 // scale factors / crossover rates: last read by the mutation, Z first written by the evaluator
     L.SORTED = L.NC;                                             // the trials' costs are dead once the selection is done
     L.RED = p; p += 16;  L.HS = p; p += 8;
     L.PIDX = (int*)p; p += PI;  L.R0 = (int*)p; p += PI;  L.R1 = (int*)p; p += PI;  L.JR = (int*)p; p += PI;
@@ -160,8 +161,11 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ step
+// Six waves per SIMD (80 VGPRs): at NP = 50, D = 30 the 512-thread workgroup needs 53.2 KB of LDS, so three of them share a CU (24 waves).
+// The generic kernel fits in 72 VGPRs; the compile-time-geometry instantiation spills (55 VGPRs) and is still the faster one
+// (all 30 noisy functions, 16 384 instances: 792 us at two resident workgroups -> 627 us at three).
 #ifndef MBX_LDE_WAVES
-#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(6)))
 #endif
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int THREADS, int NPC = 0, int DC = 0>
