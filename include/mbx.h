@@ -239,6 +239,11 @@ int mbx_qlpso_rollout(mbx_batch* b, const double* d_q_table, int n_steps, int32_
  * op: 0 log, 1 exp, 2 sin, 3 cos, 4 pow(x, y), 5 T_osz(x) (bbob.py:51-67), 6 T_asy(x; beta_lin = y) (bbob.py:70-82). */
 int mbx_debug_math(int op, const double* d_x, const double* d_y, double* d_out, int n, void* stream);
 
+/* Diagnostics: how the generation kernel of this batch is launched.  out[0] = threads per workgroup, out[1] = dynamic LDS bytes per
+ * workgroup, out[2] = compile-time-geometry instantiation in use (0 = run-time geometry), out[3] = doubles of
+ * state per instance.  Host-only, no device work. */
+int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4]);
+
 const char* mbx_last_error(void);
 const char* mbx_version(void);
 

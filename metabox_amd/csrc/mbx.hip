@@ -778,6 +778,13 @@ __global__ void k_debug_math(int op, const double* __restrict__ x, const double*
     out[i] = r;
 }
 
+extern "C" int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4])
+{
+    if (!b || !out) return fail(MBX_E_ARG, "mbx_batch_launch_info: bad arguments");
+    out[0] = b->threads; out[1] = (int32_t)b->lds_bytes; out[2] = b->fixed_geometry; out[3] = (int32_t)b->state_stride;
+    return MBX_OK;
+}
+
 extern "C" int mbx_debug_math(int op, const double* d_x, const double* d_y, double* d_out, int n, void* stream)
 {
     if (op < 0 || op > 6 || !d_x || !d_out || n < 0 || ((op == 4 || op == 6) && !d_y)) return fail(MBX_E_ARG, "mbx_debug_math: bad arguments");

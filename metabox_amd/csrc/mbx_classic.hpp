@@ -12,6 +12,11 @@
 #include "mbx_rlepso.hpp"   // BatchParams, align2, log_and_terminate
 
 namespace mbx {
+// four waves per SIMD: left alone the compiler takes 126-160 VGPRs for the multi-step / sweep kernels (three resident workgroups per CU
+// although the LDS would hold five); capped at 128 they spill little or nothing (QLPSO rollout 82 -> 69 us, RL-PSO rollout 60 -> 53 us per step)
+#ifndef MBX_N4_WAVES
+#define MBX_N4_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 
 struct ClLds {
     double *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *NC, *RED, *POP, *COST, *GB, *SC, *C, *B, *VEC;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void k_classic_reset(BatchParams bp, int 
 }
 
 // ------------------------------------------------------------------------------------------------ DE sweep (deap_de.py:48-82)
-__global__ __launch_bounds__(kThreads) void k_de_sweep(BatchParams bp, double* __restrict__ state_out, double* __restrict__ reward_out,
+__global__ __launch_bounds__(kThreads) MBX_N4_WAVES void k_de_sweep(BatchParams bp, double* __restrict__ state_out, double* __restrict__ reward_out,
                                                        uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void k_de_sweep(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ PSO sweep (deap_pso.py:31-48, 89-120)
-__global__ __launch_bounds__(kThreads) void k_pso_sweep(BatchParams bp, double* __restrict__ state_out, double* __restrict__ reward_out,
+__global__ __launch_bounds__(kThreads) MBX_N4_WAVES void k_pso_sweep(BatchParams bp, double* __restrict__ state_out, double* __restrict__ reward_out,
                                                         uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];

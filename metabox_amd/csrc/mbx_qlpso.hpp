@@ -12,6 +12,11 @@
 #include "mbx_rlepso.hpp"   // BatchParams, align2
 
 namespace mbx {
+// four waves per SIMD: left alone the compiler takes 126-160 VGPRs for the multi-step / sweep kernels (three resident workgroups per CU
+// although the LDS would hold five); capped at 128 they spill little or nothing (QLPSO rollout 82 -> 69 us, RL-PSO rollout 60 -> 53 us per step)
+#ifndef MBX_N4_WAVES
+#define MBX_N4_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 
 // np.add.reduce over n <= 128 contiguous values produced by elem(k): 8 accumulators, then the tail (numpy's pairwise_sum).
 template <class F>
@@ -159,7 +164,7 @@ __device__ __forceinline__ int ql_choose(const double* __restrict__ q_row, doubl
 // MULTI = false: exactly one step (mbx_step, or a one-step rollout); MULTI = true: the n_steps loop (see mbx_rlpso.hpp for why the
 // two are separate instantiations).
 template <bool MULTI>
-__global__ __launch_bounds__(kThreads) void k_qlpso_step(BatchParams bp, const int32_t* __restrict__ actions, const double* __restrict__ q_table,
+__global__ __launch_bounds__(kThreads) MBX_N4_WAVES void k_qlpso_step(BatchParams bp, const int32_t* __restrict__ actions, const double* __restrict__ q_table,
                                                          int n_steps, double* __restrict__ state_out, double* __restrict__ reward_out,
                                                          uint8_t* __restrict__ done_out, int32_t* __restrict__ actions_out)
 {

@@ -15,6 +15,11 @@
 #include "mbx_rlepso.hpp"   // BatchParams, align2, GaussMlp, sample_normal
 
 namespace mbx {
+// four waves per SIMD: left alone the compiler takes 126-160 VGPRs for the multi-step / sweep kernels (three resident workgroups per CU
+// although the LDS would hold five); capped at 128 they spill little or nothing (QLPSO rollout 82 -> 69 us, RL-PSO rollout 60 -> 53 us per step)
+#ifndef MBX_N4_WAVES
+#define MBX_N4_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 
 struct RpLds {
     double *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *NC, *RED, *GB, *XC, *SC;
@@ -150,7 +155,7 @@ __device__ __forceinline__ float rp_policy(const GaussMlp& net, const RpLds& L, 
 // MULTI = false: exactly one step, no loop -- 82 VGPRs; MULTI = true: the n_steps loop, in which the evaluator's loop-invariant
 // address arithmetic gets hoisted and stays live across iterations (141 VGPRs, 3 waves per SIMD instead of 5).
 template <bool MULTI>
-__global__ __launch_bounds__(kThreads) void k_rlpso_step(BatchParams bp, const float* __restrict__ actions, GaussMlp net, int n_steps,
+__global__ __launch_bounds__(kThreads) MBX_N4_WAVES void k_rlpso_step(BatchParams bp, const float* __restrict__ actions, GaussMlp net, int n_steps,
                                                          double* __restrict__ state_out, double* __restrict__ reward_out,
                                                          uint8_t* __restrict__ done_out, float* __restrict__ actions_out)
 {

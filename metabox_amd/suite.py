@@ -238,6 +238,13 @@ class Batch:
         _abi.check(self.lib.mbx_debug_read_state(self._h, int(instance), out.ctypes.data_as(_abi.c_double_p)))
         return out
 
+    def launch_info(self):
+        """How the generation kernel is launched: threads per workgroup, LDS bytes, compile-time-geometry id, state doubles."""
+        import ctypes as C
+        out = (C.c_int32 * 4)()
+        _abi.check(self.lib.mbx_batch_launch_info(self._h, out))
+        return {'threads': out[0], 'lds_bytes': out[1], 'fixed_geometry': out[2], 'state_doubles': out[3]}
+
     def close(self):
         if getattr(self, '_h', None):
             self.lib.mbx_batch_destroy(self._h)
