@@ -240,8 +240,8 @@ int mbx_qlpso_rollout(mbx_batch* b, const double* d_q_table, int n_steps, int32_
 int mbx_debug_math(int op, const double* d_x, const double* d_y, double* d_out, int n, void* stream);
 
 /* Diagnostics: how the generation kernel of this batch is launched.  out[0] = threads per workgroup, out[1] = dynamic LDS bytes per
- * workgroup, out[2] = compile-time-geometry instantiation in use (0 = run-time geometry), out[3] = doubles of
- * state per instance.  Host-only, no device work. */
+ * workgroup, out[2] = compile-time-geometry instantiation in use (0 = run-time geometry), out[3] = stride, in doubles,
+ * between the state blocks of consecutive instances (>= mbx_instance_state_doubles).  Host-only, no device work. */
 int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4]);
 
 const char* mbx_last_error(void);

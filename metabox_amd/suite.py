@@ -239,7 +239,7 @@ class Batch:
         return out
 
     def launch_info(self):
-        """How the generation kernel is launched: threads per workgroup, LDS bytes, compile-time-geometry id, state doubles."""
+        """How the generation kernel is launched: threads per workgroup, LDS bytes, compile-time-geometry id, state stride in doubles."""
         import ctypes as C
         out = (C.c_int32 * 4)()
         _abi.check(self.lib.mbx_batch_launch_info(self._h, out))

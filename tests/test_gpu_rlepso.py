@@ -467,3 +467,22 @@ def test_compile_time_geometry_kernel_equals_generic_kernel(env, monkeypatch):
             states.append(np.stack([batch.read_state(b) for b in range(B)]))
             batch.close()
         assert np.array_equal(states[0], states[1], equal_nan=True), (np_, n)
+
+
+def test_launch_info_routes_baseline_geometries_to_their_instantiations(env):
+    """mbx_batch_launch_info: the BASELINE.json geometries run the compile-time-geometry kernels, anything else the generic ones, and
+    the LDS footprints are the ones DESIGN.md's resident-workgroup arithmetic uses (5 x 30.5 KB RLEPSO workgroups per 160 KB CU)."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_RLEPSO, ALGO_GLEET
+    s, ids = env['bbob']
+    b = Batch(s, ALGO_RLEPSO, [0, 1], [1, 2], NP, MAXFES, LOGI, NLOG)
+    info = b.launch_info()
+    assert info['threads'] == 256 and info['fixed_geometry'] == 1 and 5 * info['lds_bytes'] <= 160 * 1024, info
+    assert info['state_doubles'] >= len(b.read_state(0))
+    b.close()
+    b = Batch(s, ALGO_RLEPSO, [0, 1], [1, 2], 60, MAXFES, LOGI, NLOG)          # not a BASELINE geometry
+    assert b.launch_info()['fixed_geometry'] == 0
+    b.close()
+    b = Batch(s, ALGO_GLEET, [0, 1], [1, 2], NP, MAXFES, LOGI, NLOG)
+    assert b.launch_info()['fixed_geometry'] == 5
+    b.close()

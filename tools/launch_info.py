@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Print how each algorithm's generation kernel is launched (threads, LDS bytes, compile-time-geometry id) -- the inputs of the
+resident-workgroups-per-CU arithmetic in DESIGN.md.   python tools/launch_info.py   (needs a GPU: batches are created)"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 from metabox_amd.problem.bbob import BBOB_Dataset
