@@ -96,7 +96,7 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.state_doubles = MBX_DQ_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
         g.sc_off = MBX_DQ_ST_SCALARS(c.np, c.dim);
         g.tape_stride = MBX_DQ_TAPE_STRIDE(c.np, c.dim);
-        g.lds_doubles = dq_lds_doubles(c.np, c.dim);
+        g.lds_doubles = dq_lds_doubles(c.np, c.np, c.dim);          // k_dq_reset; k_dq_step launches with the one-row layout
         g.state_dim = MBX_DQ_NFEAT; g.action_dim = 1;
     } else if (c.algo == MBX_ALGO_RANDOM_SEARCH) {
         g.state_doubles = MBX_RS_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
@@ -619,10 +619,10 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
             hipLaunchKernelGGL(k_lde_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->fixed_geometry == 4)
-            hipLaunchKernelGGL((k_dq_step<100, 12>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL((k_dq_step<100, 12>), dim3(b->B), dim3(kThreads), (size_t)dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double), (hipStream_t)stream, make_params(b),
                                (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
         else
-            hipLaunchKernelGGL(k_dq_step<>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL(k_dq_step<>, dim3(b->B), dim3(kThreads), (size_t)dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double), (hipStream_t)stream, make_params(b),
                                (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
     }
     HIP_TRY(hipGetLastError());

@@ -23,18 +23,20 @@ struct DqLds {
 };
 constexpr int kDqRec = 820;
 
-__host__ __device__ inline int64_t dq_lds_doubles(int NP, int D)
+// rows: how many candidates the evaluator sees at once -- NP in k_dq_reset, ONE in k_dq_step (a step evaluates a single trial vector:
+// 17.9 KB instead of 40.9 KB at NP = 100, D = 12, so the register budget, not the LDS, decides how many workgroups share a CU)
+__host__ __device__ inline int64_t dq_lds_doubles(int rows, int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
-    return NE + eval_t_doubles(NP, D) + SC + 2 * DD + 4 * align2(D) + 2 * P + kDqRec + 100 + 16 + 16 + 2 * align2(D);
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
+    return NE + eval_t_doubles(rows, D) + SC + 2 * DD + 4 * align2(D) + 2 * P + kDqRec + 100 + 16 + 16 + 2 * align2(D);
 }
 
-__device__ __forceinline__ DqLds dq_carve(double* base, int NP, int D)
+__device__ __forceinline__ DqLds dq_carve(double* base, int rows, int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
+    const int64_t NE = align2((int64_t)rows * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D), P = align2(NP);
     DqLds L;
     double* p = base;
-    L.X = p; p += NE;  L.T = p; p += eval_t_doubles(NP, D);  L.Z = p; p += SC;  L.M1T = p; p += DD;  L.M2T = p; p += DD;
+    L.X = p; p += NE;  L.T = p; p += eval_t_doubles(rows, D);  L.Z = p; p += SC;  L.M1T = p; p += DD;  L.M2T = p; p += DD;
     L.DSH = p; p += align2(D);  L.V0 = p; p += align2(D);  L.V1 = p; p += align2(D);  L.V2 = p; p += align2(D);
     L.NC = p; p += P;  L.COST = p; p += P;  L.REC = p; p += kDqRec;  L.FEAT = p; p += 100;  L.RED = p; p += 16;  L.MISC = p;
     return L;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* _
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
     const int NP = bp.NP, D = bp.D, NE = NP * D;
     const DevProblem P = bp.problems[bp.problem_idx[b]];
-    const DqLds L = dq_carve(smem, NP, D);
+    const DqLds L = dq_carve(smem, NP, NP, D);
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_DQ_ST_SCALARS(NP, D);
     double* ex = S + MBX_DQ_ST_EXTRA(NP, D);
@@ -185,9 +187,12 @@ __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ step
+#ifndef MBX_DQ_WAVES
+#define MBX_DQ_WAVES
+#endif
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int NPC = 0, int DC = 0>
-__global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int32_t* __restrict__ actions, double* __restrict__ state_out,
+__global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams bp, const int32_t* __restrict__ actions, double* __restrict__ state_out,
                                                       double* __restrict__ reward_out, uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_step(BatchParams bp, const int3
         return;
     }
     const DevProblem P = bp.problems[bp.problem_idx[b]];
-    const DqLds L = dq_carve(smem, NP, D);
+    const DqLds L = dq_carve(smem, 1, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const int action = actions[b];
     const int steps = (int)sc[MBX_SC_GEN] + 1;

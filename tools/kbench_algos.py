@@ -42,6 +42,7 @@ if 'ddqn' in which:
     B = 35 * 64
     env = BatchedPBO_Env(ps, opt, np.repeat(np.arange(35), 64), np.arange(B, dtype=np.uint64) + 1)
     state = env.reset()
+    print(json.dumps({'ddqn_launch_info': env.batch.launch_info()}))
     def run(n):
         global state
         with torch.no_grad():
