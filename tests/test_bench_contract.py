@@ -1,0 +1,46 @@
+"""bench.py's output contract: one JSON line with the driver's keys plus `roofline` and `cpu_baseline`."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpu_baseline_worker_runs_whole_episodes(tmp_path):
+    """oracle/cpu_workload.py (one worker of bench.py's cpu_baseline leg): a flat policy table, half a second of episodes."""
+    table = np.concatenate([np.full((20202, 35), 0.5, np.float32), np.full((20202, 35), 0.2, np.float32)], axis=1)
+    path = tmp_path / 't.npy'
+    np.save(path, table)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'cpu_workload.py'), '--table', str(path), '--seconds', '0.5',
+                          '--worker', '3'], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-400:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r['episodes'] >= 1 and r['steps'] >= 100 and r['seconds'] > 0
+    assert r['steps'] <= r['episodes'] * 199                                    # an episode is at most 199 generations
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '40', '--warmup', '4', '--no-cpu-baseline'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-600:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 40 and d['warmup'] == 4 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
+    assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    # value = live env-steps / wall time of the timed region
+    assert abs(d['value'] - d['config']['live_env_steps'] / (d['ms_per_step'] * 1e-3 * d['steps'])) <= 1e-6 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_kernel_us'] * 1e-6) / 1e9) <= 1e-6 * r['achieved']
+    assert r['algorithmic_bytes_per_env_step'] == 54057 and 0 < r['avg_kernel_us'] < 1e4
+    assert r['traffic'] is None or 0.5 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 2.0
