@@ -87,6 +87,11 @@ class DE_DDQN_Agent(Basic_Agent):
             return int(np.random.randint(low=0, high=self.__config.n_act))
         return int(torch.argmax(q))
 
+    @torch.no_grad()
+    def greedy_batch(self, states):
+        """Greedy operator choice for a batch of states [B, 99] -> int32 [B] (argmax Q, de_ddqn_agent.py:59-68,108-117)."""
+        return self.__pred_func(states.to(torch.float32)).argmax(dim=1).to(torch.int32)
+
     def rollout_episode(self, env):
         state, done, total = env.reset(), False, 0
         while not done:
@@ -104,10 +109,8 @@ class DE_DDQN_Agent(Basic_Agent):
             bc = env.batch.cfg
             max_steps = bc.max_fes - bc.np                # one evaluation per step
         state = env.reset()
-        net = self.__pred_func
 
-        def greedy_of(st):
-            return net(st.to(torch.float32)).argmax(dim=1).to(torch.int32)
+        greedy_of = self.greedy_batch
 
         replay, static_action = None, None
         if graph:
