@@ -72,7 +72,9 @@
  * r = sqrt(-2 ln(1-ua)), n0 = r cos(2 pi ub), n1 = r sin(2 pi ub).
  *
  *   site                 index        words
- *   MBX_SITE_ELEM_A      e = i*D+d    u53(w0,w1) = clpso_u[e];  mulhi(w2,NP), mulhi(w3,NP) = tournament pair
+ *   MBX_SITE_ELEM_A      e >> 1       u53(w0,w1) = clpso_u[e] for even e, u53(w2,w3) = clpso_u[e] for odd e (one call per element pair)
+ *   MBX_SITE_TOURN       e >> 1       mulhi(w0,NP), mulhi(w1,NP) = tournament pair of the even element, mulhi(w2,NP), mulhi(w3,NP) = of the odd one;
+ *                                     only consumed where !(clpso_u[e] > pci_i)
  *   MBX_SITE_ELEM_B      e >> 1       u53(w0,w1) = fdr_u[e] for even e, u53(w2,w3) = fdr_u[e] for odd e (one call per element pair)
  *   MBX_SITE_PART        i            u53(w0,w1) = rand1[i];    u53(w2,w3) = rand2[i]
  *   MBX_SITE_REINIT      i            u53(w0,w1) = reinit_u[i]
@@ -290,6 +292,7 @@
  *      Philox, generation g >= 1: MBX_SITE_ELEM_A(i*D+d): Box-Muller(u53(w0,w1), u53(w2,w3)) first normal -> arz[i][d];
  *      noise MBX_SITE_NOISE0_A/B(i).                                                                                            */
 #define MBX_SITE_CLASSIC     16u
+#define MBX_SITE_TOURN       17u   /* RLEPSO, see the table above */
 #define MBX_DE_ST_X(NP, D)          ((int64_t)0)
 #define MBX_DE_ST_COST(NP, D)       ((int64_t)(NP) * (D))
 #define MBX_DE_ST_SCALARS(NP, D)    ((int64_t)(NP) * (D) + (NP))

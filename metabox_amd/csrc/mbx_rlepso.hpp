@@ -46,15 +46,23 @@ __device__ __forceinline__ bool log_and_terminate(const BatchParams& bp, const D
 struct RlLds {
     double *PB, *X, *Z, *T, *M1T, *M2T, *DSH, *V0, *V1, *V2, *PBC, *NC, *PNI, *CMUT, *R1, *R2, *GB, *COEF, *RED;
     int *IMPR, *MASK, *RANK;
+    // KB (NE bytes): rank of the FDR exemplar of every (rank, dimension), carved out of the part of Z that R1 / R2 / COEF leave free
+    // (all dead before the evaluator first writes Z)
+    uint8_t* KB;
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
 
 __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_t)1; }
 
-// evaluator scratch Z: n*D doubles, at least 2 per thread for the block reductions, and room for the move phase's R1 | R2 | COEF
+// doubles of the move phase's byte table inside Z: KB (NE bytes)
+__host__ __device__ inline int64_t rl_aux_doubles(int NP, int D) { return ((int64_t)NP * D + 15) / 16 * 2; }
+
+// evaluator scratch Z: n*D doubles, at least 2 per thread for the block reductions, and room for the move phase's R1 | R2 | COEF | tables
 __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
 {
-    const int64_t NE = align2((int64_t)NP * D), need = 2 * kThreads > 2 * align2(NP) + 96 ? 2 * kThreads : 2 * align2(NP) + 96;
+    const int64_t NE = align2((int64_t)NP * D);
+    int64_t need = 2 * align2(NP) + 96 + rl_aux_doubles(NP, D);
+    if (need < 2 * kThreads) need = 2 * kThreads;
     return align2(NE > need ? NE : need);
 }
 
@@ -62,9 +70,9 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = align2((int64_t)D * D),
                   P = align2(NP), TS = eval_t_doubles(NP, D);
-    // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC (R1, R2 and COEF, which are
-    // dead before the first evaluation, live in it); M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT: P each; RED: 16;
-    // 3 int arrays  (29.8 KB at NP = 100, D = 10: five workgroups per CU)
+    // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC (R1, R2, COEF and the byte tables of
+    // the move phase, all dead before the first evaluation, live in it); M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT: P each;
+    // RED: 16; 3 int arrays  (29.8 KB at NP = 100, D = 10: five workgroups per CU)
     return TS + NE + SC + 2 * DD + 4 * P + 5 * align2(D) + 16 + 3 * align2((P + 1) / 2);
 }
 
@@ -78,6 +86,7 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
     L.X = p; p += NE;
     L.Z = p;
     L.R1 = p; L.R2 = p + P; L.COEF = p + 2 * P;   // per-particle draws and group coefficients: last read in the move phase, Z first written by the evaluator
+    L.KB = (uint8_t*)(p + 2 * P + 96);
     p += SC;
     L.M1T = p; p += DD;
     L.M2T = p; p += DD;
@@ -206,102 +215,125 @@ __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, dou
 #endif
 }
 
-// Move W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk (rlepso_optimizer.py:179-195).
+// ---- FDR exemplar (rlepso_optimizer.py:97-109): argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum.
+//  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
+//    among the strictly better particles (negative ratios) if there are any, otherwise it is 0 and np.argmin
+//    returns the lowest index with pbest_j == pbest_i.  Only the `nless` better particles are scanned, in
+//    ascending-cost order (ORDER / NC), halving the O(NP^2 D) work on average.
+//  * ratios are compared by cross-multiplication (denominators >= 1e-5 > 0): a_j/b_j < a*/b* <=> a_j b* < a* b_j.
+//    Identical candidates (same pbest cost and same coordinate) are adjacent in the (cost, index) order, so the
+//    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
+//    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
+// Exact float64 scan for W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk; returns the exemplar's rank per coordinate.
 template <int W>
-__device__ __forceinline__ void rl_move(const MoveCtx& c, int rk, int d0)
+__device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W])
+{
+#pragma unroll
+    for (int q = 0; q < W; ++q) kb[q] = nless;                   // rank of the exemplar when nobody is strictly better
+    if (nless <= 0) return;
+    const double fi = L.NC[rk];
+    double pp[W], ab[W], bb[W];
+    const double a0 = L.NC[0] - fi;
+#pragma unroll
+    for (int q = 0; q < W; ++q) { pp[q] = L.PB[rk * D + d0 + q]; kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
+    const double* col = L.PB + d0;
+    // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
+    // issued before its first comparison
+    int k = 1;
+    for (; k + MBX_FDR_UNROLL <= nless; k += MBX_FDR_UNROLL) {
+        double a[MBX_FDR_UNROLL], x[MBX_FDR_UNROLL][W];
+#pragma unroll
+        for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
+            a[u] = L.NC[k + u];
+#pragma unroll
+            for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
+        }
+#pragma unroll
+        for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
+            const double au = a[u] - fi;                      // shared by the W coordinates
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const double b = fabs(x[u][q] - pp[q]) + 1e-5;
+                fdr_take(au * bb[q], ab[q] * b, ab[q], bb[q], kb[q], au, b, k + u);
+            }
+        }
+    }
+    for (; k < nless; ++k) {
+        const double a = L.NC[k] - fi;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
+            fdr_take(a * bb[q], ab[q] * b, ab[q], bb[q], kb[q], a, b, k);
+        }
+    }
+}
+
+// Velocity / position update of W adjacent coordinates of particle i (rlepso_optimizer.py:179-195); FDR exemplars from KB.
+// CLPSO (:76-95): one Philox call carries the uniforms of an element PAIR (site ELEM_A, index e >> 1), another one (site TOURN, same
+// index) the two tournament pairs; the latter is only evaluated where a tournament is consumed, i.e. where !(u > pci_i).
+template <int W>
+__device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, const double cur[W], const double vel[W])
 {
     const RlLds& L = c.L;
     const int NP = c.NP, D = c.D;
-    const int i = c.ORDER[rk], e0 = i * D + d0, es0 = rk * D + d0;
-    const double r1 = L.R1[i], r2 = L.R2[i], fi = L.PBC[i], pci = c.bp.pci[i];
-    double uc[W], uf[W], cur[W], vel[W], pp[W], v_clpso[W];
-    int t1[W], t2[W];
-    if (!c.tape) {
+    const int rk = c.RANK[i], e0 = i * D + d0, es0 = rk * D + d0;
+    const double r1 = L.R1[i], r2 = L.R2[i];
+    double uf[W];
+    if (c.tape) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) uf[q] = c.tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e0 + q];
+    } else {
         // one Philox call carries the FDR weights of an element PAIR (site ELEM_B, index e >> 1: words 0-1 for the even element,
         // 2-3 for the odd one); a two-coordinate work item starts on an even element (D even, d0 even)
         const U4 w = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_ELEM_B);
         if (W == 2) { uf[0] = u53(w.x, w.y); uf[W - 1] = u53(w.z, w.w); }
         else uf[0] = (e0 & 1) ? u53(w.z, w.w) : u53(w.x, w.y);
     }
-#pragma unroll
-    for (int q = 0; q < W; ++q) {
-        const int e = e0 + q;
-        if (c.tape) {
-            uc[q] = c.tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
-            t1[q] = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2[q] = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1];
-            uf[q] = c.tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e];
-        } else {
-            const U4 w = c.rng.draw((uint32_t)e, MBX_SITE_ELEM_A); uc[q] = u53(w.x, w.y);
-            t1[q] = (int)__umulhi(w.z, (uint32_t)NP); t2[q] = (int)__umulhi(w.w, (uint32_t)NP);
-        }
-        // position and velocity come straight from HBM: the loads are issued here and first used after the FDR scan below, which
-        // hides their latency (they are no longer staged through LDS by the prologue)
-        cur[q] = c.gPos[e]; vel[q] = c.gVel[e]; pp[q] = L.PB[es0 + q];
-        // CLPSO exemplar: binary tournament on pbest cost, first candidate wins ties (:76-95)
-        const int tw = L.PBC[t2[q]] < L.PBC[t1[q]] ? t2[q] : t1[q];
-        v_clpso[q] = uc[q] > pci ? pp[q] : L.PB[c.RANK[tw] * D + d0 + q];      // the exemplar; turned into the velocity term below
-    }
-    // FDR exemplar: argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum (:97-109).
-    //  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
-    //    among the strictly better particles (negative ratios) if there are any, otherwise it is 0 and np.argmin
-    //    returns the lowest index with pbest_j == pbest_i.  Only the `nless` better particles are scanned, in
-    //    ascending-cost order (ORDER / NC), halving the O(NP^2 D) work on average.
-    //  * ratios are compared by cross-multiplication (denominators >= 1e-5 > 0): a_j/b_j < a*/b* <=> a_j b* < a* b_j.
-    //    Identical candidates (same pbest cost and same coordinate) are adjacent in the (cost, index) order, so the
-    //    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
-    //    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
-    const int nless = c.NLESS[i];
-    int kb[W];
-#pragma unroll
-    for (int q = 0; q < W; ++q) kb[q] = nless;                   // rank of the exemplar
-#ifndef MBX_ABLATE_FDR
-    if (nless > 0) {
-        double ab[W], bb[W];
-        const double a0 = L.NC[0] - fi;
-#pragma unroll
-        for (int q = 0; q < W; ++q) { kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
-        const double* col = L.PB + d0;
-        // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
-        // issued before its first comparison
-        int k = 1;
-        for (; k + MBX_FDR_UNROLL <= nless; k += MBX_FDR_UNROLL) {
-            double a[MBX_FDR_UNROLL], x[MBX_FDR_UNROLL][W];
-#pragma unroll
-            for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
-                a[u] = L.NC[k + u];
-#pragma unroll
-                for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
-            }
-#pragma unroll
-            for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
-                const double au = a[u] - fi;                      // shared by the W coordinates
-#pragma unroll
-                for (int q = 0; q < W; ++q) {
-                    const double b = fabs(x[u][q] - pp[q]) + 1e-5;
-                    fdr_take(au * bb[q], ab[q] * b, ab[q], bb[q], kb[q], au, b, k + u);
-                }
-            }
-        }
-        for (; k < nless; ++k) {
-            const double a = L.NC[k] - fi;
-#pragma unroll
-            for (int q = 0; q < W; ++q) {
-                const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
-                fdr_take(a * bb[q], ab[q] * b, ab[q], bb[q], kb[q], a, b, k);
-            }
-        }
-    }
-#endif
     const int g = c.fg.div(i);
     double cw = 0., c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
     if (g < c.G) { const double* k = L.COEF + g * 6; cw = k[1]; c1 = k[2]; c2 = k[3]; c3 = k[4]; c4 = k[5]; }
+    double ucs[W]; int xrs[W];
+    {
+        const double pci = c.bp.pci[i];
+        U4 wa{0, 0, 0, 0};
+        if (!c.tape) wa = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_ELEM_A);
+        bool need = false;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const int e = e0 + q;
+            if (c.tape) ucs[q] = c.tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
+            else ucs[q] = (W == 2 ? q == 1 : (e & 1)) ? u53(wa.z, wa.w) : u53(wa.x, wa.y);
+            xrs[q] = rk;
+            need = need || !(ucs[q] > pci);
+        }
+        if (need) {
+            U4 wt{0, 0, 0, 0};
+            if (!c.tape) wt = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_TOURN);
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int e = e0 + q;
+                if (!(ucs[q] > pci)) {
+                    int t1, t2;
+                    if (c.tape) { t1 = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e]; t2 = (int)c.tape[MBX_RLEPSO_TAPE_TOURN(NP, D) + 2 * e + 1]; }
+                    else {
+                        const bool odd = W == 2 ? q == 1 : (e & 1);
+                        t1 = (int)__umulhi(odd ? wt.z : wt.x, (uint32_t)NP); t2 = (int)__umulhi(odd ? wt.w : wt.y, (uint32_t)NP);
+                    }
+                    xrs[q] = c.RANK[L.PBC[t2] < L.PBC[t1] ? t2 : t1];   // binary tournament on pbest cost, first candidate wins ties
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < W; ++q) {
         const int e = e0 + q, d = d0 + q;
-        const double v_fdr = uf[q] * (L.PB[kb[q] * D + d] - pp[q]);
-        const double v_pbest = r1 * (pp[q] - cur[q]);
+        const double pp = L.PB[es0 + q], uc = ucs[q];
+        const int xr = xrs[q], kb = L.KB[es0 + q];
+        const double ex = L.PB[xr * D + d];                        // CLPSO exemplar (own rank: the particle's own pbest)
+        const double v_fdr = uf[q] * (L.PB[kb * D + d] - pp);
+        const double v_pbest = r1 * (pp - cur[q]);
         const double v_gbest = r2 * (L.GB[d] - cur[q]);
-        const double v_cl = uc[q] * (v_clpso[q] - cur[q]);
+        const double v_cl = uc * (ex - cur[q]);
         double nv = cw * vel[q] + c1 * v_cl + c2 * v_fdr + c3 * v_gbest + c4 * v_pbest;
         nv = fmin(fmax(nv, -c.vmax), c.vmax);
         double np_ = cur[q] + nv;
@@ -498,26 +530,60 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
     __syncthreads();
     MBX_PHASE(2);                                                 // pbest rows -> LDS in rank order
 
-    // ---- velocity / position update (:179-195).  A work item is W adjacent dimensions of one particle (W = 2 when D is
-    // even: the pbest-cost difference of the FDR scan is then shared by both dimensions and their coordinates come from
-    // one 16-byte LDS read).  Items are visited in pbest-rank order so that the lanes of a wave own particles of similar
-    // rank, i.e. similar FDR trip counts.
-    const MoveCtx mc{L, bp, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
-    // The FDR trip count grows with the rank, and wave w of every resident workgroup shares one SIMD: odd passes run
-    // backwards (boustrophedon) so that each wave pairs a cheap slice of ranks with an expensive one.
+    // ---- FDR exemplars -> KB[rank * D + d]  (a pass of its own: the scan's registers are dead before the velocity update starts, which
+    // keeps the kernel at 80 VGPRs without scratch; fused into the update it needed 96 and spilled)
+#ifndef MBX_ABLATE_FDR
+    // Items are visited in pbest-rank
+    // order so that the lanes of a wave own particles of similar rank, i.e. similar trip counts; the trip count grows with the rank and
+    // wave w of every resident workgroup shares one SIMD, so odd passes run backwards (boustrophedon): each wave pairs a cheap slice of
+    // ranks with an expensive one.
     if ((D & 1) == 0) {
         const int HD = D >> 1, NI = NP * HD;
         const FastDiv fh(HD);
         for (int base = 0, pass = 0; base < NI; base += MBX_NT, ++pass) {
             const int lim = base + MBX_NT < NI ? base + MBX_NT : NI;
             const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
-            if (ps >= base && ps < lim) { const int rk = fh.div(ps); rl_move<2>(mc, rk, 2 * (ps - rk * HD)); }
+            if (ps >= base && ps < lim) {
+                const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
+                int kb[2];
+                fdr_exact<2>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
+            }
         }
     } else {
         for (int base = 0, pass = 0; base < NE; base += MBX_NT, ++pass) {
             const int lim = base + MBX_NT < NE ? base + MBX_NT : NE;
             const int es = (pass & 1) ? lim - 1 - tid : base + tid;
-            if (es >= base && es < lim) { const int rk = fd.div(es); rl_move<1>(mc, rk, es - rk * D); }
+            if (es >= base && es < lim) {
+                const int rk = fd.div(es), d0 = es - rk * D;
+                int kb[1];
+                fdr_exact<1>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                L.KB[es] = (uint8_t)kb[0];
+            }
+        }
+    }
+#else
+    for (int e = tid; e < NE; e += MBX_NT) L.KB[e] = 0;
+    __syncthreads();
+#endif
+    __syncthreads();
+
+    // ---- velocity / position update (:179-195).  A work item is W adjacent dimensions of one particle (W = 2 when D is even).
+    const MoveCtx mc{L, bp, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
+    if ((D & 1) == 0) {
+        const int HD = D >> 1, NI = NP * HD;
+        const FastDiv fh(HD);
+        for (int it = tid; it < NI; it += MBX_NT) {
+            const int i = fh.div(it);
+            const double2 c2 = *(const double2*)(gPos + 2 * it), v2 = *(const double2*)(gVel + 2 * it);
+            const double cur[2] = {c2.x, c2.y}, vel[2] = {v2.x, v2.y};
+            rl_move<2>(mc, i, 2 * (it - i * HD), cur, vel);
+        }
+    } else {
+        for (int e = tid; e < NE; e += MBX_NT) {
+            const int i = fd.div(e);
+            const double cur[1] = {gPos[e]}, vel[1] = {gVel[e]};
+            rl_move<1>(mc, i, e - i * D, cur, vel);
         }
     }
     __syncthreads();

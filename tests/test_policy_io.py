@@ -6,8 +6,8 @@ greedy action = argmax Q) and RLEPSO's critic (src/agent/rlepso_agent.py:50-61).
 (the modules are plain PyTorch: host logic) and, marked gpu, on cuda:0 through the code path rollout_batch uses
 (PolicyNet.act_batch / LDE's fused `mbx_lde_policy` kernel, the batched greedy action of DE_DDQN_Agent).
 
-Tolerances: float32 networks, 2e-6 absolute on outputs that are O(1) (mu, sigma, h', c', value); Q-values are O(1) sums of 100
-products, 1e-5.  argmax must be equal wherever the recorded top-2 gap exceeds the tolerance (stated in the test)."""
+Tolerances: float32 networks, 2e-6 absolute on outputs that are O(1) (mu, sigma, h', c'); the critic's values are O(1e5), 5e-7 relative
+(4 float32 ulp); Q-values are O(1) sums of 100 products, 1e-5.  argmax must be equal wherever the recorded top-2 gap exceeds the tolerance (stated in the test)."""
 import numpy as np
 import pytest
 import torch
@@ -72,7 +72,8 @@ def _check_rlepso_critic(device):
     with torch.no_grad():
         v_det, v = agent.critic(torch.from_numpy(pol['io/state']).to(device))
     assert v_det.shape == (len(pol['io/state']),) and not v_det.requires_grad
-    assert np.abs(v.detach().cpu().numpy() - pol['io/value'][:, 0]).max() <= 2e-6
+    want = pol['io/value'][:, 0]                                  # O(1e5): float32, so the bound is relative (4 ulp)
+    assert np.all(np.abs(v.detach().cpu().numpy() - want) <= 5e-7 * np.abs(want) + 2e-6)
     assert np.array_equal(v_det.cpu().numpy(), v.detach().cpu().numpy())
 
 

@@ -81,6 +81,24 @@ OPU(k_bperm_nowait, "ds_bpermute_b32 %0, %1, %0")
 OPU(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
 OPU(k_alignbit, "v_alignbit_b32 %0, %0, %1, 7")
 
+
+OPF(k_cmp_lt_f32, "v_cmp_lt_f32 s[10:11], %0, %1")
+OPU(k_cmp_lt_u32, "v_cmp_lt_u32 s[10:11], %0, %1")
+OPU(k_cndmask_sgpr, "v_cndmask_b32 %0, %0, %1, s[10:11]")
+OPF(k_cmp_cndmask_f32, "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
+OPF(k_max_f32, "v_max_f32 %0, %0, %1")
+OPF(k_min3_f32, "v_min3_f32 %0, %0, %1, %2")
+OPF(k_sub_f32, "v_sub_f32 %0, %0, %1")
+OPU(k_and_b32, "v_and_b32 %0, %0, %1")
+OPU(k_or_b32, "v_or_b32 %0, %0, %1")
+OPU(k_bfi_b32, "v_bfi_b32 %0, %1, %0, %2")
+OPU(k_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+OPU(k_sub_u32, "v_sub_u32 %0, %0, %1")
+OPU(k_max_u32, "v_max_u32 %0, %0, %1")
+OPU(k_max_i32, "v_max_i32 %0, %0, %1")
+OPU(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+OPU(k_add_dpp, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+
 // 64-bit products: v_mad_u64_u32 writes a pair
 __global__ void k_mad_u64_u32(unsigned long long* out, double seed)
 {
@@ -228,7 +246,7 @@ int main()
         T(k_add_f32), T(k_mul_f32), T(k_fma_f32), T(k_pk_mul_f32), T(k_pk_add_f32), T(k_rcp_f32), T(k_exp_f32), T(k_log_f32), T(k_sqrt_f32), T(k_sin_f32),
         T(k_min_f32), T(k_med3_f32), T(k_addabs_f32),
         T(k_mov_b32), T(k_add_u32), T(k_xor_b32), T(k_and_or_b32), T(k_min_u32), T(k_med3_u32), T(k_mul_lo_u32), T(k_mul_hi_u32), T(k_mul_u24),
-        T(k_mad_u64_u32), T(k_cndmask_b32), T(k_lshl_add), T(k_alignbit), T(k_bperm_nowait), T(k_ds_read_b64_bcast), T(k_ds_read_b128_5addr),
+        T(k_mad_u64_u32), T(k_cmp_lt_f32), T(k_cmp_lt_u32), T(k_cndmask_sgpr), {"k_cmp+cndmask_f32", k_cmp_cndmask_f32, 2}, T(k_max_f32), T(k_min3_f32), T(k_sub_f32), T(k_and_b32), T(k_or_b32), T(k_bfi_b32), T(k_lshlrev_b32), T(k_sub_u32), T(k_max_u32), T(k_max_i32), T(k_mov_dpp), T(k_add_dpp), T(k_lshl_add), T(k_alignbit), T(k_bperm_nowait), T(k_ds_read_b64_bcast), T(k_ds_read_b128_5addr),
     };
     unsigned long long* d; hipMalloc(&d, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
