@@ -15,6 +15,10 @@ timed region.
 Also reported on the same JSON line:
   roofline     — fused generation kernel: algorithmic bytes (54.0 KB per env-step) x live instances
                  per launch / average kernel duration measured with HIP events on the launch stream, vs 8 TB/s.
+  roofline.valu — the kernel is VALU-issue bound, not bandwidth bound: wave-instructions per launch and the issue bound they imply,
+                 from the committed PMC profile (profiles/r*_pmc_hbm_traffic.json, `valu_issue_bound`), beside the measured time.
+  other_configs — one GPU's share of BASELINE.json configs 3 (LDE, NP = 50 and NP = 100), 4 (DE-DDQN on protein docking) and
+                 5 (RLEPSO D = 40, NP = 128): ms per lock-step step, env-steps/s, algorithmic bytes and roofline fraction (N = 1 only).
   cpu_baseline — the C oracle (a float64 port of the reference path, oracle/mbx_oracle.c) on all host cores (one
                  single-threaded worker per core) and on one core, on a bounded sample of the same workload
                  (rank 0, N = 1 only).
@@ -111,19 +115,155 @@ def cpu_baseline(seconds_budget=20.0):
                       f'{one["steps"]} env-steps in {one["seconds"]:.1f} s'}
 
 
-def pmc_traffic_per_launch(live_per_launch):
-    """HBM bytes per launch of the generation kernel from the committed rocprofv3 PMC passes
-    (2 x FETCH_SIZE + WRITE_SIZE, calibration in profiles/*_pmc_hbm_traffic.json; collected with every instance
-    live), scaled to this run's average number of live instances per launch.  None when no profile is committed."""
+def _latest_profile():
+    """The newest committed PMC summary (tools/pmc_summary.py output), or None."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), reverse=True):
         try:
             with open(path) as f:
-                per_launch = json.load(f)['calibration']['hbm_bytes_per_launch']
-        except (OSError, ValueError, KeyError, TypeError):
+                return os.path.basename(path), json.load(f)
+        except (OSError, ValueError):
             continue                                   # an incomplete profile must never take the bench line down
-        return per_launch / INSTANCES_PER_GPU * live_per_launch
-    return None
+    return None, None
+
+
+def pmc_traffic_per_launch(live_per_launch):
+    """HBM bytes per launch of the generation kernel from the committed rocprofv3 PMC passes
+    (2 x FETCH_SIZE + WRITE_SIZE, calibration in profiles/*_pmc_hbm_traffic.json; collected with every instance
+    live), scaled to this run's average number of live instances per launch.  (None, None) when no profile is committed."""
+    name, prof = _latest_profile()
+    try:
+        return prof['calibration']['hbm_bytes_per_launch'] / INSTANCES_PER_GPU * live_per_launch, name
+    except (KeyError, TypeError):
+        return None, None
+
+
+def valu_roofline(live_per_launch, avg_kernel_s):
+    """VALU side of the roofline ('report both achieved GB/s and VALU utilisation'): wave-instructions per launch by
+    class from the committed PMC profile x the issue cost of each class measured with tools/ubench/valu_rates.hip, scaled to this
+    run's live instances.  frac = issue-bound time / measured time (an interval: the counters do not split 2- and 4-cycle integer ops)."""
+    name, prof = _latest_profile()
+    try:
+        v = prof['valu_issue_bound']
+        scale = live_per_launch / INSTANCES_PER_GPU
+        lo, hi = (x * scale for x in v['issue_bound_us_at_2.4GHz'])
+        return {'bound': 'valu', 'wave_instructions_per_launch': v['wave_instructions_per_launch']['total'] * scale,
+                'f64_share': v['wave_instructions_per_launch']['f64_add_mul_fma'] / v['wave_instructions_per_launch']['total'],
+                'issue_bound_us': [lo, hi], 'measured_us': avg_kernel_s * 1e6,
+                'frac': [lo / (avg_kernel_s * 1e6), hi / (avg_kernel_s * 1e6)],
+                'active_lanes_per_instruction': v.get('active_lanes_per_valu_instruction'),
+                'source': f'profiles/{name} (rocprofv3 --pmc passes of this command, not collected during this run) + profiles/r02_valu_issue_rates.txt'}
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
+
+
+def _bracket(fn, steps, stream_sync=True):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def other_configs(budget_s=60.0):
+    """One GPU's share of BASELINE.json configs 3, 4 and 5, policy included, each on its own lock-step batch: ms per step, env-steps/s,
+    algorithmic bytes per env-step and the fraction of the 8 TB/s roofline they imply.  Bounded: a few dozen steps each."""
+    from metabox_amd._abi import ALGO_RLEPSO
+    from metabox_amd.agent import DE_DDQN_Agent, LDE_Agent, RLEPSO_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import DE_DDQN_Optimizer, LDE_Optimizer
+    from metabox_amd.problem.bbob import BBOB_Dataset
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd.utils import construct_problem_set
+    out, t_start = [], time.perf_counter()
+
+    def entry(name, B, dt, bytes_per_step, extra=None):
+        e = {'config': name, 'instances': B, 'ms_per_step': dt * 1e3, 'env_steps_per_s': B / dt,
+             'algorithmic_bytes_per_env_step': bytes_per_step, 'roofline_frac': B * bytes_per_step / dt / 1e9 / HBM_PEAK_GBS}
+        e.update(extra or {})
+        out.append(e)
+
+    with torch.no_grad():
+        # ---- config 3: LDE on bbob-noisy d=30, 16384 instances; NP = 50 (the reference's population, lde_optimizer.py:10, shipped weights)
+        #      and NP = 100 (BASELINE.json as written; no shipped policy fits 2 NP = 200 outputs: seeded fresh PolicyNet)
+        for np_lde in (50, 100):
+            if time.perf_counter() - t_start > budget_s:
+                break
+            cfg = get_config(['--problem', 'bbob-noisy', '--dim', '30', '--device', 'cuda'])
+            cfg.agent_save_dir = None
+            if np_lde != 50:
+                cfg.NP_override = np_lde
+            torch.manual_seed(0)
+            agent = LDE_Agent(cfg)
+            if np_lde == 50:
+                agent.load_exported_weights(np.load(os.path.join(ROOT, 'metabox_amd', 'agent_model', 'lde_bbob_easy.npz')))
+            agent.to('cuda')
+            opt = LDE_Optimizer(cfg)
+            tr, te = construct_problem_set(cfg)
+            ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+            B = 16384
+            env = BatchedPBO_Env(ps, opt, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
+            st = {'s': env.reset(), 'h': torch.zeros(1, B, 50, device='cuda'), 'c': torch.zeros(1, B, 50, device='cuda')}
+
+            def run(n, st=st, env=env, agent=agent):
+                for _ in range(n):
+                    st['s'], st['h'], st['c'] = agent.policy_step(env, st['s'], st['h'], st['c'])
+            run(3)
+            dt = _bracket(run, 30)
+            D = 30
+            entry(f'config 3: LDE bbob-noisy d=30 pop={np_lde}, 16384 instances (one GPU), LSTM policy included', B, dt,
+                  (2 * np_lde * D + 2 * np_lde) * 8 + 4 * 2 * np_lde + 8 * (np_lde + 10) + (D * D + D + 2) * 8,
+                  {'launch_info': env.batch.launch_info(), 'policy': agent.policy_route()})
+            env.close()
+        # ---- config 4: DE-DDQN on protein docking, one GPU's share = 35 problems x 64 runs (seeded fresh Q-net: no checkpoint ships)
+        if time.perf_counter() - t_start <= budget_s:
+            cfg = get_config(['--problem', 'protein', '--device', 'cuda'])
+            cfg.agent_save_dir = None
+            torch.manual_seed(0)
+            agent = DE_DDQN_Agent(cfg).to('cuda')
+            opt = DE_DDQN_Optimizer(cfg)
+            tr, te = construct_problem_set(cfg)
+            ps = (tr + te).data[:35]
+            B = 35 * 64
+            env = BatchedPBO_Env(ps, opt, np.repeat(np.arange(35), 64), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
+            st = {'s': env.reset()}
+
+            def run4(n, st=st, env=env, agent=agent):
+                for _ in range(n):
+                    st['s'], _, _ = env.step(agent.greedy_batch(st['s']).contiguous())
+            run4(5)
+            dt = _bracket(run4, 100)
+            entry('config 4: DE-DDQN protein-docking d=12 pop=100, 2240 instances = 35 problems x 64 runs (one GPU of eight), Q-net included', B, dt,
+                  15 * 1024, {'note': 'compute-bound (10^4 atom pairs per evaluation), the HBM fraction is nominal', 'launch_info': env.batch.launch_info()})
+            env.close()
+        # ---- config 5: RLEPSO on the mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances per GPU, act + step fused
+        if time.perf_counter() - t_start <= budget_s:
+            ps = []
+            for suite in ('bbob', 'bbob-noisy'):
+                tr, te = BBOB_Dataset.get_datasets(suite, 40, 5.0)
+                ps += sorted(tr.data + te.data, key=lambda p: p.func_id)
+            s5 = Suite(ps)
+            cfg = get_config(['--problem', 'bbob', '--dim', '40', '--device', 'cuda'])
+            cfg.agent_save_dir = None
+            agent = RLEPSO_Agent(cfg).load_exported_weights(np.load(os.path.join(ROOT, 'metabox_amd', 'agent_model', 'rlepso_bbob_easy.npz'))).to('cuda')
+            actor = agent.actor
+            h1, h2 = actor.hidden_sizes()
+            B, NP5, D5 = 8192, 128, 40
+            b = Batch(s5, ALGO_RLEPSO, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 3, NP5, 80000, 1600, 50, early_stop=False)
+            table = b.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+            b.reset()
+
+            def run5(n, b=b, table=table):
+                for _ in range(n):
+                    b.act_step(table)
+            run5(2)
+            dt = _bracket(run5, 8)
+            S5 = (3 * NP5 * D5 + 3 * NP5 + D5 + 1) * 8 + 16
+            entry('config 5: RLEPSO mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances (one GPU of eight), policy fused', B, dt,
+                  2 * S5 + 4 * 35 + (D5 * D5 + D5 + 2) * 8 + 13, {'launch_info': b.launch_info()})
+            b.close()
+    return out
 
 
 def main():
@@ -133,6 +273,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs 3 / 4 / 5 legs (other_configs)')
     ap.add_argument('--functions', default='all24',
                     help="all24 (default: every bbob function round-robin), train18 (the bbob-easy train split), or a comma list of "
                          "function ids (SURVEY §8(d) C2 asks for the split and per-function figures next to the headline)")
@@ -143,7 +284,8 @@ def main():
                          'hip: mbx_gauss_policy + mbx_step; torch: the two MLPs as batched PyTorch ops; table: (mu, sigma) gathered '
                          'from the per-fes table with PyTorch ops')
     ap.add_argument('--graph-policy', action='store_true', help='with --policy torch / table: replay the policy as one hipGraph')
-    ap.add_argument('--event-stride', type=int, default=8, help='bracket every n-th generation kernel with HIP events (1 = all)')
+    ap.add_argument('--event-stride', type=int, default=0,
+                    help='bracket every n-th generation kernel with HIP events (default: every kernel when steps <= 64, else every 8th)')
     ap.add_argument('--dist-backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses cuda:0')
     args = ap.parse_args()
@@ -185,7 +327,8 @@ def main():
     B = args.instances
     gid = np.arange(B, dtype=np.int64) + rank * B                       # global instance ids: weak scaling
     pidx = (gid % len(ps)).astype(np.int32)
-    seeds = (gid // len(ps)).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(12345)
+    from metabox_amd.distributed import philox_seed
+    seeds = philox_seed(gid // len(ps), gid, epoch_salt=12345)          # key = f(run, global id): results independent of the GPU count
     env = BatchedPBO_Env(ps, optimizer, pidx, seeds, early_stop=not args.fixed_horizon)
     actor = agent.actor
     table = agent.actor_table(MAXFES, NP_, dev)
@@ -211,8 +354,11 @@ def main():
         torch.cuda.synchronize()
 
     K, W = args.steps, args.warmup
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    # Kernel timing: ONE event per `stride` generations on the launch stream; consecutive events bracket `stride` back-to-back generation
+    # kernels (act + step is a single launch, nothing else runs on the stream), so every kernel of the timed region is covered and an event
+    # costs stream time only once per span.  Spans that contain an episode restart (mbx_reset) are left out.
+    stride = args.event_stride if args.event_stride > 0 else (2 if K <= 64 else 8)
+    marks, mark_step, reset_steps = [], [], []
     state = env.reset()
     # The policy forward is two 3-layer MLPs, tanh, Normal sampling and clamp: ~15 tiny kernels.  Launched eagerly they
     # are asynchronous and hide behind the previous generation kernel; --graph-policy captures them once into a hipGraph
@@ -243,6 +389,8 @@ def main():
                     base = 0
                 state = env.reset()
                 gen_in_ep = 0
+                if it >= W:
+                    reset_steps.append(it - W)
                 if it <= W:
                     base = 0
             if fused_table is not None:
@@ -252,21 +400,38 @@ def main():
                 actions = static_actions
             else:
                 actions = policy(state)
-            timed = it >= W and (it - W) % args.event_stride == 0
-            if timed:
-                ev0[it - W].record()
+            if it >= W and (it - W) % stride == 0:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e); mark_step.append(it - W)
             if fused_table is not None:
                 state, _, _ = env.batch.act_step(fused_table)
             else:
                 state, _, _ = env.step(actions)
-            if timed:
-                ev1[it - W].record()
             gen_in_ep += 1
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e); mark_step.append(K)
         barrier()
         elapsed = time.perf_counter() - t0
         live += steps_sum() - base
-    n_timed = len(range(0, K, args.event_stride))
-    kern_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(0, K, args.event_stride)) * K / n_timed
+    # cost of an empty event pair on this stream (an event costs stream time too): measured, then subtracted from every bracket
+    ea = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
+    eb = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
+    for a_, b_ in zip(ea, eb):
+        a_.record(); b_.record()
+    torch.cuda.synchronize()
+    pair_ms = sorted(a_.elapsed_time(b_) for a_, b_ in zip(ea, eb))[len(ea) // 2]
+    span_ms, span_kernels = 0., 0
+    for j in range(len(marks) - 1):
+        a_, b_ = mark_step[j], mark_step[j + 1]
+        if any(a_ < r <= b_ for r in reset_steps) or args.policy != 'fused':      # (the reset of step r is enqueued before the mark of step r)
+            continue                                    # a reset kernel (or policy kernels) inside the span: not a pure generation-kernel span
+        span_ms += max(marks[j].elapsed_time(marks[j + 1]) - pair_ms, 0.)
+        span_kernels += b_ - a_
+    if span_kernels == 0:                               # policies that launch their own kernels between generations: fall back to the step time
+        span_ms, span_kernels = elapsed * 1e3, K
+    kern_ms = span_ms / span_kernels * K
 
     red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
     tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=red_dev)
@@ -285,7 +450,8 @@ def main():
         live_per_launch = live_all / world / K
         bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
-        traffic = pmc_traffic_per_launch(live_per_launch)
+        traffic, traffic_src = pmc_traffic_per_launch(live_per_launch)
+        first_gen = W % EPISODE_GENS + 1
         out = {
             'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed_max / K * 1e3, 'higher_is_better': True,
@@ -300,13 +466,25 @@ def main():
                                   'hip': 'mbx_gauss_policy (both MLPs over the whole batch, one launch) + mbx_step per generation',
                                   'torch': 'both actor MLPs as batched PyTorch ops every generation' + (', hipGraph replay' if args.graph_policy else ''),
                                   'table': '(mu, sigma) gathered from the per-fes table with PyTorch ops' + (', hipGraph replay' if args.graph_policy else '')}[args.policy],
-                       'kernel_timing': f'HIP events around every {args.event_stride}-th generation kernel'},
+                       'kernel_timing': f'one HIP event every {stride} generations on the launch stream; consecutive events bracket {stride} back-to-back '
+                                        f'generation kernels (all of them are covered), minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)',
+                       'timed_window': f'{K} consecutive lock-step generations starting at generation {first_gen} of an episode of {EPISODE_GENS} '
+                                       f'(episodes restart with mbx_reset inside the window when it is longer)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_rlepso_step',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': (f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
+                                            f"run's live instances (not collected during this run)") if traffic_src else None,
+                         'kernel': 'k_rlepso_step<256, 100, 10, 5>',
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
-                         'live_instances_per_launch': live_all / world / K},
+                         'live_instances_per_launch': live_all / world / K,
+                         'valu': valu_roofline(live_per_launch, avg_kernel_s)},
         }
+        if world == 1 and not args.no_other_configs:
+            try:
+                out['other_configs'] = other_configs()
+            except Exception as exc:                       # the headline line must survive a failure of the side legs
+                out['other_configs'] = {'error': repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -114,6 +114,16 @@ class LDE_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
 
     @torch.no_grad()
+    def policy_step(self, env, state, h, c):
+        """One lock-step generation of a BatchedPBO_Env: act (LSTM cell + heads + sampling over the whole batch) and env.step."""
+        actions, h, c = self.__net.act_batch(state.to(torch.float32), h, c)
+        state, _, _ = env.step(actions.contiguous())
+        return state, h, c
+
+    def policy_route(self):
+        return 'PyTorch-ROCm: one LSTM cell + two linear heads over [B, NP + 10] per generation (rocBLAS / hipBLASLt GEMMs)'
+
+    @torch.no_grad()
     def rollout_batch(self, env, max_steps=None):
         if max_steps is None:
             bc = env.batch.cfg
@@ -121,8 +131,7 @@ class LDE_Agent(Basic_Agent):
         state = env.reset()
         h, cc = self.__zeros(env.B)
         for _ in range(max_steps):
-            actions, h, cc = self.__net.act_batch(state.to(torch.float32), h, cc)
-            state, _, _ = env.step(actions.contiguous())
+            state, h, cc = self.policy_step(env, state, h, cc)
         res = env.results()
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}
 

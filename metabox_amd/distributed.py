@@ -28,10 +28,11 @@ def instance_table(n_problems, runs, sort_by_problem=True):
 
 def philox_seed(run, global_id, epoch_salt=0):
     """64-bit Philox key of an instance: depends on (run seed, global instance id, salt) only."""
-    x = (np.asarray(run, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-         ^ (np.asarray(global_id, dtype=np.uint64) + np.uint64(0xD1B54A32D192ED03)) * np.uint64(0xBF58476D1CE4E5B9)
-         ^ np.uint64(epoch_salt) * np.uint64(0x94D049BB133111EB))
-    x ^= x >> np.uint64(31)
+    with np.errstate(over='ignore'):                    # arithmetic modulo 2^64 is the point
+        x = (np.asarray(run, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+             ^ (np.asarray(global_id, dtype=np.uint64) + np.uint64(0xD1B54A32D192ED03)) * np.uint64(0xBF58476D1CE4E5B9)
+             ^ np.uint64(epoch_salt) * np.uint64(0x94D049BB133111EB))
+        x ^= x >> np.uint64(31)
     return x
 
 

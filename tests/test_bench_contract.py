@@ -44,3 +44,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_kernel_us'] * 1e-6) / 1e9) <= 1e-6 * r['achieved']
     assert r['algorithmic_bytes_per_env_step'] == 54057 and 0 < r['avg_kernel_us'] < 1e4
     assert r['traffic'] is None or 0.5 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 2.0
+    # event brackets are net of the empty-pair cost: the kernel cannot take longer than the step that contains it
+    assert r['avg_kernel_us'] <= d['ms_per_step'] * 1e3 * 1.02
+    assert 'generation' in d['config']['timed_window'] and 'every 2 generations' in d['config']['kernel_timing']
+    v = r['valu']
+    assert v is None or (v['bound'] == 'valu' and 0 < v['frac'][0] <= v['frac'][1] and v['wave_instructions_per_launch'] > 1e6)
+    oc = d['other_configs']
+    assert isinstance(oc, list) and len(oc) == 4, oc
+    assert [e['config'].split(':')[0] for e in oc] == ['config 3', 'config 3', 'config 4', 'config 5']
+    for e in oc:
+        assert e['ms_per_step'] > 0 and abs(e['env_steps_per_s'] - e['instances'] / (e['ms_per_step'] * 1e-3)) <= 1e-6 * e['env_steps_per_s']
+        assert 0 < e['roofline_frac'] < 1

@@ -35,4 +35,28 @@ if 'FETCH_SIZE' in step and 'WRITE_SIZE' in step:
         'hbm_bytes_per_launch': (2 * step['FETCH_SIZE']['mean'] + step['WRITE_SIZE']['mean']) * 1024}
     if 'SQ_ACTIVE_INST_VALU' in step and 'SQ_BUSY_CYCLES' in step:
         out['calibration']['valu_wave_instructions_per_launch'] = step['SQ_INSTS_VALU']['mean']
+    if 'SQ_INSTS_VALU_ADD_F64' in step and 'SQ_INSTS_VALU_INT32' in step and 'SQ_INSTS_VALU' in step:
+        # VALU issue bound of the generation kernel: wave-instructions by class x the issue cost of the class measured with
+        # tools/ubench/valu_rates.hip on this GPU (profiles/r02_valu_issue_rates.txt; cycles per wave-instruction per SIMD at saturation):
+        #   float64 add / mul / fma / min / cmp, v_mov_b64, cvt, v_mad_u64_u32, every compare / select / min / max / shift / 3-operand
+        #   integer op: 4;  float64 rcp / sqrt: 16;  float32 add / mul / fma, v_mov_b32, 32-bit add / sub / and / or / xor: 2;  float32 rcp etc.: 8.
+        # SQ_INSTS_VALU_INT32 mixes 2-cycle (add, logic) and 4-cycle (shift, mul, compare) instructions and the remainder of SQ_INSTS_VALU
+        # (moves, selects, compares, lane ops) is not broken down by the counters, so the bound is an interval: both at 2 / both at 4.
+        m = lambda c: step[c]['mean'] if c in step else 0.
+        f64 = m('SQ_INSTS_VALU_ADD_F64') + m('SQ_INSTS_VALU_MUL_F64') + m('SQ_INSTS_VALU_FMA_F64')
+        f32 = m('SQ_INSTS_VALU_ADD_F32') + m('SQ_INSTS_VALU_MUL_F32') + m('SQ_INSTS_VALU_FMA_F32')
+        fixed = 4 * (f64 + m('SQ_INSTS_VALU_INT64') + m('SQ_INSTS_VALU_CVT')) + 16 * m('SQ_INSTS_VALU_TRANS_F64') + 2 * f32 + 8 * m('SQ_INSTS_VALU_TRANS_F32')
+        i32 = m('SQ_INSTS_VALU_INT32')
+        other = m('SQ_INSTS_VALU') - (f64 + f32 + m('SQ_INSTS_VALU_INT64') + m('SQ_INSTS_VALU_CVT') + m('SQ_INSTS_VALU_TRANS_F64') + m('SQ_INSTS_VALU_TRANS_F32') + i32)
+        simds, clock = 256 * 4, 2.4e9
+        lo, hi = fixed + 2 * (i32 + other), fixed + 4 * (i32 + other)
+        out['valu_issue_bound'] = {
+            'wave_instructions_per_launch': {'total': m('SQ_INSTS_VALU'), 'f64_add_mul_fma': f64, 'f64_trans': m('SQ_INSTS_VALU_TRANS_F64'), 'f32_add_mul_fma': f32,
+                                             'f32_trans': m('SQ_INSTS_VALU_TRANS_F32'), 'int64': m('SQ_INSTS_VALU_INT64'), 'cvt': m('SQ_INSTS_VALU_CVT'), 'int32': i32,
+                                             'other_mov_cmp_select_lane': other},
+            'simd_cycles_per_launch': [lo, hi],
+            'issue_bound_us_at_2.4GHz': [lo / simds / clock * 1e6, hi / simds / clock * 1e6],
+            'active_lanes_per_valu_instruction': m('SQ_THREAD_CYCLES_VALU') / m('SQ_INSTS_VALU') if m('SQ_THREAD_CYCLES_VALU') else None,
+            'note': 'issue cost per class from tools/ubench/valu_rates.hip (profiles/r02_valu_issue_rates.txt); the interval prices SQ_INSTS_VALU_INT32 and the '
+                    'uncategorised remainder at 2 (low) or 4 (high) cycles; 1024 SIMDs at the nominal 2.4 GHz (the sustained clock under this load is lower, MI355X_MICROARCH.md DVFS note, so the wall-clock bound is higher)'}
 print(json.dumps(out, indent=1))

@@ -11,9 +11,12 @@ cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python "$ROOT/bench.py" --steps 199 --warmup 10 --no-cpu-baseline > "$OUT/trace.log" 2>&1
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY"; do
+# (one pass per quoted group: TCC counters cannot share a pass; 8 SQ counters per pass; no trace domains next to --pmc)
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
+            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32" \
+            "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM"; do
     name=$(echo $pass | cut -d' ' -f1)
-    rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1
+    rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline --no-other-configs > "$OUT/pmc_$name.log" 2>&1
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/pmc_hbm_traffic.json"
 rm -rf "$OUT"/trace "$OUT"/pmc_*/ 2>/dev/null
