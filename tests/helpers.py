@@ -31,6 +31,55 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+# ------------------------------------------------------------------------------------------------ branch divergences, proven
+# The reference and this build compute the same float64 objective with different instruction sequences (numpy's SIMD transcendentals /
+# BLAS vs libm or the kernels' own routines): costs agree to ~1e-15 at first and, because a PSO amplifies perturbations, to 1e-13 .. 1e-10
+# late in a 199-generation episode.  An integer-valued output (per_no_improve, hence the re-initialisation mask and fes; reward; done)
+# can therefore differ only where the comparison that produces it, `new_cost < c_cost` (rlepso_optimizer.py:225-233), is closer than that
+# deviation.  Instead of granting the tests a budget of mismatching generations, the FIRST generation at which the bookkeeping of an episode
+# differs is examined: for every particle whose stagnation counter differs, the reference's own margin |new_cost - c_cost| must be no larger
+# than twice the deviation between the two implementations' operands (+ 4 ulp), and that deviation must itself be inside the parity
+# tolerance.  Everything before that generation must be exact; afterwards the two runs are different (equally valid) trajectories and only
+# the float tolerances on gbest / cost curves apply.  tests/golden/rlepso_ties.npz (tools/gen_golden.py rlepso_ties) holds the reference's
+# per-generation per_no_improve for every episode and its c_cost for the episodes that need the proof.
+TIE_RTOL = 1e-9
+
+
+def prove_tie_arrays(rp, rn, ref_pni, prev_cc, cur_cc, cur_pni, ledger, who, case, g):
+    """rp / rn: the reference side's c_cost before / after the update, ref_pni its counters after; the other arguments are this side's."""
+    cur_pni, ref_pni = np.asarray(cur_pni, dtype=np.float64), np.asarray(ref_pni, dtype=np.float64)
+    if np.array_equal(cur_pni, ref_pni):
+        return True
+    rec = []
+    for i in np.nonzero(cur_pni != ref_pni)[0]:
+        margin = abs(rn[i] - rp[i])
+        dev = abs(cur_cc[i] - rn[i]) + abs(prev_cc[i] - rp[i])
+        assert dev <= TIE_RTOL * abs(rn[i]) + ATOL, (who, case, g, int(i), 'operands outside the parity tolerance', dev, rn[i])
+        assert margin <= 2 * dev + 4 * np.spacing(abs(rn[i])), (who, case, g, int(i), 'a decision differs although the reference margin exceeds the '
+                                                                'deviation between the implementations', margin, dev)
+        rec.append((int(i), float(margin / np.spacing(abs(rn[i]))), float(dev / np.spacing(abs(rn[i])))))
+    ledger.append((who, case, g, rec))
+    return False
+
+
+def prove_tie(ties, case, g, prev_cc, cur_cc, cur_pni, ledger, who):
+    """Compare the stagnation counters after update() number g (0-based) with the reference's.  Returns True when they are identical;
+    otherwise proves that every differing particle sits on a near-tie (see above), appends a record to `ledger` and returns False."""
+    ref_pni = ties[f'{case}/pni'][g + 1]
+    if np.array_equal(np.asarray(cur_pni, dtype=np.float64), ref_pni.astype(np.float64)):
+        return True
+    key = f'{case}/ccost'
+    assert key in ties.files, (f'{who}: {case}: bookkeeping differs from the reference at generation {g}, but the fixture holds no reference '
+                               f'c_cost for this episode: add it to EXTRA_TIE_CASES in tools/gen_golden.py and regenerate rlepso_ties')
+    return prove_tie_arrays(ties[key][g], ties[key][g + 1], ref_pni, prev_cc, cur_cc, cur_pni, ledger, who, case, g)
+
+
+def print_ledger(ledger):
+    for who, case, g, rec in ledger:
+        parts = ', '.join(f'particle {i}: reference margin {m:.0f} ulp <= 2 x deviation {d:.0f} ulp' for i, m, d in rec)
+        print(f'  [{who}] {case}: first branch divergence at generation {g}: {parts}')
+
+
 def fake_results(rs, names, problem_names):
     """Synthetic test.pkl-shaped results dict (schema of src/tester.py:123-127) drawn from RandomState `rs`; shared by
     tools/gen_golden.py (which feeds it to the reference's metric functions) and the metric tests."""
