@@ -85,8 +85,10 @@ def test_lde_tape_replay_matches_reference_episodes():
         batch.close()
 
 
-@pytest.mark.parametrize('suite,dim', [('bbob', 10), ('bbob-noisy', 30)])
-def test_lde_philox_parity_with_oracle(suite, dim):
+# NP = 50 is the reference's population (lde_optimizer.py:10-14, lde_agent.py:37); NP = 100 is BASELINE.json config 3 as written
+# ("LDE ... dim=30 pop=100"), reachable through config.NP_override: same kernel family, run-time geometry, 512 threads, 90.8 KB of LDS.
+@pytest.mark.parametrize('suite,dim,NP', [('bbob', 10, 50), ('bbob-noisy', 30, 50), ('bbob-noisy', 30, 100)])
+def test_lde_philox_parity_with_oracle(suite, dim, NP):
     from metabox_amd.suite import Batch
     from metabox_amd._abi import ALGO_LDE
     s, ids = _suite(suite, dim)
@@ -119,8 +121,10 @@ def test_lde_philox_parity_with_oracle(suite, dim):
     batch.close()
 
 
-def test_lde_large_batch_properties():
-    """16384 instances (BASELINE.json config 3 size) on bbob-noisy d=30: deterministic, shard-independent, sorted."""
+@pytest.mark.parametrize('NP', [50, 100])
+def test_lde_large_batch_properties(NP):
+    """16384 instances (BASELINE.json config 3 size) on bbob-noisy d=30, at the reference's NP = 50 and at the configuration's pop = 100:
+    deterministic, shard-independent, sorted; the launch geometry is the documented one."""
     from metabox_amd.suite import Batch
     from metabox_amd._abi import ALGO_LDE
     s, ids = _suite('bbob-noisy', 30)
@@ -131,6 +135,10 @@ def test_lde_large_batch_properties():
 
     def run(sel):
         b = Batch(s, ALGO_LDE, pidx[sel], seeds[sel], NP, 60000, 1200, 50)
+        info = b.launch_info()
+        assert info['threads'] == 512 and info['fixed_geometry'] == (3 if NP == 50 else 0), info
+        assert info['lds_bytes'] == {50: 53248, 100: 90816}[NP], info      # three workgroups per CU at NP = 50, one at NP = 100
+        assert b.state_dim == NP + 10 and b.action_dim == 2 * NP
         b.reset()
         for _ in range(6):
             st, _, _ = b.step(act[sel].contiguous())
@@ -209,3 +217,29 @@ def test_lde_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch):
         states.append(np.stack([batch.read_state(b) for b in range(B)]))
         batch.close()
     assert np.array_equal(states[0], states[1], equal_nan=True)
+
+
+def test_lde_config3_population_through_the_plugin_surface():
+    """BASELINE.json config 3 as written (pop = 100) through LDE_Agent / LDE_Optimizer / BatchedPBO_Env: config.NP_override = 100 sizes the
+    PolicyNet (state NP + 10, action 2 NP) and the batch; a seeded fresh policy (no shipped weights fit 2 NP = 200 outputs) rolls out."""
+    from metabox_amd.agent import LDE_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import LDE_Optimizer
+    cfg = get_config(['--problem', 'bbob-noisy', '--dim', '30', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    cfg.NP_override = 100
+    torch.manual_seed(3)
+    agent = LDE_Agent(cfg).to('cuda')
+    opt = LDE_Optimizer(cfg)
+    assert cfg.NP == 100 and cfg.node_dim == 110 and cfg.output_dim_actor == 200
+    ps = problems('bbob-noisy', 30)
+    ids = sorted(ps)
+    env = BatchedPBO_Env([ps[i] for i in ids], opt, np.arange(60) % len(ids), np.arange(60, dtype=np.uint64) + 5)
+    assert env.state_dim == 110 and env.action_dim == 200
+    out = agent.rollout_batch(env, max_steps=12)
+    fes = out['fes'].cpu().numpy()
+    assert np.all(fes == 100 * 13) and np.all(np.isfinite(out['cost'].cpu().numpy()))
+    cost = out['cost'].cpu().numpy()
+    assert np.all(cost[:, -1] <= cost[:, 0])
+    env.close()
