@@ -133,18 +133,29 @@ class DE_DDQN_Agent(Basic_Agent):
         return {k: res[k] for k in ('cost', 'fes', 'return', 'steps', 'cost_len')}
 
     # ---- learning -------------------------------------------------------------------------------------
-    def __learn_from_replay(self):
+    def learn_from_batch(self, obs, act, rew, nxt, dn, sync_gradients=False):
+        """One double-DQN update on a mini-batch (de_ddqn_agent.py:79-89): MSE between Q(s, a) and r + (1 - done) gamma max_a' Q_target(s', a'),
+        AdamW step.  Shared by train_episode (host replay) and train_batch (device replay)."""
         cfg = self.__config
-        obs, act, rew, nxt, dn = (t.to(self.__device) for t in self.__replay_buffer.sample(cfg.batch_size))
         q_taken = self.__pred_func(obs).gather(1, act.view(-1, 1).long()).squeeze(1)
         with torch.no_grad():
             target = rew + (1 - dn) * cfg.gamma * self.__target_func(nxt).max(1)[0]
         self.__optimizer.zero_grad()
-        self.__criterion(q_taken, target).backward()
+        loss = self.__criterion(q_taken, target)
+        loss.backward()
+        if sync_gradients:
+            from ..distributed import average_gradients
+            average_gradients(list(self.__pred_func.parameters()))
         self.__optimizer.step()
         self.__global_ls += 1
-        if self.__global_ls >= cfg.save_interval * self.__cur_checkpoint:
+        if getattr(cfg, 'agent_save_dir', None) and self.__global_ls >= cfg.save_interval * self.__cur_checkpoint:
             self.__checkpoint()
+        return loss
+
+    def __learn_from_replay(self):
+        cfg = self.__config
+        obs, act, rew, nxt, dn = (t.to(self.__device) for t in self.__replay_buffer.sample(cfg.batch_size))
+        self.learn_from_batch(obs, act, rew, nxt, dn)
 
     def train_batch(self, env, max_updates=None, updates_per_step=1):
         """Double-DQN training over a lock-step BatchedPBO_Env.  Every env step all B instances act epsilon-greedily on the device,
@@ -153,7 +164,7 @@ class DE_DDQN_Agent(Basic_Agent):
         the target network, refreshed every update_target_steps updates) follow -- the reference's loop (de_ddqn_agent.py:70-106)
         with a batch axis.  By construction the data : update ratio is B times the reference's.  Gradients are averaged across ranks.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'})."""
-        from ..distributed import average_gradients
+        from ..distributed import all_ranks_any
         cfg, dev = self.__config, env.batch.device
         net, tgt = self.__pred_func, self.__target_func
         B, S = env.B, cfg.state_size
@@ -163,12 +174,11 @@ class DE_DDQN_Agent(Basic_Agent):
                                     act=torch.empty(cap, dtype=torch.int64, device=dev), rew=torch.empty(cap, device=dev),
                                     done=torch.empty(cap, device=dev), size=0, head=0)
         rb = self._dev_replay
-        params = list(net.parameters())
         state = env.reset().to(torch.float32).clone()
         alive = torch.ones(B, dtype=torch.bool, device=dev)
         ret_sum = torch.zeros(B, dtype=torch.float64, device=dev)
         updates, exceed = 0, False
-        while bool(alive.any()) and not exceed:
+        while all_ranks_any(bool(alive.any()), dev) and not exceed:      # global loop control: every rank issues the same collectives
             with torch.no_grad():
                 greedy = net(state).argmax(dim=1)
                 explore = torch.rand(B, device=dev) < cfg.epsilon
@@ -186,20 +196,13 @@ class DE_DDQN_Agent(Basic_Agent):
                 rb['size'] = min(cap, rb['size'] + n)
             alive = alive & (done == 0)
             state = nstate
-            if rb['size'] >= min(cfg.warm_up_size, cap):
+            # warm-up reached on ANY rank starts the updates on EVERY rank (same number of gradient all-reduces everywhere); a rank that is
+            # still short samples its mini-batch, with replacement, from what it has
+            if all_ranks_any(rb['size'] >= min(cfg.warm_up_size, cap), dev) and rb['size'] >= 1:
                 for _ in range(updates_per_step):
                     idx = torch.randint(0, rb['size'], (cfg.batch_size,), device=dev)
-                    q_taken = net(rb['obs'][idx]).gather(1, rb['act'][idx].view(-1, 1)).squeeze(1)
-                    with torch.no_grad():
-                        target = rb['rew'][idx] + (1 - rb['done'][idx]) * cfg.gamma * tgt(rb['nxt'][idx]).max(1)[0]
-                    self.__optimizer.zero_grad()
-                    self.__criterion(q_taken, target).backward()
-                    average_gradients(params)
-                    self.__optimizer.step()
-                    self.__global_ls += 1
+                    self.learn_from_batch(rb['obs'][idx], rb['act'][idx], rb['rew'][idx], rb['nxt'][idx], rb['done'][idx], sync_gradients=True)
                     updates += 1
-                    if getattr(cfg, 'agent_save_dir', None) and self.__global_ls >= cfg.save_interval * self.__cur_checkpoint:
-                        self.__checkpoint()
                     if self.__global_ls % cfg.update_target_steps == 0:
                         tgt.load_state_dict(net.state_dict())
                     if self.__global_ls >= self.__max_learning_step or (max_updates is not None and updates >= max_updates):

@@ -292,7 +292,7 @@ class GLEET_Agent(Basic_Agent):
         (step, swarm) pairs still running.  By construction one optimizer step consumes B trajectories instead of one.  Gradients are
         averaged across ranks when torch.distributed is initialised.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'}) with per-batch means."""
-        from ..distributed import average_gradients
+        from ..distributed import all_ranks_any, average_gradients
         c = self.__config
         actor, critic = self.actor, self.critic
         params = list(actor.parameters()) + list(critic.parameters())
@@ -310,7 +310,7 @@ class GLEET_Agent(Basic_Agent):
         alive = torch.ones(B, dtype=torch.bool, device=state.device)
         ret_sum = torch.zeros(B, dtype=torch.float64, device=state.device)
         updates, exceed = 0, False
-        while bool(alive.any()) and not exceed:
+        while all_ranks_any(bool(alive.any()), state.device) and not exceed:   # global loop control: every rank issues the same collectives
             S, A, LP, V, R, M = [], [], [], [], [], []
             for _ in range(c.n_step):
                 with torch.no_grad():

@@ -136,16 +136,21 @@ class LDE_Agent(Basic_Agent):
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}
 
     def __discounted(self, rewards, n_traj):
-        """Per-trajectory discounted returns (gamma = 0.99) over `n_traj` equally long segments of `rewards`."""
+        """Discounted returns (gamma = 0.99) exactly as the reference slices them (lde_agent.py:70-83): the flat reward vector is cut into
+        n_traj segments of length len(rewards) // n_traj -- which are the trajectories only when all of them have the same length; with
+        ragged trajectories (an early `done`) the reference's segments straddle trajectory boundaries and the last len % n_traj rewards
+        are dropped.  Kept as is: the loss then averages over the first n_traj * length samples (torch broadcasting would fail otherwise,
+        so the caller trims log_prob to the same length)."""
         gamma = self.__config.gamma
-        out = np.array(rewards, dtype=np.float64, copy=True).reshape(n_traj, -1)
-        for t in range(out.shape[1] - 2, -1, -1):
+        r = np.asarray(rewards, dtype=np.float64)
+        length = r.shape[0] // n_traj
+        out = r[:n_traj * length].reshape(n_traj, length).copy()
+        for t in range(length - 2, -1, -1):
             out[:, t] += gamma * out[:, t + 1]
         return out.reshape(-1)
 
     def __reinforce_step(self, inputs, hs, cs, actions, returns):
         """One REINFORCE update: loss = -mean(log pi(a + 1e-8 | s, h, c) * discounted return)  (lde_agent.py:124-133)."""
-        c = self.__config
         mean, std, _, _ = self.__net.forward(inputs[None], hs[None], cs[None])
         log_prob = torch.distributions.Normal(mean[0], std[0]).log_prob(actions + 1e-8).sum(1)
         loss = -(log_prob * returns).mean()
@@ -159,32 +164,38 @@ class LDE_Agent(Basic_Agent):
             save_class(c.agent_save_dir, f'checkpoint{self.__cur_checkpoint}', self)
             self.__cur_checkpoint += 1
 
-    def train_episode(self, env):
+    def train_episode(self, env, forced_actions=None):
         """REINFORCE over TRAJECTORY_NUM = 20 trajectories of at most TRAJECTORY_LENGTH = 50 steps, every trajectory
-        restarting the environment with a zero LSTM state (reference: lde_agent.py:85-145)."""
+        restarting the environment with a zero LSTM state (reference: lde_agent.py:85-145).  `forced_actions` ([n_steps, 2 NP]) replaces
+        the sampled actions (parity test against a recorded reference update)."""
         c = self.__config
         dev = c.device
         self.__optimizer.zero_grad()
         feats, acts, hs, cs, rews = [], [], [], [], []
-        total = 0
+        total, k = 0, 0
         for _ in range(c.TRAJECTORY_NUM):
             obs = env.reset()
             h, cell = self.__zeros()
             for _step in range(c.TRAJECTORY_LENGTH):
-                obs = obs.reshape(self.__feature_shape)
-                with torch.no_grad():
-                    a, h_next, c_next = self.__net.sampler(torch.FloatTensor(obs[None, :]).to(dev), h, cell)
-                a = np.squeeze(a.reshape(1, self.__BATCH_SIZE, -1).cpu().numpy(), axis=0)
+                obs = np.asarray(obs).reshape(self.__feature_shape)
+                # no torch.no_grad() here, like the reference: the (h, c) fed to the update below stay connected to the LSTM steps that
+                # produced them, so loss.backward() also back-propagates through time along every trajectory (lde_agent.py:99-111, 124-133)
+                a, h_next, c_next = self.__net.sampler(torch.FloatTensor(obs[None, :]).to(dev), h, cell)
+                a = np.squeeze(a.reshape(1, self.__BATCH_SIZE, -1).detach().cpu().numpy(), axis=0)
+                if forced_actions is not None:
+                    a = np.asarray(forced_actions[k], dtype=np.float32).reshape(a.shape)
+                k += 1
                 nxt, reward, done = env.step(a)
                 feats.append(obs[0]); acts.append(a[0]); hs.append(h[0, 0]); cs.append(cell[0, 0])
                 rews.append(float(np.mean(reward)))
                 total += np.mean(reward)
-                h, cell, obs = h_next, c_next, nxt.copy()
+                h, cell, obs = h_next, c_next, np.array(nxt, copy=True)
                 if done:
                     break
         returns = torch.FloatTensor(self.__discounted(rews, c.TRAJECTORY_NUM)).to(dev)
-        self.__reinforce_step(torch.FloatTensor(np.stack(feats)).to(dev), torch.stack(hs), torch.stack(cs),
-                              torch.FloatTensor(np.stack(acts)).to(dev), returns)
+        n = returns.shape[0]                                 # == len(rews) unless the trajectories are ragged (see __discounted)
+        self.__reinforce_step(torch.FloatTensor(np.stack(feats))[:n].to(dev), torch.stack(hs)[:n], torch.stack(cs)[:n],
+                              torch.FloatTensor(np.stack(acts))[:n].to(dev), returns)
         self.__optimizer.step()
         self.__after_update()
         return self.__learn_steps >= c.max_learning_step, {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1],
@@ -193,8 +204,10 @@ class LDE_Agent(Basic_Agent):
     def train_batch(self, env, max_updates=None):
         """Batched REINFORCE: the B instances of a lock-step BatchedPBO_Env are the trajectories (the
         reference collects 20 of them one after the other); TRAJECTORY_LENGTH = 50 steps each, then one update, repeated
-        until every instance is done.  Finished instances are masked out; gradients are averaged over ranks."""
-        from ..distributed import average_gradients
+        until every instance is done.  Finished instances are masked out; gradients are averaged over ranks.  The update's arithmetic
+        (log-probability of action + 1e-8, discounted returns, back-propagation through the collection-phase LSTM steps) is the one
+        tests/test_training_parity.py pins against the reference for train_episode."""
+        from ..distributed import all_ranks_any, average_gradients
         c = self.__config
         dev = env.batch.device
         state = env.reset().to(torch.float32).clone()
@@ -203,11 +216,13 @@ class LDE_Agent(Basic_Agent):
         alive = torch.ones(B, dtype=torch.bool, device=dev)
         ret_sum = torch.zeros(B, dtype=torch.float64, device=dev)
         updates, exceed, loss = 0, False, torch.zeros(())
-        while bool(alive.any()) and not exceed:
+        while all_ranks_any(bool(alive.any()), dev) and not exceed:       # global loop control: every rank issues the same collectives
             S, H, C_, A, R, M = [], [], [], [], [], []
+            h, cell = h.detach(), cell.detach()                     # the previous segment's graph was consumed by its update
             for _ in range(c.TRAJECTORY_LENGTH):
-                with torch.no_grad():
-                    a, h2, c2 = self.__net.act_batch(state, h, cell)
+                # the LSTM steps of the collection phase stay in the autograd graph (see train_episode): the update back-propagates through time
+                mu_, sg_, h2, c2 = self.__net.forward(state[None], h, cell)
+                a = torch.clip(mu_[0] + sg_[0] * torch.randn_like(mu_[0]), 0, 1).detach()
                 S.append(state); H.append(h[0]); C_.append(cell[0]); A.append(a); M.append(alive.clone())
                 nstate, reward, done = env.step(a.contiguous())
                 r = torch.nan_to_num(reward.to(torch.float32), nan=0.0, posinf=0.0, neginf=0.0) * alive

@@ -15,7 +15,7 @@ from torch.distributions import Normal
 
 from .basic_agent import Basic_Agent
 from .networks import MLP
-from .utils import Memory, save_class
+from .utils import save_class
 
 
 class Actor(nn.Module):
@@ -46,7 +46,8 @@ class Actor(nn.Module):
     def _fused_weights(self):
         """The mu- and sigma-networks share their input and their shapes, so one generation needs 3 (batched) GEMMs instead
         of 6: layer 1 of both nets is one [1 -> 128] affine map, layers 2 and 3 are 2-batch bmm's."""
-        key = tuple(p.data_ptr() for p in self.parameters()) + (str(next(self.parameters()).device),)
+        # keyed on (storage, in-place version): optimizer.step() and load_state_dict() modify parameters in place
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(next(self.parameters()).device),)
         if getattr(self, '_fw_key', None) != key:
             nets = (self.mu_net.net, self.sigma_net.net)
             lin = [[n._modules[f'layer{i}-linear'] for n in nets] for i in range(3)]
@@ -267,36 +268,46 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
                 'cost_len': res['cost_len']}
 
-    # ---- batched training -------------------------------------------------------------------------
-    def train_batch(self, env, max_updates=None):
-        """PPO over a lock-step BatchedPBO_Env: the reference's n_step = 10 segments / K_epochs = 3 / clipped surrogate +
-        clipped value loss (rlepso_agent.py:140-276), with every quantity carrying a leading batch axis and the losses
-        averaged over the (step, instance) pairs that were still running.  Semantic difference from the reference, by
-        construction: one optimizer step now consumes B trajectories instead of one, and `learn_steps` counts optimizer
-        steps.  Gradients are averaged across ranks when torch.distributed is initialised.
-        Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'}) with per-batch means."""
-        from ..distributed import average_gradients
+    # ---- training: PPO (reference rlepso_agent.py:113-292), one implementation for B >= 1 -------------------------------------
+    def train_batch(self, env, max_updates=None, forced_actions=None):
+        """PPO over a lock-step batch of environments: n_step = 10 segments, K_epochs = 3 optimizer steps per segment, clipped
+        surrogate + clipped value loss, n-step returns bootstrapped from the critic at the segment's last state (rlepso_agent.py:140-276).
+        Every quantity carries a leading [T, B] shape and the losses average over the (step, instance) pairs that were still running;
+        at B = 1 this IS the reference's update (tests/test_training_parity.py replays reference segments: same gradients, same weights).
+        For B > 1 one optimizer step consumes B trajectories -- a semantic difference by construction -- and `learn_steps` counts
+        optimizer steps.  With torch.distributed initialised, gradients are averaged over ranks and the loop control is global
+        (every rank runs the same number of segments and optimizer steps; a rank whose shard has finished contributes zero gradients).
+
+        env: BatchedPBO_Env-like (B, reset() -> [B, 1], step(actions [B, 35]) -> (state, reward, done), results()).
+        forced_actions: optional [T_total, B, 35] tensor replayed instead of sampling (parity tests).
+        Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps', 'last_losses'})."""
+        from ..distributed import all_ranks_any, average_gradients
         config = self.__config
         gamma, n_step, K_epochs, eps_clip = config.gamma, config.n_step, config.K_epochs, config.eps_clip
         actor, critic = self.__actor, self.__critic
         params = list(actor.parameters()) + list(critic.parameters())
         B = env.B
         state = env.reset().to(torch.float32).clone()                     # [B, 1]
-        alive = torch.ones(B, dtype=torch.bool, device=state.device)
-        ret_sum = torch.zeros(B, dtype=torch.float64, device=state.device)
-        updates, exceed = 0, False
+        dev = state.device
+        alive = torch.ones(B, dtype=torch.bool, device=dev)
+        ret_sum = torch.zeros(B, dtype=torch.float64, device=dev)
+        updates, exceed, t_all = 0, False, 0
+        baseline_loss = reinforce_loss = torch.zeros((), device=dev)
 
         def evaluate(states, actions):
             mu, sigma = actor.distribution(states)
-            dist_ = Normal(mu, sigma)
-            return dist_.log_prob(actions).sum(-1), critic.value_head(states).squeeze(-1)
+            return Normal(mu, sigma).log_prob(actions).sum(-1), critic.value_head(states).squeeze(-1)
 
-        while bool(alive.any()) and not exceed:
+        while all_ranks_any(bool(alive.any()), dev) and not exceed:
             S, A, LP, V, R, M = [], [], [], [], [], []
             for _ in range(n_step):
-                with torch.no_grad():
-                    mu, sigma = actor.distribution(state)
-                    action = torch.clamp(mu + sigma * torch.randn_like(mu), 0, 1)
+                if forced_actions is not None:
+                    action = forced_actions[t_all].to(dev)
+                else:
+                    with torch.no_grad():
+                        mu, sigma = actor.distribution(state)
+                        action = torch.clamp(mu + sigma * torch.randn_like(mu), 0, 1)
+                t_all += 1
                 logp, val = evaluate(state, action)
                 S.append(state); A.append(action); LP.append(logp); V.append(val); M.append(alive.clone())
                 nstate, reward, done = env.step(action.contiguous())
@@ -355,86 +366,33 @@ class RLEPSO_Agent(Basic_Agent):
             'return': float(ret_sum.mean()), 'learn_steps': self.__learning_time,
             'last_losses': (float(baseline_loss.detach()), float(reinforce_loss.detach()))}
 
-    # ---- training (PPO, single environment; reference rlepso_agent.py:113-292) ------------------------
     def train_episode(self, env):
-        config = self.__config
-        memory = Memory()
-        state = torch.FloatTensor(env.reset()).to(self.__device)
-        gamma, n_step, K_epochs, eps_clip = config.gamma, config.n_step, config.K_epochs, config.eps_clip
-        t, _R, is_done = 0, 0, False
+        """The reference's single-environment entry point (rlepso_agent.py:113-292): the B = 1 case of train_batch over a one-instance
+        view of the PBO_Env."""
+        exceed, info = self.train_batch(SingleEnvBatch(env, self.__device))
+        info.pop('last_losses', None)
+        info['normalizer'], info['gbest'] = env.optimizer.cost[0], env.optimizer.cost[-1]
+        return exceed, info
 
-        def info():
-            return {'normalizer': env.optimizer.cost[0], 'gbest': env.optimizer.cost[-1], 'return': _R,
-                    'learn_steps': self.__learning_time}
-        while not is_done:
-            t_s = t
-            entropy, bl_val_detached, bl_val = [], [], []
-            while t - t_s < n_step:
-                memory.states.append(state.clone())
-                action, log_lh, entro_p = self.__actor(state, require_entropy=True)
-                action = action.reshape(config.action_shape)
-                memory.actions.append(action.clone().detach())
-                memory.logprobs.append(log_lh)
-                entropy.append(entro_p.detach().cpu())
-                v_det, v = self.__critic(state)
-                bl_val_detached.append(v_det)
-                bl_val.append(v)
-                next_state, reward, is_done = env.step(action.cpu().numpy())
-                _R += reward
-                memory.rewards.append(torch.FloatTensor([reward]).to(self.__device))
-                t += 1
-                state = torch.FloatTensor(next_state).to(self.__device)
-                if is_done:
-                    break
-            t_time = t - t_s
-            old_actions = torch.stack(memory.actions)
-            old_states = torch.stack(memory.states).detach()
-            old_logprobs = torch.stack(memory.logprobs).detach().view(-1)
-            old_value = None
-            for _k in range(K_epochs):
-                if _k == 0:
-                    logprobs = memory.logprobs
-                else:
-                    logprobs, entropy, bl_val_detached, bl_val = [], [], [], []
-                    for tt in range(t_time):
-                        _, log_p, entro_p = self.__actor(old_states[tt], fixed_action=old_actions[tt], require_entropy=True)
-                        logprobs.append(log_p)
-                        entropy.append(entro_p.detach().cpu())
-                        v_det, v = self.__critic(old_states[tt])
-                        bl_val_detached.append(v_det)
-                        bl_val.append(v)
-                logprobs = torch.stack(logprobs).view(-1)
-                bl_val_detached = torch.stack(bl_val_detached).view(-1)
-                bl_val = torch.stack(bl_val).view(-1)
-                # n-step bootstrapped returns
-                R = self.__critic(state)[0]
-                Reward = []
-                for r in memory.rewards[::-1]:
-                    R = R * gamma + r
-                    Reward.append(R)
-                Reward = torch.stack(Reward[::-1], 0).view(-1)
-                ratios = torch.exp(logprobs - old_logprobs.detach())
-                advantages = Reward - bl_val_detached
-                surr1 = ratios * advantages
-                surr2 = torch.clamp(ratios, 1 - eps_clip, 1 + eps_clip) * advantages
-                reinforce_loss = -torch.min(surr1, surr2).mean()
-                if old_value is None:
-                    baseline_loss = ((bl_val - Reward) ** 2).mean()
-                    old_value = bl_val.detach()
-                else:
-                    vpredclipped = old_value + torch.clamp(bl_val - old_value, -eps_clip, eps_clip)
-                    baseline_loss = torch.max((bl_val - Reward) ** 2, (vpredclipped - Reward) ** 2).mean()
-                self.__optimizer_actor.zero_grad()
-                self.__optimizer_critic.zero_grad()
-                baseline_loss.backward()
-                reinforce_loss.backward()
-                self.__optimizer_actor.step()
-                self.__optimizer_critic.step()
-                self.__learning_time += 1
-                if self.__learning_time >= (config.save_interval * self.__cur_checkpoint):
-                    save_class(config.agent_save_dir, 'checkpoint' + str(self.__cur_checkpoint), self)
-                    self.__cur_checkpoint += 1
-                if self.__learning_time >= config.max_learning_step:
-                    return True, info()
-            memory.clear_memory()
-        return self.__learning_time >= config.max_learning_step, info()
+
+class SingleEnvBatch:
+    """B = 1 lock-step view of a reference-protocol PBO_Env (reset() -> state, step(action) -> (state, reward, done) with numpy /
+    Python scalars), for the agents' batched training loops."""
+
+    def __init__(self, env, device):
+        self.env, self.B, self.device = env, 1, torch.device(device)
+
+    def _state(self, s):
+        return torch.as_tensor(np.asarray(s, dtype=np.float64).reshape(1, -1), device=self.device)
+
+    def reset(self):
+        return self._state(self.env.reset())
+
+    def step(self, actions):
+        s, r, d = self.env.step(actions[0].detach().cpu().numpy())
+        return (self._state(s), torch.as_tensor([float(np.mean(r))], dtype=torch.float64, device=self.device),
+                torch.as_tensor([1 if d else 0], dtype=torch.uint8, device=self.device))
+
+    def results(self):
+        c = np.asarray(self.env.optimizer.cost, dtype=np.float64).reshape(1, -1)
+        return {'cost': torch.as_tensor(c)}

@@ -80,3 +80,16 @@ def average_gradients(params, group=None):
         n = g.numel()
         g.copy_(flat[o:o + n].view_as(g))
         o += n
+
+
+def all_ranks_any(flag, device=None, group=None):
+    """Logical OR of a per-rank Python bool over all ranks (one scalar all-reduce; the local value when torch.distributed is not
+    initialised).  The batched training loops use it so that every rank issues the same number of gradient all-reduces even though
+    shards finish their episodes at different generations."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    dev = device if (device is not None and dist.get_backend(group) == 'nccl') else torch.device('cpu')
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item())

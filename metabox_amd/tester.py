@@ -62,6 +62,13 @@ def _world():
     return 0, 1
 
 
+def _accel_device(config):
+    """The batched harness runs on the GPU whatever `--device` says (the reference's default is 'cpu'): agents follow the batch."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('the batched test / rollout harness needs an MI355X (torch.cuda.is_available() is False): there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
 def _pad51(row):
     row = list(row)
     while len(row) < N_COST:
@@ -69,10 +76,11 @@ def _pad51(row):
     return row
 
 
-def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0):
+def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0, n_logpoint=50):
     """Run `runner(suite_problems, problem_idx, seeds) -> results dict` over the (problem x run) table, sharded over
     ranks and optionally chunked; returns (cost [N, nlog+1], fes [N], ret [N]) as numpy arrays in table order plus the
-    wall time in ms."""
+    wall time in ms normalised to the whole table (max over ranks of wall / local instances, times N), so that wall / N is the
+    per-instance time whatever the number of ranks."""
     pidx, run = instance_table(len(problems), runs)
     n_total = len(pidx)
     rank, world = _world()
@@ -86,9 +94,18 @@ def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0):
         rows.append(pack_rows(runner(problems, pidx[a:b], seeds[a:b])))
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1000
-    local = torch.cat(rows, 0) if rows else torch.zeros(0, 1)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    # an empty shard (fewer instances than ranks) still takes part in the all-gather with the right width and device
+    local = torch.cat(rows, 0) if rows else torch.zeros(0, n_logpoint + 1 + 3, dtype=torch.float64, device=dev)
     full = unpack_rows(gather_rows(local, n_total))
-    return full['cost'].cpu().numpy(), full['fes'].cpu().numpy(), full['return'].cpu().numpy(), wall_ms
+    # per-instance wall time (the batched engine's T2, see module docstring): this rank's wall over ITS instances, the slowest rank counts
+    per_instance_ms = wall_ms / max(hi - lo, 1)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([per_instance_ms], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_instance_ms = float(t.item())
+    return full['cost'].cpu().numpy(), full['fes'].cpu().numpy(), full['return'].cpu().numpy(), per_instance_ms * n_total
 
 
 def _learnable_runner(agent, optimizer, suite_cache, early_stop=True):
@@ -169,14 +186,14 @@ class Tester(object):
         early = not getattr(cfg, 'fixed_horizon', False)
         for name, agent, optimizer in zip(self.agent_name_list, self.agent_for_cp, self.l_optimizer_for_cp):
             if hasattr(agent, 'to'):
-                agent.to(cfg.device)
-            cost, fes, _, wall = run_pairs(problems, _learnable_runner(agent, optimizer, cache, early), self.runs, cap)
+                agent.to(_accel_device(cfg))
+            cost, fes, _, wall = run_pairs(problems, _learnable_runner(agent, optimizer, cache, early), self.runs, cap, n_logpoint=cfg.n_logpoint)
             _fill(self.test_results, problems, name, self.runs, cost, fes)
             self.test_results['T1'][name] = 0.
             self.test_results['T2'][name] = wall / len(cost)
         for optimizer in self.t_optimizer_for_cp:
             name = type(optimizer).__name__
-            cost, fes, _, wall = run_pairs(problems, _random_search_runner(optimizer, cache), self.runs, cap)
+            cost, fes, _, wall = run_pairs(problems, _random_search_runner(optimizer, cache), self.runs, cap, n_logpoint=cfg.n_logpoint)
             _fill(self.test_results, problems, name, self.runs, cost, fes)
             self.test_results['T1'][name] = 0.
             self.test_results['T2'][name] = wall / len(cost)
@@ -201,7 +218,7 @@ def test_for_random_search(config):
         res['cost'][str(p)] = {name: []}
         res['fes'][str(p)] = {name: []}
     runs = getattr(config, 'test_runs', 51)
-    cost, fes, _, wall = run_pairs(problems, _random_search_runner(optimizer, {}), runs, getattr(config, 'n_instances', 0))
+    cost, fes, _, wall = run_pairs(problems, _random_search_runner(optimizer, {}), runs, getattr(config, 'n_instances', 0), n_logpoint=config.n_logpoint)
     _fill(res, problems, name, runs, cost, fes)
     res['T2'][name] = wall / len(cost)
     return res
@@ -227,9 +244,9 @@ def rollout(config):
             with open(config.agent_load_dir + agent_name + '/checkpoint' + str(cp) + '.pkl', 'rb') as f:
                 agent = pickle.load(f)
             if hasattr(agent, 'to'):
-                agent.to(config.device)
+                agent.to(_accel_device(config))
             cost, fes, ret, _ = run_pairs(problems, _learnable_runner(agent, optimizer, cache), runs,
-                                          getattr(config, 'n_instances', 0), epoch_salt=cp)
+                                          getattr(config, 'n_instances', 0), epoch_salt=cp, n_logpoint=config.n_logpoint)
             for k, p in enumerate(problems):
                 rows = slice(k * runs, (k + 1) * runs)
                 results['cost'][str(p)][agent_name][cp] = [_pad51(r) for r in cost[rows]]
@@ -275,8 +292,8 @@ def mgd_test(config):
     cache = {}
     for name, agent in zip(names, agents):
         if hasattr(agent, 'to'):
-            agent.to(config.device)
-        cost, fes, _, wall = run_pairs(problems, _learnable_runner(agent, optimizer, cache), runs, cap)
+            agent.to(_accel_device(config))
+        cost, fes, _, wall = run_pairs(problems, _learnable_runner(agent, optimizer, cache), runs, cap, n_logpoint=config.n_logpoint)
         _fill(results, problems, name, runs, cost, fes)
         results['T2'][name] = wall / len(cost)
     baseline = test_for_random_search(config)

@@ -82,3 +82,61 @@ def test_gradient_averaging_world2():
         assert p.exitcode == 0
     # rank r sees x = r+1: d/dW sum(Wx+b) = 4*(r+1) per entry, averaged over ranks 1 and 2 -> 6; bias grad 4
     assert np.allclose(gw, 6.0) and np.allclose(gb, 4.0)
+
+
+class _ScriptedShard:
+    """One-instance lock-step environment whose episode lasts `T` steps: stands for a rank's shard that finishes earlier / later than
+    the other rank's (the stop rule gbest <= 1e-8 and re-initialisation billing make episode lengths shard-dependent)."""
+
+    def __init__(self, T, seed):
+        self.T, self.B, self.t, self.rs = T, 1, 0, np.random.RandomState(seed)
+
+    def reset(self):
+        self.t = 0
+        return torch.tensor([[0.005]], dtype=torch.float64)
+
+    def step(self, actions):
+        self.t += 1
+        return (torch.tensor([[0.005 + 0.005 * self.t]], dtype=torch.float64), torch.tensor([float(self.rs.choice([-1., 1.]))], dtype=torch.float64),
+                torch.tensor([1 if self.t >= self.T else 0], dtype=torch.uint8))
+
+    def results(self):
+        return {'cost': torch.tensor([[1.0, 0.5]], dtype=torch.float64)}
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    from metabox_amd.config import get_config
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cpu', '--max_learning_step', '1000'])
+    cfg.agent_save_dir = None
+    cfg.save_interval = 10 ** 9
+    torch.manual_seed(0)                                            # identical initial weights on both ranks
+    agent = RLEPSO_Agent(cfg)
+    torch.manual_seed(100 + rank)                                   # different action noise per rank
+    exceed, info = agent.train_batch(_ScriptedShard(7 if rank == 0 else 23, rank))      # 1 segment vs 3 segments
+    flat = torch.cat([p.detach().reshape(-1) for p in list(agent.actor.parameters()) + list(agent.critic.parameters())])
+    q.put((rank, info['learn_steps'], flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batched_training_with_unequal_episode_lengths_world2():
+    """the number of gradient all-reduces per epoch used to depend on rank-local state (`while alive.any()` over the local
+    shard), so ranks whose shards finished at different generations issued different numbers of collectives and hung.  Loop control is
+    global now: both ranks run 3 segments x 3 optimizer steps (the finished rank contributes zero gradients) and end with identical weights."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert outs[0][1] == outs[1][1] == 9
+    assert np.array_equal(outs[0][2], outs[1][2])

@@ -1,0 +1,243 @@
+"""Training updates against the reference.
+
+tests/golden/train_updates.npz (tools/gen_golden.py train) holds, for scripted environments, what the reference's agents saw and did in
+one training call and what it did to them: initial weights, states / sampled actions / rewards, the gradient of every parameter at every
+optimizer step, the weights afterwards.
+  * RLEPSO: `RLEPSO_Agent.train_episode` (rlepso_agent.py:113-292) on episodes of 10, 7 and 13 steps (one full segment, a short one, 10 + 3);
+  * LDE: `LDE_Agent.train_episode` (lde_agent.py:85-145), 20 trajectories of equal and of ragged length;
+  * DE-DDQN: three double-DQN updates (de_ddqn_agent.py:79-89) on recorded replay mini-batches.
+The same data is replayed through THIS framework's update code -- `train_batch` at B = 1 (which `train_episode` is), with the recorded
+actions forced -- and the gradients at every optimizer step and the final weights must agree.
+
+Tolerances (float32 networks, CPU): gradients 2e-5 relative to the largest entry of the tensor (+1e-9); weight change after the updates
+within 2 % of the learning rate per step taken (Adam's first steps move every weight by ~lr, so the DELTA is what carries information).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load
+
+G = load('train_updates.npz')
+
+
+def _cfg(problem='bbob', dim=10):
+    from metabox_amd.config import get_config
+    cfg = get_config(['--problem', problem, '--dim', str(dim), '--device', 'cpu', '--max_learning_step', '1000'])
+    cfg.agent_save_dir = None
+    cfg.save_interval = 10 ** 9
+    return cfg
+
+
+class _Sub:
+    """View of the fixture under a key prefix, with the `.files` / [] protocol load_exported_weights expects."""
+
+    def __init__(self, prefix):
+        self.prefix = prefix
+        self.files = [k[len(prefix):] for k in G.files if k.startswith(prefix)]
+
+    def __getitem__(self, k):
+        return G[self.prefix + k]
+
+
+def _hook(opt, named, sink, tag):
+    orig = opt.step
+
+    def step(*a, **k):
+        sink.append((tag, {n: p.grad.detach().clone().numpy() for n, p in named}))
+        return orig(*a, **k)
+    opt.step = step
+
+
+def _close_grad(got, want, what):
+    scale = max(np.abs(want).max(), 1e-30)
+    assert np.abs(got - want).max() <= 2e-5 * scale + 1e-9, (what, np.abs(got - want).max(), scale)
+
+
+# ------------------------------------------------------------------------------------------------------------- RLEPSO / PPO
+_REF2OURS = {'_Actor__mu_net.': 'mu_net.', '_Actor__sigma_net.': 'sigma_net.', '_Critic__value_head.': 'value_head.'}
+
+
+def _ours(name):
+    for a, b in _REF2OURS.items():
+        if name.startswith(a):
+            return b + name[len(a):]
+    raise KeyError(name)
+
+
+class _ScriptedBatch:
+    """B = 1 lock-step environment that replays the fixture's states / rewards and ends after T steps."""
+
+    def __init__(self, tag):
+        self.states, self.rewards, self.B, self.t = G[f'{tag}/states'], G[f'{tag}/rewards'], 1, 0
+        self.seen = []
+
+    def reset(self):
+        self.t = 0
+        return torch.as_tensor(self.states[0].reshape(1, 1))
+
+    def step(self, actions):
+        self.seen.append(actions.detach().numpy().copy())
+        self.t += 1
+        done = self.t >= len(self.rewards)
+        return (torch.as_tensor(self.states[self.t].reshape(1, 1)), torch.tensor([self.rewards[self.t - 1]], dtype=torch.float64),
+                torch.tensor([1 if done else 0], dtype=torch.uint8))
+
+    def results(self):
+        return {'cost': torch.tensor([[1.0, 0.5]], dtype=torch.float64)}
+
+
+@pytest.mark.parametrize('tag', ['ppo10', 'ppo7', 'ppo13'])
+def test_rlepso_ppo_update_reproduces_the_reference(tag):
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    agent = RLEPSO_Agent(_cfg()).load_exported_weights(_Sub(f'{tag}/init/'))
+    actor, critic = agent.actor, agent.critic
+    sink = []
+    _hook(agent._RLEPSO_Agent__optimizer_actor, list(actor.named_parameters()), sink, 'actor')
+    _hook(agent._RLEPSO_Agent__optimizer_critic, list(critic.named_parameters()), sink, 'critic')
+    env = _ScriptedBatch(tag)
+    forced = torch.as_tensor(G[f'{tag}/actions'])[:, None, :]                  # [T, 1, 35]
+    exceed, info = agent.train_batch(env, forced_actions=forced)
+    n_upd = int(G[f'{tag}/n_updates'])
+    assert not exceed and info['learn_steps'] == n_upd and len(sink) == 2 * n_upd
+    assert np.array_equal(np.concatenate(env.seen), G[f'{tag}/actions'])
+    assert info['return'] == pytest.approx(float(G[f'{tag}/rewards'].sum()))
+    ref_keys = [k for k in G.files if k.startswith(f'{tag}/grad0/')]
+    assert len(ref_keys) == 18                                                  # 12 actor + 6 critic tensors
+    for u in range(n_upd):
+        for which, grads in (sink[2 * u], sink[2 * u + 1]):
+            for k in [k for k in G.files if k.startswith(f'{tag}/grad{u}/{which}/')]:
+                name = _ours(k.split('/', 3)[3])
+                _close_grad(grads[name], G[k], (tag, u, which, name))
+    lr = 1e-5
+    for which, mod in (('actor', actor), ('critic', critic)):
+        sd = mod.state_dict()
+        for k in [k for k in G.files if k.startswith(f'{tag}/post/{which}/')]:
+            name = _ours(k.split('/', 3)[3])
+            init = G[k.replace('/post/', '/init/')]
+            d_ref, d_got = G[k] - init, sd[name].numpy() - init
+            assert np.abs(d_ref).max() > 0.5 * lr                               # the update did move the weights
+            assert np.abs(d_got - d_ref).max() <= 0.02 * lr * n_upd, (tag, which, name, np.abs(d_got - d_ref).max())
+
+
+def test_rlepso_train_episode_is_train_batch_at_b1():
+    """train_episode (the reference's entry point over a PBO_Env) goes through the same code: same sampled actions under the same torch
+    seed, same weights afterwards as train_batch over the equivalent one-instance batch."""
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+
+    class Env:                                                                   # reference protocol: numpy in, numpy / scalars out
+        optimizer = types.SimpleNamespace(cost=[1.0, 0.5])
+
+        def __init__(self):
+            self.t = 0
+
+        def reset(self):
+            self.t = 0
+            return G['ppo13/states'][0]
+
+        def step(self, a):
+            self.t += 1
+            return G['ppo13/states'][self.t], float(G['ppo13/rewards'][self.t - 1]), self.t >= 13
+    outs = []
+    for use_episode in (True, False):
+        agent = RLEPSO_Agent(_cfg()).load_exported_weights(_Sub('ppo13/init/'))
+        torch.manual_seed(3)
+        if use_episode:
+            exceed, info = agent.train_episode(Env())
+            assert info['normalizer'] == 1.0 and info['gbest'] == 0.5 and 'last_losses' not in info
+        else:
+            exceed, info = agent.train_batch(_ScriptedBatch('ppo13'))
+        assert info['learn_steps'] == 6
+        outs.append({k: v.clone() for k, v in agent.actor.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_every_rollout_policy_sees_the_weights_after_an_update():
+    """Actor._fused_weights was keyed on storage pointers only, so act_batch kept sampling from the pre-update weights after
+    optimizer.step().  All caches are keyed on the parameters' in-place version now."""
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    agent = RLEPSO_Agent(_cfg()).load_exported_weights(_Sub('ppo10/init/'))
+    st = torch.rand(16, 1)
+    torch.manual_seed(0)
+    before = agent.actor.act_batch(st)
+    with torch.no_grad():
+        for p in agent.actor.parameters():
+            p.add_(0.05)                                                         # what an optimizer step does: in place
+    torch.manual_seed(0)
+    after = agent.actor.act_batch(st)
+    mu, sigma = agent.actor.distribution(st)
+    torch.manual_seed(0)
+    want = torch.clamp(mu + sigma * torch.randn_like(mu), 0, 1)
+    assert not torch.allclose(before, after) and torch.allclose(after, want.detach(), atol=3e-6)
+    agent.train_batch(_ScriptedBatch('ppo10'))                                  # a real update invalidates the per-fes table too
+    tab = agent.actor_table(20000, 100, torch.device('cpu'))
+    mu2, _ = agent.actor.distribution(torch.tensor([[0.25]]))
+    assert torch.allclose(tab.table[5000, :35], mu2[0].detach(), atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------- LDE / REINFORCE
+@pytest.mark.parametrize('tag', ['lde_equal', 'lde_ragged'])
+def test_lde_reinforce_update_reproduces_the_reference(tag):
+    from metabox_amd.agent.lde_agent import LDE_Agent
+    agent = LDE_Agent(_cfg()).load_exported_weights(_Sub(f'{tag}/init/'))
+    net = agent.net
+    sink = []
+    _hook(agent._LDE_Agent__optimizer, list(net.named_parameters()), sink, 'net')
+    lens = G[f'{tag}/lens']
+    inputs, rewards = G[f'{tag}/inputs'], G[f'{tag}/rewards']
+
+    class Env:
+        optimizer = types.SimpleNamespace(cost=[1.0, 0.5])
+
+        def __init__(self):
+            self.k, self.traj, self.t, self.seen = 0, -1, 0, []
+
+        def reset(self):
+            self.traj += 1
+            self.t = 0
+            return inputs[self.k][None, :]
+
+        def step(self, a):
+            self.seen.append(np.asarray(a).reshape(-1).copy())
+            r = np.array([rewards[self.k]])
+            self.k += 1
+            self.t += 1
+            nxt = inputs[min(self.k, len(inputs) - 1)][None, :]
+            return nxt, r, self.t >= lens[self.traj]
+    env = Env()
+    exceed, info = agent.train_episode(env, forced_actions=G[f'{tag}/actions'])
+    assert env.k == len(inputs) and len(sink) == 1 and info['learn_steps'] == 1
+    assert info['return'] == pytest.approx(float(rewards.sum()), rel=1e-6)
+    strip = '_PolicyNet__'
+    for k in [k for k in G.files if k.startswith(f'{tag}/grad0/net/')]:
+        name = k.split('/', 3)[3].replace(strip, '')
+        _close_grad(sink[0][1][name], G[k], (tag, name))
+    lr = 0.005
+    sd = net.state_dict()
+    for k in [k for k in G.files if k.startswith(f'{tag}/post/net/')]:
+        name = k.split('/', 3)[3].replace(strip, '')
+        init = G[k.replace('/post/', '/init/')]
+        assert np.abs((sd[name].numpy() - init) - (G[k] - init)).max() <= 0.02 * lr, (tag, name)
+
+
+# ------------------------------------------------------------------------------------------------------------- DE-DDQN
+def test_ddqn_updates_reproduce_the_reference():
+    from metabox_amd.agent.de_ddqn_agent import DE_DDQN_Agent
+    agent = DE_DDQN_Agent(_cfg('protein', 12)).load_exported_weights(_Sub('ddqn/init/'))
+    net = agent.q_net
+    sink = []
+    _hook(agent._DE_DDQN_Agent__optimizer, list(net.named_parameters()), sink, 'net')
+    for u in range(3):
+        b = {n: torch.as_tensor(G[f'ddqn/batch{u}/{n}']) for n in ('obs', 'act', 'rew', 'nxt', 'done')}
+        agent.learn_from_batch(b['obs'], b['act'], b['rew'], b['nxt'], b['done'])
+        for k in [k for k in G.files if k.startswith(f'ddqn/grad{u}/net/')]:
+            _close_grad(sink[u][1][k.split('/', 3)[3]], G[k], ('ddqn', u, k))
+    lr = 1e-4
+    sd = net.state_dict()
+    for k in [k for k in G.files if k.startswith('ddqn/post/net/')]:
+        name = k.split('/', 3)[3]
+        init = G[k.replace('/post/', '/init/')]
+        assert np.abs((sd[name].numpy() - init) - (G[k] - init)).max() <= 0.02 * lr * 3, name

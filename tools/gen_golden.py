@@ -917,7 +917,180 @@ def gen_rlepso_ties():
 
 
 
-SECTIONS = {'rlepso_ties': gen_rlepso_ties, 'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+
+# ---------------------------------------------------------------------------------------------------- train
+# One training update of each reference agent on a SCRIPTED environment (states / rewards / done are fixed sequences, so nothing but the
+# agent's own arithmetic is exercised): RLEPSO's PPO segment(s) (rlepso_agent.py:113-292), LDE's REINFORCE step (lde_agent.py:85-145) and
+# DE-DDQN's double-DQN updates (de_ddqn_agent.py:70-106).  Recorded: initial weights, what the agent saw and did (states, the actions it
+# sampled, rewards, segment / trajectory lengths, replay mini-batches), the gradient of every parameter at every optimizer step and the
+# weights afterwards.  tests/test_training_parity.py feeds the same data to this framework's update code.
+def _hook_steps(opt, params_named, sink, tag):
+    orig = opt.step
+
+    def step(*a, **k):
+        sink.append((tag, {n: p.grad.detach().cpu().numpy().copy() for n, p in params_named}))
+        return orig(*a, **k)
+    opt.step = step
+
+
+def gen_train():
+    import copy as _copy
+    import random as _random
+    import types
+    from agent import DE_DDQN_Agent, LDE_Agent, RLEPSO_Agent
+    scratch = tempfile.mkdtemp()
+    data = {}
+
+    # ---- RLEPSO / PPO: episodes of 10 (one full segment), 7 (short segment) and 13 (10 + 3) steps
+    for tag, T in (('ppo10', 10), ('ppo7', 7), ('ppo13', 13)):
+        config = ref_import.ref_config(['--problem', 'bbob', '--dim', '10', '--max_learning_step', '1000'], scratch)
+        config.save_interval = 10 ** 9
+        torch.manual_seed(100 + T)
+        agent = RLEPSO_Agent(_copy.deepcopy(config))
+        actor, critic = agent._RLEPSO_Agent__actor, agent._RLEPSO_Agent__critic
+        for k, v in actor.state_dict().items():
+            data[f'{tag}/init/actor/{k}'] = v.cpu().numpy().copy()
+        for k, v in critic.state_dict().items():
+            data[f'{tag}/init/critic/{k}'] = v.cpu().numpy().copy()
+        sink = []
+        _hook_steps(agent._RLEPSO_Agent__optimizer_actor, list(actor.named_parameters()), sink, 'actor')
+        _hook_steps(agent._RLEPSO_Agent__optimizer_critic, list(critic.named_parameters()), sink, 'critic')
+        rs = np.random.RandomState(T)
+
+        class Env:
+            optimizer = types.SimpleNamespace(cost=[1.0, 0.5])
+
+            def __init__(self):
+                self.actions, self.rewards, self.states, self.t = [], [], [], 0
+
+            def reset(self):
+                self.t = 0
+                self.states.append(np.array([100. / 20000.]))
+                return self.states[-1]
+
+            def step(self, a):
+                self.actions.append(np.asarray(a, dtype=np.float32).copy())
+                self.t += 1
+                r = float(rs.choice([-1., 1.]))
+                self.rewards.append(r)
+                self.states.append(np.array([(100. + 100. * self.t + rs.randint(0, 40)) / 20000.]))
+                return self.states[-1], r, self.t >= T
+        env = Env()
+        torch.manual_seed(5)
+        agent.train_episode(env)
+        data[f'{tag}/states'] = np.stack(env.states)                 # [T + 1, 1]
+        data[f'{tag}/actions'] = np.stack(env.actions)               # [T, 35]
+        data[f'{tag}/rewards'] = np.array(env.rewards)
+        n_upd = len(sink) // 2
+        for u in range(n_upd):
+            for which, grads in (sink[2 * u], sink[2 * u + 1]):
+                for k, g in grads.items():
+                    data[f'{tag}/grad{u}/{which}/{k}'] = g
+        data[f'{tag}/n_updates'] = np.int32(n_upd)
+        for k, v in actor.state_dict().items():
+            data[f'{tag}/post/actor/{k}'] = v.cpu().numpy().copy()
+        for k, v in critic.state_dict().items():
+            data[f'{tag}/post/critic/{k}'] = v.cpu().numpy().copy()
+        print(tag, 'updates', n_upd)
+
+    # ---- LDE / REINFORCE: 20 trajectories; equal lengths (6 each) and ragged lengths (the reference slices total // 20 per trajectory)
+    for tag, lens in (('lde_equal', [6] * 20), ('lde_ragged', [4 + (i % 5) for i in range(20)])):
+        config = ref_import.ref_config(['--problem', 'bbob', '--dim', '10', '--max_learning_step', '1000'], scratch)
+        config.save_interval = 10 ** 9
+        torch.manual_seed(77)
+        agent = LDE_Agent(_copy.deepcopy(config))
+        net = agent._LDE_Agent__net
+        for k, v in net.state_dict().items():
+            data[f'{tag}/init/net/{k}'] = v.cpu().numpy().copy()
+        sink = []
+        _hook_steps(agent._LDE_Agent__optimizer, list(net.named_parameters()), sink, 'net')
+        rs = np.random.RandomState(len(tag))
+
+        class LEnv:
+            optimizer = types.SimpleNamespace(cost=[1.0, 0.5])
+
+            def __init__(self):
+                self.inputs, self.actions, self.rewards, self.traj, self.t = [], [], [], -1, 0
+
+            def reset(self):
+                self.traj += 1
+                self.t = 0
+                self.cur = rs.uniform(0, 1, size=(1, 60))
+                return self.cur
+
+            def step(self, a):
+                self.inputs.append(self.cur[0].copy())
+                self.actions.append(np.asarray(a, dtype=np.float32).reshape(-1).copy())
+                self.t += 1
+                r = np.array([rs.uniform(0, 0.3)])
+                self.rewards.append(float(r[0]))
+                self.cur = rs.uniform(0, 1, size=(1, 60))
+                return self.cur, r, self.t >= lens[self.traj]
+        env = LEnv()
+        torch.manual_seed(9)
+        agent.train_episode(env)
+        data[f'{tag}/inputs'] = np.stack(env.inputs)
+        data[f'{tag}/actions'] = np.stack(env.actions)
+        data[f'{tag}/rewards'] = np.array(env.rewards)
+        data[f'{tag}/lens'] = np.array(lens, dtype=np.int32)
+        for k, g in sink[0][1].items():
+            data[f'{tag}/grad0/net/{k}'] = g
+        for k, v in net.state_dict().items():
+            data[f'{tag}/post/net/{k}'] = v.cpu().numpy().copy()
+        print(tag, 'steps', len(env.inputs), 'updates', len(sink))
+
+    # ---- DE-DDQN: three double-DQN updates on recorded replay mini-batches (warm-up shortened to 64 transitions)
+    config = ref_import.ref_config(['--problem', 'protein', '--max_learning_step', '3'], scratch)
+    config.save_interval = 10 ** 9
+    torch.manual_seed(31)
+    agent = DE_DDQN_Agent(_copy.deepcopy(config))
+    agent._DE_DDQN_Agent__warm_up_size = 64
+    agent._DE_DDQN_Agent__max_learning_step = 3
+    pred = agent._DE_DDQN_Agent__pred_func
+    for k, v in pred.state_dict().items():
+        data[f'ddqn/init/net/{k}'] = v.cpu().numpy().copy()
+    sink, batches = [], []
+    _hook_steps(agent._DE_DDQN_Agent__optimizer, list(pred.named_parameters()), sink, 'net')
+    rb = agent._DE_DDQN_Agent__replay_buffer
+    orig_sample = rb.sample
+
+    def sample(n):
+        out = orig_sample(n)
+        batches.append([t.cpu().numpy().copy() for t in out])
+        return out
+    rb.sample = sample
+    rs = np.random.RandomState(4)
+
+    class DEnv:
+        optimizer = types.SimpleNamespace(cost=[1.0, 0.5])
+
+        def __init__(self):
+            self.t = 0
+
+        def reset(self):
+            self.t = 0
+            return rs.uniform(0, 1, size=99)
+
+        def step(self, a):
+            self.t += 1
+            return rs.uniform(0, 1, size=99), float(rs.uniform(0, 2) * (rs.rand() < 0.3)), self.t >= 200
+    _random.seed(12)
+    np.random.seed(12)
+    agent.train_episode(DEnv())
+    assert len(sink) == 3 and len(batches) == 3
+    for u in range(3):
+        for name, arr in zip(('obs', 'act', 'rew', 'nxt', 'done'), batches[u]):
+            data[f'ddqn/batch{u}/{name}'] = arr
+        for k, g in sink[u][1].items():
+            data[f'ddqn/grad{u}/net/{k}'] = g
+    for k, v in pred.state_dict().items():
+        data[f'ddqn/post/net/{k}'] = v.cpu().numpy().copy()
+    print('ddqn updates', len(sink))
+    np.savez_compressed(os.path.join(OUT, 'train_updates.npz'), **data)
+
+
+
+SECTIONS = {'train': gen_train, 'rlepso_ties': gen_rlepso_ties, 'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
