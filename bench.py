@@ -165,6 +165,34 @@ def _bracket(fn, steps, stream_sync=True):
     return (time.perf_counter() - t0) / steps
 
 
+def plugin_view_cost(episodes=3):
+    """The single-instance compatibility view -- PBO_Env.reset()/step() through RLEPSO_Optimizer.init_population / update, the reference's own
+    protocol, one instance, one host round trip per generation -- timed next to the reference's 2.5 ms per generation.
+    This is what a user plugin written against MetaBox pays when it does not use the batched path."""
+    from metabox_amd.environment import PBO_Env
+    from metabox_amd.optimizer import RLEPSO_Optimizer
+    from metabox_amd.problem.bbob import BBOB_Dataset
+    cfg = make_config()
+    tr, _ = BBOB_Dataset.get_datasets('bbob', DIM, 5.0)
+    opt = RLEPSO_Optimizer(cfg)
+    rs = np.random.RandomState(0)
+    t_reset, t_step, n_steps = [], 0., 0
+    for ep in range(episodes + 1):
+        env = PBO_Env(tr.data[ep % len(tr.data)], opt)
+        t0 = time.perf_counter()
+        env.reset()
+        t1 = time.perf_counter()
+        done, n = False, 0
+        while not done:
+            _, _, done = env.step(rs.uniform(0, 1, 35).astype(np.float32))
+            n += 1
+        if ep:                                               # the first episode pays allocation
+            t_reset.append(t1 - t0); t_step += time.perf_counter() - t1; n_steps += n
+    return {'path': 'PBO_Env + RLEPSO_Optimizer, B = 1: H2D of the action, one generation kernel, one 536-byte D2H (mbx_read_public) per env.step',
+            'ms_per_env_step': t_step / n_steps * 1e3, 'env_steps_per_s': n_steps / t_step, 'ms_per_reset': float(np.mean(t_reset)) * 1e3,
+            'reference_ms_per_env_step': 2.5, 'reference_source': 'SURVEY.md section 6: 432 env-steps/s on one host core (build container)'}
+
+
 def other_configs(budget_s=60.0):
     """One GPU's share of BASELINE.json configs 3, 4 and 5, policy included, each on its own lock-step batch: ms per step, env-steps/s,
     algorithmic bytes per env-step and the fraction of the 8 TB/s roofline they imply.  Bounded: a few dozen steps each."""
@@ -482,6 +510,7 @@ def main():
         }
         if world == 1 and not args.no_other_configs:
             try:
+                out['plugin_view'] = plugin_view_cost()
                 out['other_configs'] = other_configs()
             except Exception as exc:                       # the headline line must survive a failure of the side legs
                 out['other_configs'] = {'error': repr(exc)}

@@ -164,6 +164,17 @@ int mbx_results(mbx_batch* b, double* d_cost_curves /* [B, n_logpoint+1] */, dou
                 double* d_return /* [B] */, int32_t* d_steps /* [B] */, int32_t* d_cost_len /* [B] */,
                 void* stream);
 
+/* Give an existing batch new (problem, seed) pairs without re-allocating anything: the next mbx_reset starts episode 0 of the new
+ * instances.  This is what the reference does when PBO_Env.reset() is called for another problem / run with the same optimizer object
+ * (src/environment/basic_environment.py:17-19 -> init_population).  Synchronises the device. */
+int mbx_batch_rebind(mbx_batch* b, const int32_t* problem_idx /* [B] */, const uint64_t* seeds /* [B] */);
+
+/* The public attributes the reference's optimizers expose after every update() -- optimizer.fes, .cost, .log_index
+ * (src/optimizer/rlepso_optimizer.py:27-30, 241-261) -- for ONE instance: copies the instance's scalar block and cost list,
+ * host_out[0 .. MBX_NSCALAR + n_logpoint] (layout: MBX_SC_* in include/mbx_layout.h), with one small device-to-host copy on `stream`
+ * and waits for it.  The single-instance compatibility view (B = 1) calls it once per step instead of reading the whole state back. */
+int mbx_read_public(mbx_batch* b, int instance, double* host_out /* [MBX_NSCALAR + n_logpoint + 1] */, void* stream);
+
 /* Test / diagnostics: copy the internal per-instance optimizer state to the host.
  * RLEPSO layout: see MBX_RLEPSO_* offsets in include/mbx_layout.h. */
 int64_t mbx_instance_state_doubles(const mbx_batch* b);

@@ -385,6 +385,29 @@ extern "C" int64_t mbx_tape_stride(const mbx_algo_cfg* c)
     return geom_of(*c).tape_stride;
 }
 
+// Longest-processing-time-first launch order: workgroups of the expensive objectives are dispatched first so that they do not form the
+// tail of the launch (per-kind weights = measured us per 4096-instance generation).
+static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
+{
+    const mbx_suite* s = b->suite;
+    const int n_instances = b->B;
+    auto weight = [&](int pi) -> int {
+        const int k = s->h_problems[pi].kind;
+        switch (k) {
+        case MBX_KIND_PROTEIN: return 3000;
+        case 16: case 21: return 390; case 15: return 322; case 17: case 18: return 319; case 3: return 310;
+        case 4: return 285; case 2: case 10: case 11: return 277; case 23: return 268; case 22: return 263;
+        case 12: return 248; case 14: return 241; case 5: return 188; default: return 225;
+        }
+    };
+    std::vector<int32_t> order(n_instances);
+    for (int i = 0; i < n_instances; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return weight(problem_idx[a]) > weight(problem_idx[c]); });
+    if (!b->d_order) HIP_TRY(hipMalloc(&b->d_order, n_instances * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(b->d_order, order.data(), n_instances * sizeof(int32_t), hipMemcpyHostToDevice));
+    return MBX_OK;
+}
+
 extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int32_t* problem_idx, const uint64_t* seeds,
                                 int n_instances, mbx_batch** out)
 {
@@ -427,23 +450,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     HIP_TRY(hipMemcpy(b->d_problem_idx, problem_idx, n_instances * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d_state, 0, (size_t)n_instances * b->state_stride * sizeof(double)));
-    {   // Longest-processing-time-first launch order: workgroups of the expensive objectives are dispatched first so
-        // that they do not form the tail of the launch (per-kind weights = measured us per 4096-instance generation).
-        auto weight = [&](int pi) -> int {
-            const int k = s->h_problems[pi].kind;
-            switch (k) {
-            case MBX_KIND_PROTEIN: return 3000;
-            case 16: case 21: return 390; case 15: return 322; case 17: case 18: return 319; case 3: return 310;
-            case 4: return 285; case 2: case 10: case 11: return 277; case 23: return 268; case 22: return 263;
-            case 12: return 248; case 14: return 241; case 5: return 188; default: return 225;
-            }
-        };
-        std::vector<int32_t> order(n_instances);
-        for (int i = 0; i < n_instances; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return weight(problem_idx[a]) > weight(problem_idx[c]); });
-        HIP_TRY(hipMalloc(&b->d_order, n_instances * sizeof(int32_t)));
-        HIP_TRY(hipMemcpy(b->d_order, order.data(), n_instances * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
+    if (int rc = upload_launch_order(b, problem_idx)) return rc;
     hipLaunchKernelGGL(k_init_state, dim3((n_instances + 255) / 256), dim3(256), 0, nullptr, b->d_state, b->state_stride,
                        g.sc_off, n_instances);
     HIP_TRY(hipDeviceSynchronize());
@@ -501,6 +508,29 @@ extern "C" int mbx_batch_destroy(mbx_batch* b)
     if (!b) return MBX_OK;
     (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order); (void)hipFree(b->d_pci);
     delete b;
+    return MBX_OK;
+}
+
+extern "C" int mbx_batch_rebind(mbx_batch* b, const int32_t* problem_idx, const uint64_t* seeds)
+{
+    if (!b || !problem_idx || !seeds) return fail(MBX_E_ARG, "mbx_batch_rebind: bad arguments");
+    for (int i = 0; i < b->B; ++i)
+        if (problem_idx[i] < 0 || problem_idx[i] >= b->suite->n) return fail(MBX_E_ARG, "problem_idx[%d]=%d out of range", i, problem_idx[i]);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(b->d_problem_idx, problem_idx, b->B * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_seeds, seeds, b->B * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (int rc = upload_launch_order(b, problem_idx)) return rc;
+    hipLaunchKernelGGL(k_init_state, dim3((b->B + 255) / 256), dim3(256), 0, nullptr, b->d_state, b->state_stride, b->sc_off, b->B);   // episode counter back to -1
+    HIP_TRY(hipDeviceSynchronize());
+    return MBX_OK;
+}
+
+extern "C" int mbx_read_public(mbx_batch* b, int instance, double* host_out, void* stream)
+{
+    if (!b || instance < 0 || instance >= b->B || !host_out) return fail(MBX_E_ARG, "mbx_read_public: bad arguments");
+    const size_t n = (size_t)(MBX_NSCALAR + b->cfg.n_logpoint + 1) * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(host_out, b->d_state + (int64_t)instance * b->state_stride + b->sc_off, n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return MBX_OK;
 }
 

@@ -41,10 +41,12 @@ class RLEPSO_Optimizer(Learnable_Optimizer):
                      early_stop=early_stop, n_group=self.__n_group)
 
     # ---- single-instance protocol (B = 1 view) ------------------------------------------------------
+    # One env step = the action's H2D copy, one generation kernel, ONE device-to-host copy of the instance's scalar block + cost list
+    # (mbx_read_public: 67 doubles).  State, reward and done are derived from those scalars on the host (state = fes / maxFEs,
+    # rlepso_optimizer.py:170-171; reward = change of the running return, :251-254), so nothing else crosses PCIe.  A reset for another
+    # problem / run re-binds the existing one-instance batch (mbx_batch_rebind) instead of re-creating it.
     def __sync_public(self):
-        st = self.__batch.read_state(0)
-        NP, D = self.__NP, self.__dim
-        sc = st[3 * NP * D + 3 * NP + D:]
+        sc = self.__batch.read_public(0)
         self.fes = int(sc[1])
         self.log_index = int(sc[2])
         n = int(sc[3])
@@ -56,20 +58,27 @@ class RLEPSO_Optimizer(Learnable_Optimizer):
         # the Philox key is drawn from numpy's global stream so that `np.random.seed(run)` (src/tester.py:198)
         # still makes a run reproducible
         seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 + int(np.random.randint(0, 2 ** 31 - 1))
-        key = (id(suite), problem._suite_index)
-        if self.__batch is not None:
-            self.__batch.close()
-        self.__batch = self.make_batch(suite, [problem._suite_index], [seed])
-        self.__batch_key = key
-        state = self.__batch.reset()
-        torch.cuda.synchronize()
-        self.__sync_public()
-        return state[0].cpu().numpy()
+        if self.__batch is not None and self.__batch_key == id(suite):
+            self.__batch.rebind([problem._suite_index], [seed])
+        else:
+            if self.__batch is not None:
+                self.__batch.close()
+            self.__batch = self.make_batch(suite, [problem._suite_index], [seed])
+            self.__batch_key = id(suite)
+            self.__action = torch.zeros(1, self.__n_group * 7, dtype=torch.float32, device=self.__batch.device)
+            self.__host_action = torch.zeros(1, self.__n_group * 7, dtype=torch.float32).pin_memory()
+        self.__batch.reset()
+        sc = self.__sync_public()
+        self.__return = float(sc[5])
+        return np.array([sc[1] / self.__max_fes])
 
     def update(self, action, problem):
-        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, -1)).cuda()
+        a = np.asarray(action, dtype=np.float32).reshape(1, -1)
         assert a.shape[-1] == self.__n_group * 7, 'actions size is not right!'
-        state, reward, done = self.__batch.step(a)
-        torch.cuda.synchronize()
-        self.__sync_public()
-        return state[0].cpu().numpy(), float(reward[0].item()), bool(done[0].item())
+        self.__host_action.copy_(torch.from_numpy(a))
+        self.__action.copy_(self.__host_action, non_blocking=True)
+        self.__batch.step(self.__action)
+        sc = self.__sync_public()                         # waits for the kernel: the copy is enqueued behind it on the same stream
+        reward = float(sc[5]) - self.__return
+        self.__return = float(sc[5])
+        return np.array([sc[1] / self.__max_fes]), reward, bool(sc[4] != 0.)

@@ -232,6 +232,20 @@ class Batch:
         _abi.check(self.lib.mbx_results(self._h, _ptr(cost), _ptr(fes), _ptr(ret), _ptr(steps), _ptr(clen), _stream()))
         return {'cost': cost, 'fes': fes, 'return': ret, 'steps': steps, 'cost_len': clen}
 
+    def rebind(self, problem_idx, seeds):
+        """New (problem, seed) pairs for the same batch (``mbx_batch_rebind``): no allocation, the next reset() starts their episode 0."""
+        pidx = np.ascontiguousarray(problem_idx, dtype=np.int32)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert pidx.shape == sd.shape == (self.B,)
+        _abi.check(self.lib.mbx_batch_rebind(self._h, pidx.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p)))
+
+    def read_public(self, instance=0):
+        """Scalar block + cost list of one instance (``mbx_read_public``): numpy [NSCALAR + n_logpoint + 1], one small D2H copy."""
+        if getattr(self, '_pub', None) is None:
+            self._pub = np.empty(16 + self.cfg.n_logpoint + 1)
+        _abi.check(self.lib.mbx_read_public(self._h, int(instance), self._pub.ctypes.data_as(_abi.c_double_p), _stream()))
+        return self._pub
+
     def read_state(self, instance):
         n = int(self.lib.mbx_instance_state_doubles(self._h))
         out = np.empty(n)
