@@ -202,6 +202,21 @@ typedef struct mbx_gauss_mlp {
 int mbx_gauss_policy(mbx_batch* b, const mbx_gauss_mlp* net, const double* d_state, float* d_actions, float* d_mu_sigma,
                       void* stream);
 
+/* LDE's PolicyNet as ONE kernel launch per generation (src/agent/lde_agent.py:8-29 PolicyNet.forward / sampler, :147-163 the rollout loop
+ * body): one LSTM cell in_dim -> hidden (torch.nn.LSTM gate order i, f, g, o), mu = Linear(h'), sigma = sigmoid(Linear(h')),
+ * action = clip(Normal(mu, sigma).sample(), 0, 1).  d_weights (float32), every matrix TRANSPOSED so that consecutive output units are
+ * consecutive words:  W_ih^T [in_dim][4 hidden] | W_hh^T [hidden][4 hidden] | b_ih + b_hh [4 hidden] | W_mu^T [hidden][out_dim] |
+ * W_sigma^T [hidden][out_dim] | b_mu [out_dim] | b_sigma [out_dim].
+ * d_state [n_instances, in_dim] float64 (what mbx_reset / mbx_step wrote); d_h, d_c [n_instances, hidden] float32 are read and
+ * overwritten with (h', c'); d_actions [n_instances, out_dim] float32 (may be NULL: no sampling), ready for mbx_step; d_mu_sigma, if not
+ * NULL, receives [n_instances, 2, out_dim].  Philox draws (j, MBX_SITE_POLICY, gen + 1, episode) of the instance's own stream. */
+typedef struct mbx_lstm_policy {
+    const float* d_weights;
+    int32_t in_dim, hidden, out_dim;
+} mbx_lstm_policy;
+int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state, float* d_h, float* d_c, float* d_actions,
+                   float* d_mu_sigma, void* stream);
+
 /* The agent's act() and the environment's step() in ONE launch (the loop body of RLEPSO_Agent.rollout_episode,
  * src/agent/rlepso_agent.py:294-303: `action = actor(state); state, reward, done = env.step(action)`).
  * RLEPSO's state is the scalar fes/maxFEs (rlepso_optimizer.py:170-171) and fes is an integer, so the actor's (mu, sigma)

@@ -30,6 +30,20 @@ class PolicyNet(nn.Module):
         sample_w = torch.clip(torch.distributions.Normal(mu, sigma).sample(), 0, 1).reshape(self.action_shape)
         return sample_w, ht_, ct_
 
+    def packed_weights(self):
+        """float32 CUDA tensor in the layout ``mbx_lstm_policy`` documents (include/mbx.h): every matrix transposed, the two LSTM biases
+        summed.  Re-packed whenever a parameter has been modified in place (optimizer step, load)."""
+        ps = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_pw_key', None) != key:
+            l = self.lstm
+            parts = [l.weight_ih_l0.detach().t().reshape(-1), l.weight_hh_l0.detach().t().reshape(-1), (l.bias_ih_l0 + l.bias_hh_l0).detach().reshape(-1),
+                     self.mu.weight.detach().t().reshape(-1), self.sigma.weight.detach().t().reshape(-1), self.mu.bias.detach().reshape(-1),
+                     self.sigma.bias.detach().reshape(-1)]
+            self._pw = torch.cat(parts).to(torch.float32).contiguous()
+            self._pw_key = key
+        return self._pw
+
     @torch.no_grad()
     def act_batch(self, states, h, c):
         """states [B, NP+10] float32, h/c [1, B, 50] -> actions [B, 2NP], h', c'."""
@@ -114,24 +128,32 @@ class LDE_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
 
     @torch.no_grad()
-    def policy_step(self, env, state, h, c):
-        """One lock-step generation of a BatchedPBO_Env: act (LSTM cell + heads + sampling over the whole batch) and env.step."""
+    def policy_step(self, env, state, h, c, policy='hip'):
+        """One lock-step generation of a BatchedPBO_Env: act (LSTM cell + heads + sampling over the whole batch) and env.step.
+        'hip' (default): the whole PolicyNet as one launch (``mbx_lde_policy``; h, c [1, B, 50] contiguous, updated in place; Philox
+        sampling); 'torch': the PyTorch modules (``PolicyNet.act_batch``, torch's generator).  Same distribution either way."""
+        if policy == 'hip':
+            net = self.__net
+            actions = env.batch.lde_policy(net.packed_weights(), net.lstm.hidden_size, h, c)
+            state, _, _ = env.step(actions)
+            return state, h, c
         actions, h, c = self.__net.act_batch(state.to(torch.float32), h, c)
         state, _, _ = env.step(actions.contiguous())
         return state, h, c
 
-    def policy_route(self):
-        return 'PyTorch-ROCm: one LSTM cell + two linear heads over [B, NP + 10] per generation (rocBLAS / hipBLASLt GEMMs)'
+    def policy_route(self, policy='hip'):
+        return {'hip': 'mbx_lde_policy: LSTM cell + both heads + sampling in ONE hand-written launch per generation (float32 VALU, weights in L2)',
+                'torch': 'PyTorch-ROCm: one LSTM cell + two linear heads over [B, NP + 10] per generation (rocBLAS / hipBLASLt GEMMs)'}[policy]
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None):
+    def rollout_batch(self, env, max_steps=None, policy='hip'):
         if max_steps is None:
             bc = env.batch.cfg
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         state = env.reset()
         h, cc = self.__zeros(env.B)
         for _ in range(max_steps):
-            state, h, cc = self.policy_step(env, state, h, cc)
+            state, h, cc = self.policy_step(env, state, h, cc, policy)
         res = env.results()
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}
 

@@ -17,6 +17,7 @@
 #include "mbx_ddqn.hpp"
 #include "mbx_rs.hpp"
 #include "mbx_policy.hpp"
+#include "mbx_lstm_policy.hpp"
 #include "mbx_rlpso.hpp"
 #include "mbx_gleet.hpp"
 #include "mbx_qlpso.hpp"
@@ -689,6 +690,24 @@ extern "C" int mbx_gauss_policy(mbx_batch* b, const mbx_gauss_mlp* net, const do
     const GaussMlp g{net->d_weights, net->in_dim, net->h1, net->h2, net->out_dim, net->min_sigma, net->max_sigma, net->variant};
     hipLaunchKernelGGL(k_gauss_mlp_policy, dim3(policy_blocks(b->B)), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
                        d_state, d_actions, d_mu_sigma, 0);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state, float* d_h, float* d_c, float* d_actions,
+                              float* d_mu_sigma, void* stream)
+{
+    if (!b || !net || !net->d_weights || !d_state || !d_h || !d_c) return fail(MBX_E_ARG, "mbx_lde_policy: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_LDE) return fail(MBX_E_UNSUPPORTED, "mbx_lde_policy: the batch is not an LDE batch");
+    if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->hidden < 1 || net->hidden > 64 || net->out_dim > 512)
+        return fail(MBX_E_ARG, "mbx_lde_policy: network %d -> %d -> %d does not fit the batch (state %d, action %d; hidden <= 64)",
+                    net->in_dim, net->hidden, net->out_dim, b->state_dim, b->action_dim);
+    const size_t lds = lstm_policy_lds_bytes(net->in_dim, net->hidden);
+    if (lds > (size_t)max_lds_bytes()) return fail(MBX_E_UNSUPPORTED, "mbx_lde_policy: %zu B of LDS needed", lds);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_policy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const LstmPolicy g{net->d_weights, net->in_dim, net->hidden, net->out_dim};
+    hipLaunchKernelGGL(k_lstm_policy, dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
+                       d_state, d_h, d_c, d_actions, d_mu_sigma);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

@@ -189,6 +189,21 @@ class Batch:
                                               _ptr(self.done), _stream()))
         return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
 
+    def lde_policy(self, weights, hidden, h, c, want_mu_sigma=False, sample=True):
+        """LDE's PolicyNet in one launch (``mbx_lde_policy``): reads the batch's own state tensor, updates h / c [B, hidden] (float32,
+        contiguous) in place, returns the actions [B, 2 NP] (float32; None when ``sample`` is False)[, mu_sigma [B, 2, 2 NP]]."""
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        assert h.is_cuda and c.is_cuda and h.dtype == c.dtype == torch.float32 and h.is_contiguous() and c.is_contiguous()
+        assert h.numel() == c.numel() == self.B * hidden
+        if getattr(self, '_actions', None) is None:
+            self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
+        ms = torch.empty(self.B, 2, self.action_dim, dtype=torch.float32, device=self.device) if want_mu_sigma else None
+        net = _abi.LstmPolicy(weights.data_ptr(), self.state_dim, int(hidden), self.action_dim)
+        _abi.check(self.lib.mbx_lde_policy(self._h, C.byref(net), _ptr(self.state), _ptr(h), _ptr(c), _ptr(self._actions) if sample else None,
+                                           _ptr(ms), _stream()))
+        acts = self._actions if sample else None
+        return (acts, ms) if want_mu_sigma else acts
+
     def gauss_policy(self, weights, h1, h2, min_sigma, max_sigma, want_mu_sigma=False):
         """RLEPSO / RL-PSO actor over the batch's current state in one launch (``mbx_gauss_policy``).  weights: packed float32 CUDA
         tensor (``Actor.packed_weights``).  Returns the [B, action_dim] float32 action tensor (overwritten by the next

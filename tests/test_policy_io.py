@@ -102,3 +102,47 @@ def test_ddqn_qnet_reproduces_reference_io_on_gpu():
 @pytest.mark.gpu
 def test_rlepso_critic_reproduces_reference_io_on_gpu():
     _check_rlepso_critic('cuda')
+
+
+@pytest.mark.gpu
+def test_lde_policy_kernel_reproduces_reference_io():
+    """mbx_lde_policy (the whole PolicyNet in one launch, what rollout_batch uses) on the recorded (x, h, c) -> (mu, sigma, h', c') pairs
+    of the reference's module, and against the PyTorch modules on a ragged batch (B not a multiple of the 16-instance tile).
+    Tolerance 5e-6: float32, the dot products are summed in k order instead of torch's GEMM tiling."""
+    from metabox_amd._abi import ALGO_LDE
+    from metabox_amd.suite import Batch, Suite
+    from helpers import problems
+    pol = load('lde_policy.npz')
+    net = _lde_agent('cuda').net
+    ps = problems('bbob', 10)
+    suite = Suite([ps[k] for k in sorted(ps)])
+    for B, src in ((pol['io/x'].shape[1], 'golden'), (37, 'torch')):
+        batch = Batch(suite, ALGO_LDE, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, 50, 20000, 400, 50)
+        batch.reset()
+        if src == 'golden':
+            x, h0, c0 = (torch.from_numpy(pol[k]).cuda() for k in ('io/x', 'io/h', 'io/c'))
+            want = [pol[k][0] for k in ('io/mu', 'io/sigma', 'io/h_out', 'io/c_out')]
+        else:
+            g = torch.Generator(device='cuda').manual_seed(1)
+            x = torch.rand(1, B, 60, device='cuda', generator=g)
+            h0, c0 = torch.randn(1, B, 50, device='cuda', generator=g) * 0.5, torch.randn(1, B, 50, device='cuda', generator=g)
+            with torch.no_grad():
+                want = [t[0].cpu().numpy() for t in net.forward(x, h0, c0)]
+        batch.state.copy_(x[0].to(torch.float64))
+        h, c = h0.clone().contiguous(), c0.clone().contiguous()
+        acts, ms = batch.lde_policy(net.packed_weights(), 50, h, c, want_mu_sigma=True)
+        torch.cuda.synchronize()
+        got = [ms[:, 0].cpu().numpy(), ms[:, 1].cpu().numpy(), h[0].cpu().numpy(), c[0].cpu().numpy()]
+        for name, g_, w_ in zip(('mu', 'sigma', 'h_out', 'c_out'), got, want):
+            assert np.abs(g_ - w_).max() <= 5e-6, (src, name, np.abs(g_ - w_).max())
+        a = acts.cpu().numpy()
+        assert a.shape == (B, 100) and a.min() >= 0 and a.max() <= 1
+        # the sampled actions follow clip(N(mu, sigma)): standardised residuals of the unclipped ones are ~N(0, 1)
+        z = (a - got[0]) / got[1]
+        inner = (a > 0) & (a < 1)
+        assert inner.sum() > 50 and abs(z[inner].mean()) < 0.2
+        # deterministic: same state, same Philox counters
+        h2, c2 = h0.clone().contiguous(), c0.clone().contiguous()
+        again = batch.lde_policy(net.packed_weights(), 50, h2, c2).cpu().numpy()
+        assert np.array_equal(again, a)
+        batch.close()
