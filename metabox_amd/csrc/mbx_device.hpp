@@ -259,8 +259,11 @@ __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds
     }
 }
 
-// Out[i][d] = sum_k M[d][k] * In[i][k]   (the matmul of sr_func, bbob.py:6-8), k ascending, no FMA contraction
-__device__ __forceinline__ void matvec_rows(const double* MT, const double* In, int n, int D, double* Out)
+// Out[i][d] = sum_k M[d][k] * (In[i][k] - sub[k])   (sr_func, bbob.py:6-8: shift, then the matmul), k ascending, no FMA contraction.
+// sub == nullptr: plain matvec.  Subtracting inside the product loop instead of in a pass of its own saves a barrier interval per
+// evaluation (in the short phases of the generation kernels an interval costs more than the NP*D subtractions repeated per output pair).
+template <bool SUB>
+__device__ __forceinline__ void matvec_rows_impl(const double* MT, const double* In, const double* sub, int n, int D, double* Out)
 {
     if ((D & 1) == 0) {
         // Register tile of 2 rows x 2 dimensions per thread: the plain loop below reads 16 bytes of LDS per multiply-add (M[d][k] and
@@ -277,7 +280,9 @@ __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, 
             double s00 = 0., s01 = 0., s10 = 0., s11 = 0.;
 #pragma unroll 5
             for (int k = 0; k < D; ++k) {
-                const double m0 = col[k * D], m1 = col[k * D + 1], y0 = r0[k], y1 = r1[k];
+                const double m0 = col[k * D], m1 = col[k * D + 1];
+                double y0 = r0[k], y1 = r1[k];
+                if (SUB) { const double sh = sub[k]; y0 = y0 - sh; y1 = y1 - sh; }
                 s00 += m0 * y0; s01 += m1 * y0; s10 += m0 * y1; s11 += m1 * y1;
             }
             Out[i0 * D + d] = s00; Out[i0 * D + d + 1] = s01;
@@ -293,10 +298,12 @@ __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, 
         const double* col = MT + d;
         double s = 0.;
 #pragma unroll 5
-        for (int k = 0; k < D; ++k) s += col[k * D] * row[k];
+        for (int k = 0; k < D; ++k) s += col[k * D] * (SUB ? row[k] - sub[k] : row[k]);
         Out[e] = s;
     }
 }
+__device__ __forceinline__ void matvec_rows(const double* MT, const double* In, int n, int D, double* Out) { matvec_rows_impl<false>(MT, In, nullptr, n, D, Out); }
+__device__ __forceinline__ void matvec_rows_shifted(const double* MT, const double* In, const double* sub, int n, int D, double* Out) { matvec_rows_impl<true>(MT, In, sub, n, D, Out); }
 
 // sum of v over the block (all threads call; result to every thread).  red: >= 16 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* red)
@@ -361,10 +368,31 @@ __device__ void eval_rows_protein(const DevProblem& P, const EvalLds& L, int n_r
 // (the value F*.func returns).  All arrays of `L` live in LDS; stage_problem() must have been called.
 // Must be called by every thread of the block.
 // ------------------------------------------------------------------------------------------------
-template <int DC = 0>
-__device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
+// What __get_costs adds on top of func() (noise, then `- optimum`), applied by the row's own thread at the end of the row phase when the
+// caller passes it (population_costs): one barrier interval less than a pass of its own.
+struct RowPost {
+    const Rng* rng; const double* tape_noise; uint32_t siteA, siteB; int n_total;
+};
+
+__device__ __forceinline__ double row_post(const DevProblem& P, const RowPost& rp, int i, double f)
 {
-    if (P.kind == MBX_KIND_PROTEIN) { eval_rows_protein<DC>(P, L, n); return; }
+    if (P.noise_kind != MBX_NOISE_NONE) {
+        double a, b, c;
+        if (rp.tape_noise) { a = rp.tape_noise[i]; b = rp.tape_noise[rp.n_total + i]; c = rp.tape_noise[2 * rp.n_total + i]; }
+        else philox_noise(*rp.rng, (uint32_t)i, rp.siteA, rp.siteB, P.noise_kind, a, b, c);
+        f = apply_noise(P, f, a, b, c);
+    }
+    return isnan(P.optimum) ? f : f - P.optimum;
+}
+
+template <int DC = 0>
+__device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const RowPost* post = nullptr)
+{
+    if (P.kind == MBX_KIND_PROTEIN) {
+        eval_rows_protein<DC>(P, L, n);
+        if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
+        return;
+    }
     const int D = DC ? DC : P.dim, NE = n * D, kind = P.kind, tid = threadIdx.x;
     const double ub = P.ub, bias = P.bias;
     const double* X = L.X;
@@ -380,16 +408,13 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
     const FastDiv fd(D);
 
     // ---- phase A: first linear map  z = M1 (x - dshift)   (Gallagher: M1 x, the peaks are pre-rotated)
+    // Barriers only where a phase exists for this function (the kind is workgroup-uniform, so every thread takes the same path).
     const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
     if (first_map) {
-        const bool gall = kind == 21 || kind == 22;
-        if (!gall) {
-            for (int e = tid; e < NE; e += MBX_NT) { const int d = fd.mod(e); T[e] = X[e] - dsh[d]; }
-            __syncthreads();
-        }
-        matvec_rows(M1T, gall ? X : T, n, D, Z);
+        if (kind == 21 || kind == 22) matvec_rows(M1T, X, n, D, Z);
+        else matvec_rows_shifted(M1T, X, dsh, n, D, Z);
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- phase E1: element-wise transforms
     if (kind == 21 || kind == 22) {
@@ -509,19 +534,21 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
             }
         }
     }
-    __syncthreads();
+    if (!(kind == 1 || kind == 13)) __syncthreads();
 
     // ---- phase C: second linear map (F7 keeps |z_hat_0| in F first)
     if (kind == 7) {
         for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
         matvec_rows(M2T, T, n, D, Z);
+        __syncthreads();
     } else if (kind == 12 || kind == 24) {
         matvec_rows(M1T, T, n, D, Z);
+        __syncthreads();
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
         matvec_rows(M2T, T, n, D, Z);
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- phase E2: element-wise terms after the second map
     if (kind == 15 || kind == 24) {
@@ -567,7 +594,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
             Z[e] = z * m_sin(sqrt(fabs(z)));
         }
     }
-    __syncthreads();
+    if (kind == 15 || kind == 24 || (kind >= 16 && kind <= 20)) __syncthreads();
 
     // ---- row phase: sequential sums over d in ascending order (one thread per row)
     for (int i = tid; i < n; i += MBX_NT) {
@@ -669,7 +696,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n)
         }
         default: f = NAN; break;
         }
-        F[i] = f;
+        F[i] = post ? row_post(P, *post, i, f) : f;
     }
     __syncthreads();
 }
@@ -682,23 +709,13 @@ template <int DC = 0>
 __device__ __forceinline__ void population_costs(const DevProblem& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
+    const RowPost post{&rng, tape_noise, siteA, siteB, n};
 #ifdef MBX_ABLATE_EVAL
-    for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = L.X[i * P.dim] * L.X[i * P.dim] + P.bias;
+    for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, post, i, L.X[i * P.dim] * L.X[i * P.dim] + P.bias);
     __syncthreads();
 #else
-    eval_rows<DC>(P, L, n);
+    eval_rows<DC>(P, L, n, &post);
 #endif
-    for (int i = threadIdx.x; i < n; i += MBX_NT) {
-        double f = L.F[i];
-        if (P.noise_kind != MBX_NOISE_NONE) {
-            double a, b, c;
-            if (tape_noise) { a = tape_noise[i]; b = tape_noise[n + i]; c = tape_noise[2 * n + i]; }
-            else philox_noise(rng, (uint32_t)i, siteA, siteB, P.noise_kind, a, b, c);
-            f = apply_noise(P, f, a, b, c);
-        }
-        L.F[i] = isnan(P.optimum) ? f : f - P.optimum;
-    }
-    __syncthreads();
 }
 
 }  // namespace mbx
