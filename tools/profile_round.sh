@@ -9,8 +9,12 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python "$ROOT/bench.py" --steps 199 --warmup 10 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+# headline command alone (no plugin_view / other_configs legs: they launch the same kernels on other batch sizes and would pollute the averages)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python "$ROOT/bench.py" --steps 199 --warmup 10 --no-cpu-baseline --no-other-configs > "$OUT/trace.log" 2>&1
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+# the side legs (B = 1 plugin view, configs 3 / 4 / 5) in a trace of their own
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace2" -o t -- python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/trace2.log" 2>&1
+find "$OUT/trace2" -name '*kernel_stats.csv' -exec cp {} "$OUT/other_configs_kernel_stats.csv" \;
 # (one pass per quoted group: TCC counters cannot share a pass; 8 SQ counters per pass; no trace domains next to --pmc)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
             "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32" \
@@ -19,5 +23,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
     rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --steps 20 --warmup 2 --no-cpu-baseline --no-other-configs > "$OUT/pmc_$name.log" 2>&1
 done
 python "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/pmc_hbm_traffic.json"
-rm -rf "$OUT"/trace "$OUT"/pmc_*/ 2>/dev/null
+rm -rf "$OUT"/trace "$OUT"/trace2 "$OUT"/pmc_*/ 2>/dev/null
 ls -la "$OUT"
