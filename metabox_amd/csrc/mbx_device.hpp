@@ -188,15 +188,15 @@ __device__ __forceinline__ double div_by_tenth(double L)
 
 __device__ __forceinline__ double osc1(double x)
 {
-    if (x > 0.) {
-        const double y = div_by_tenth(m_log(x));
-        return m_exp(0.1 * (y + 0.49 * (m_sin(y) + m_sin(0.79 * y))));
-    }
-    if (x < 0.) {
-        const double y = div_by_tenth(m_log(-x));
-        return -m_exp(0.1 * (y + 0.49 * (m_sin(0.55 * y) + m_sin(0.31 * y))));
-    }
-    return x;
+    // One code path for both signs: the coordinates of a wave have mixed signs, so an if / else over x > 0 / x < 0 executes BOTH sides
+    // (log + exp + 2 sin each) under complementary EXEC masks.  Selecting the two frequencies instead halves the cost; 1.0 * y == y
+    // exactly, so the positive side is bit-identical to sin(y).
+    if (x == 0.) return x;
+    const bool pos = x > 0.;
+    const double y = div_by_tenth(m_log(fabs(x)));
+    const double c1 = pos ? 1.0 : 0.55, c2 = pos ? 0.79 : 0.31;
+    const double r = m_exp(0.1 * (y + 0.49 * (m_sin(c1 * y) + m_sin(c2 * y))));
+    return pos ? r : -r;
 }
 
 __device__ __forceinline__ double asy1(double x, double beta_lin)  // asy_transform, bbob.py:70-82
