@@ -55,3 +55,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for e in oc:
         assert e['ms_per_step'] > 0 and abs(e['env_steps_per_s'] - e['instances'] / (e['ms_per_step'] * 1e-3)) <= 1e-6 * e['env_steps_per_s']
         assert 0 < e['roofline_frac'] < 1
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_two_ranks_one_device():
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`) with N = 2
+    ranks sharing the one GPU of the test box (--same-device; gloo, because RCCL rejects two ranks on one device): rank 0 prints ONE line,
+    the aggregate counts both ranks' instances, weak scaling."""
+    port = 36500 + os.getpid() % 2000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '12', '--warmup', '3',
+                          '--same-device', '--dist-backend', 'gloo', '--no-cpu-baseline'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-400:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 12
+    assert d['config']['parallelism'] == 'instances sharded x2' and d['config']['instances_per_gpu'] == 4096
+    assert 12 * 4096 < d['config']['live_env_steps'] <= 2 * 12 * 4096          # both ranks' instances are in the aggregate
+    assert 'other_configs' not in d and 'cpu_baseline' not in d                 # side legs only at N = 1
