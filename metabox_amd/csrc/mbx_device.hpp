@@ -429,10 +429,8 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
         // evaluated in the row phase with the reference's expression.
         const int npk = P.n_peaks, lane = tid & 63, wave = tid >> 6;
         const double cexp = -0.5 / D;
-        const int CH = (int)(eval_t_doubles(n, D) / (2 * D + 1));       // peaks per chunk
         double bkey[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bk[4] = {0, 0, 0, 0};
-        double* TY = T; double* TC = T + CH * D; double* TW = T + 2 * CH * D;
         if constexpr (DC > 0 && DC <= 16) {
             // compile-time dimension: a row of z stays in registers and the peak tables never touch LDS -- the peak index is
             // wave-uniform, so y_k, C_k and log w_k are read from the constant address space, i.e. as scalar loads into SGPRs
@@ -457,28 +455,55 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
                     }
                 }
             }
-        } else
-        for (int c0 = 0; c0 < npk; c0 += CH) {
-            const int cn = npk - c0 < CH ? npk - c0 : CH;
-            for (int t = tid; t < cn * D; t += MBX_NT) { TY[t] = P.pyr[c0 * D + t]; TC[t] = P.pc[c0 * D + t]; }
-            for (int t = tid; t < cn; t += MBX_NT) TW[t] = P.plogw[c0 + t];
-            __syncthreads();
+        } else if (MBX_NW <= 8) {
+            // run-time (or large) dimension, up to 8 waves: the row stays in LDS (one read per coordinate, lanes = rows), the peak tables
+            // still come through scalar loads instead of LDS chunks (three LDS reads per (row, peak, coordinate)): LDE's Gallagher functions
+            // at D = 30 1290 -> 990 us per 16 384 instances.  (With 16 waves, config 5, a wave visits only 6-7 peaks and the chunk
+            // route below is 3 % faster: it stays for 1024-thread workgroups.)
+            typedef const double __attribute__((address_space(4)))* kptr;
+            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
+            const int wv = __builtin_amdgcn_readfirstlane(wave), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = lane + 64 * q;
                 if (i < n) {
                     const double* rx = Z + i * D;
-                    for (int kk = wave; kk < cn; kk += MBX_NW) {
-                        const double* ry = TY + kk * D;
-                        const double* ck = TC + kk * D;
+                    for (int kk = wv; kk < npk; kk += nw) {
+                        const kptr ry = py + (int64_t)kk * D;
+                        const kptr ck = pcc + (int64_t)kk * D;
                         double acc = 0.;
+#pragma unroll 8
                         for (int d = 0; d < D; ++d) { const double zd = rx[d] - ry[d]; acc = __builtin_fma(ck[d], zd * zd, acc); }
-                        const double key = TW[kk] + cexp * acc;
-                        if (key > bkey[q]) { bkey[q] = key; bk[q] = c0 + kk; }
+                        const double key = plw[kk] + cexp * acc;
+                        if (key > bkey[q]) { bkey[q] = key; bk[q] = kk; }
                     }
                 }
             }
-            __syncthreads();
+        } else {
+            const int CH = (int)(eval_t_doubles(n, D) / (2 * D + 1));       // peaks per chunk
+            double* TY = T; double* TC = T + CH * D; double* TW = T + 2 * CH * D;
+            for (int c0 = 0; c0 < npk; c0 += CH) {
+                const int cn = npk - c0 < CH ? npk - c0 : CH;
+                for (int t = tid; t < cn * D; t += MBX_NT) { TY[t] = P.pyr[c0 * D + t]; TC[t] = P.pc[c0 * D + t]; }
+                for (int t = tid; t < cn; t += MBX_NT) TW[t] = P.plogw[c0 + t];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < n) {
+                        const double* rx = Z + i * D;
+                        for (int kk = wave; kk < cn; kk += MBX_NW) {
+                            const double* ry = TY + kk * D;
+                            const double* ck = TC + kk * D;
+                            double acc = 0.;
+                            for (int d = 0; d < D; ++d) { const double zd = rx[d] - ry[d]; acc = __builtin_fma(ck[d], zd * zd, acc); }
+                            const double key = TW[kk] + cexp * acc;
+                            if (key > bkey[q]) { bkey[q] = key; bk[q] = c0 + kk; }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
