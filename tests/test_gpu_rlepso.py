@@ -491,3 +491,38 @@ def test_launch_info_routes_baseline_geometries_to_their_instantiations(env):
     b = Batch(s, ALGO_GLEET, [0, 1], [1, 2], NP, MAXFES, LOGI, NLOG)
     assert b.launch_info()['fixed_geometry'] == 5
     b.close()
+
+
+def test_rebind_and_read_public_equal_a_fresh_batch(env):
+    """mbx_batch_rebind (new problems / seeds for an existing batch, what a second PBO_Env.reset() on the same optimizer object needs)
+    gives exactly the trajectory of a freshly created batch, and mbx_read_public returns the scalar block + cost list that
+    mbx_debug_read_state shows."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_RLEPSO
+    s, ids = env['bbob']
+    B, G = 6, 8
+    acts = torch.rand(G, B, 35, generator=torch.Generator().manual_seed(4)).cuda()
+    p1, s1 = np.arange(B) % len(ids), np.arange(B, dtype=np.uint64) + 77
+    p2, s2 = (np.arange(B) * 5 + 3) % len(ids), np.arange(B, dtype=np.uint64) * 13 + 5
+
+    def run(batch):
+        batch.reset()
+        for g in range(G):
+            batch.step(acts[g])
+        torch.cuda.synchronize()
+        return np.stack([batch.read_state(b) for b in range(B)])
+    reused = Batch(s, ALGO_RLEPSO, p1, s1, NP, MAXFES, LOGI, NLOG)
+    first = run(reused)
+    reused.rebind(p2, s2)
+    second = run(reused)
+    fresh = Batch(s, ALGO_RLEPSO, p2, s2, NP, MAXFES, LOGI, NLOG)
+    want = run(fresh)
+    assert not np.array_equal(first, want)
+    assert np.array_equal(second, want, equal_nan=True)
+    off = 3 * NP * D + 3 * NP + D
+    for b in (0, B - 1):
+        pub = reused.read_public(b).copy()
+        full = want[b][off:off + 16 + NLOG + 1]
+        n = int(pub[oracle.SC_COST_LEN])
+        assert np.array_equal(pub[:16], full[:16]) and np.array_equal(pub[16:16 + n], full[16:16 + n])
+    reused.close(); fresh.close()
