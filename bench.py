@@ -127,30 +127,45 @@ def _latest_profile():
     return None, None
 
 
-def pmc_traffic_per_launch(live_per_launch):
-    """HBM bytes per launch of the generation kernel from the committed rocprofv3 PMC passes
-    (2 x FETCH_SIZE + WRITE_SIZE, calibration in profiles/*_pmc_hbm_traffic.json; collected with every instance
-    live), scaled to this run's average number of live instances per launch.  (None, None) when no profile is committed."""
+def _profile_for(resident):
+    """(file name, profile, env-steps per profiled launch) of the newest committed PMC summary IF it was taken on the kernel this run
+    uses (k_rlepso_run for --policy resident, k_rlepso_step otherwise); (None, None, None) otherwise."""
     name, prof = _latest_profile()
     try:
-        return prof['calibration']['hbm_bytes_per_launch'] / INSTANCES_PER_GPU * live_per_launch, name
+        cal = prof['calibration']
+        kernel = cal.get('kernel', 'mbx::k_rlepso_step')
+        if kernel != ('mbx::k_rlepso_run' if resident else 'mbx::k_rlepso_step'):
+            return None, None, None
+        return name, prof, float(cal.get('env_steps_per_launch', INSTANCES_PER_GPU))
+    except (KeyError, TypeError, AttributeError):
+        return None, None, None
+
+
+def pmc_traffic_per_launch(live_per_launch, resident=False):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, calibration in
+    profiles/*_pmc_hbm_traffic.json; collected with every instance live), scaled to the env-steps one launch of this run processes.
+    (None, None) when no profile of this kernel is committed."""
+    name, prof, per = _profile_for(resident)
+    try:
+        return prof['calibration']['hbm_bytes_per_launch'] / per * live_per_launch, name
     except (KeyError, TypeError):
         return None, None
 
 
-def valu_roofline(live_per_launch, avg_kernel_s):
-    """VALU side of the roofline ('report both achieved GB/s and VALU utilisation'): wave-instructions per launch by
-    class from the committed PMC profile x the issue cost of each class measured with tools/ubench/valu_rates.hip, scaled to this
-    run's live instances.  frac = issue-bound time / measured time (an interval: the counters do not split 2- and 4-cycle integer ops)."""
-    name, prof = _latest_profile()
+def valu_roofline(live_per_gen, avg_gen_s, resident=False):
+    """VALU side of the roofline ('report both achieved GB/s and VALU utilisation'), per GENERATION of the batch:
+    wave-instructions by class from the committed PMC profile x the issue cost of each class measured with tools/ubench/valu_rates.hip,
+    scaled to this run's live instances.  frac = issue-bound time / measured time (an interval: the counters do not split 2- and 4-cycle
+    integer ops)."""
+    name, prof, per = _profile_for(resident)
     try:
         v = prof['valu_issue_bound']
-        scale = live_per_launch / INSTANCES_PER_GPU
+        scale = live_per_gen / per
         lo, hi = (x * scale for x in v['issue_bound_us_at_2.4GHz'])
-        return {'bound': 'valu', 'wave_instructions_per_launch': v['wave_instructions_per_launch']['total'] * scale,
+        return {'bound': 'valu', 'wave_instructions_per_generation': v['wave_instructions_per_launch']['total'] * scale,
                 'f64_share': v['wave_instructions_per_launch']['f64_add_mul_fma'] / v['wave_instructions_per_launch']['total'],
-                'issue_bound_us': [lo, hi], 'measured_us': avg_kernel_s * 1e6,
-                'frac': [lo / (avg_kernel_s * 1e6), hi / (avg_kernel_s * 1e6)],
+                'issue_bound_us': [lo, hi], 'measured_us': avg_gen_s * 1e6,
+                'frac': [lo / (avg_gen_s * 1e6), hi / (avg_gen_s * 1e6)],
                 'active_lanes_per_instruction': v.get('active_lanes_per_valu_instruction'),
                 'source': f'profiles/{name} (rocprofv3 --pmc passes of this command, not collected during this run) + profiles/r02_valu_issue_rates.txt'}
     except (KeyError, TypeError, ZeroDivisionError):
@@ -307,10 +322,14 @@ def main():
                          "function ids (SURVEY §8(d) C2 asks for the split and per-function figures next to the headline)")
     ap.add_argument('--fixed-horizon', action='store_true',
                     help='disable the reference stop rule gbest <= 1e-8: every instance runs all 199 generations')
-    ap.add_argument('--policy', choices=['fused', 'hip', 'torch', 'table'], default='fused',
-                    help='fused: the generation kernel draws its own action from the actor table (mbx_rlepso_act_step, default); '
+    ap.add_argument('--policy', choices=['resident', 'fused', 'hip', 'torch', 'table'], default='resident',
+                    help='resident (default): mbx_rlepso_rollout, up to --gens-per-launch generations of act + step per launch with the state '
+                         'on chip in between; fused: one launch per generation, the kernel draws its own action from the actor table '
+                         '(mbx_rlepso_act_step); '
                          'hip: mbx_gauss_policy + mbx_step; torch: the two MLPs as batched PyTorch ops; table: (mu, sigma) gathered '
                          'from the per-fes table with PyTorch ops')
+    ap.add_argument('--gens-per-launch', type=int, default=50,
+                    help='--policy resident: generations per mbx_rlepso_rollout launch (a launch also ends at the episode / window end)')
     ap.add_argument('--graph-policy', action='store_true', help='with --policy torch / table: replay the policy as one hipGraph')
     ap.add_argument('--event-stride', type=int, default=0,
                     help='bracket every n-th generation kernel with HIP events (default: every kernel when steps <= 64, else every 8th)')
@@ -362,10 +381,11 @@ def main():
     table = agent.actor_table(MAXFES, NP_, dev)
 
     h1, h2 = actor.hidden_sizes()
-    if args.policy in ('fused', 'hip') and args.graph_policy:
+    if args.policy in ('resident', 'fused', 'hip') and args.graph_policy:
         raise SystemExit('--graph-policy applies to --policy torch / table')
     # fused: the actor evaluated at every reachable state, once (rebuilt whenever the weights change; they do not during a rollout)
-    fused_table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma) if args.policy == 'fused' else None
+    fused_table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma) if args.policy in ('fused', 'resident') else None
+    resident = args.policy == 'resident'
 
     def policy(st):
         if args.policy == 'hip':            # reads the batch's own state tensor (st is that tensor)
@@ -405,8 +425,10 @@ def main():
             static_actions = policy(state)
     gen_in_ep, live, base = 0, 0, 0
     t0 = None
+    launches = []                                           # resident: (event before, event after, generations) of every timed launch
     with torch.no_grad():
-        for it in range(W + K):
+        it = 0
+        while it < W + K:
             if it == W:
                 barrier()
                 base = steps_sum()
@@ -421,6 +443,20 @@ def main():
                     reset_steps.append(it - W)
                 if it <= W:
                     base = 0
+            if resident:
+                # one launch = up to --gens-per-launch generations; it ends where the warm-up, the timed window or the episode ends
+                n = min(max(1, args.gens_per_launch), EPISODE_GENS - gen_in_ep, (W if it < W else W + K) - it)
+                if it >= W:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                state, _, _ = env.batch.rlepso_rollout(fused_table, n)
+                if it >= W:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    launches.append((e0, e1, n))
+                it += n
+                gen_in_ep += n
+                continue
             if fused_table is not None:
                 actions = None
             elif policy_graph is not None:
@@ -437,6 +473,7 @@ def main():
             else:
                 state, _, _ = env.step(actions)
             gen_in_ep += 1
+            it += 1
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         marks.append(e); mark_step.append(K)
@@ -457,9 +494,12 @@ def main():
             continue                                    # a reset kernel (or policy kernels) inside the span: not a pure generation-kernel span
         span_ms += max(marks[j].elapsed_time(marks[j + 1]) - pair_ms, 0.)
         span_kernels += b_ - a_
+    if resident:                                        # every launch of the window is bracketed by its own event pair
+        span_ms = sum(max(a_.elapsed_time(b_) - pair_ms, 0.) for a_, b_, _ in launches)
+        span_kernels = sum(n for _, _, n in launches)
     if span_kernels == 0:                               # policies that launch their own kernels between generations: fall back to the step time
         span_ms, span_kernels = elapsed * 1e3, K
-    kern_ms = span_ms / span_kernels * K
+    kern_ms = span_ms / span_kernels * K                # generation-kernel time of the K timed generations
 
     red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
     tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=red_dev)
@@ -474,11 +514,16 @@ def main():
             args.functions, 'bbob function(s) ' + args.functions)
         stop_desc = 'fixed horizon (stop rule disabled)' if args.fixed_horizon else 'reference stop rule'
         value = live_all / elapsed_max
-        avg_kernel_s = (kern_ms_all / world) / K / 1e3
-        live_per_launch = live_all / world / K
+        # one "launch" of the dominant kernel: a generation (k_rlepso_step) or, resident, the generations of one mbx_rlepso_rollout call
+        n_launch = len(launches) if resident else K
+        gens_per_launch = K / n_launch
+        avg_gen_s = (kern_ms_all / world) / K / 1e3
+        avg_kernel_s = avg_gen_s * gens_per_launch
+        live_per_gen = live_all / world / K
+        live_per_launch = live_per_gen * gens_per_launch           # env-steps (live instance-generations) one launch processes
         bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
-        traffic, traffic_src = pmc_traffic_per_launch(live_per_launch)
+        traffic, traffic_src = pmc_traffic_per_launch(live_per_launch, resident)
         first_gen = W % EPISODE_GENS + 1
         out = {
             'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
@@ -488,25 +533,31 @@ def main():
                                    f'({fn_desc} round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'{stop_desc}, policy = exported bbob_easy RLEPSO weights sampled on device',
                        'instances_per_gpu': B, 'live_env_steps': live_all, 'parallelism': f'instances sharded x{world}',
-                       'policy': {'fused': 'act + step in one launch (mbx_rlepso_act_step): the generation kernel draws its action from the '
+                       'policy': {'resident': f'mbx_rlepso_rollout: up to {args.gens_per_launch} generations of act + step per launch, the instance state stays in '
+                                              'LDS / registers between generations (read once, written once per launch); actions drawn in the kernel from the '
+                                              'actor (mu, sigma) table built by mbx_rlepso_policy_table; bit-identical to one mbx_rlepso_act_step launch per generation',
+                                  'fused': 'act + step in one launch (mbx_rlepso_act_step): the generation kernel draws its action from the '
                                            'actor (mu, sigma) table built by mbx_rlepso_policy_table (actor evaluated at every reachable '
                                            'state fes/maxFEs)',
                                   'hip': 'mbx_gauss_policy (both MLPs over the whole batch, one launch) + mbx_step per generation',
                                   'torch': 'both actor MLPs as batched PyTorch ops every generation' + (', hipGraph replay' if args.graph_policy else ''),
                                   'table': '(mu, sigma) gathered from the per-fes table with PyTorch ops' + (', hipGraph replay' if args.graph_policy else '')}[args.policy],
-                       'kernel_timing': f'one HIP event every {stride} generations on the launch stream; consecutive events bracket {stride} back-to-back '
-                                        f'generation kernels (all of them are covered), minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)',
+                       'kernel_timing': (f'every launch of the timed window bracketed by its own HIP event pair on the launch stream ({len(launches)} launches), '
+                                         f'minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)') if resident else
+                                        (f'one HIP event every {stride} generations on the launch stream; consecutive events bracket {stride} back-to-back '
+                                         f'generation kernels (all of them are covered), minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)'),
                        'timed_window': f'{K} consecutive lock-step generations starting at generation {first_gen} of an episode of {EPISODE_GENS} '
                                        f'(episodes restart with mbx_reset inside the window when it is longer)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': (f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
                                             f"run's live instances (not collected during this run)") if traffic_src else None,
-                         'kernel': 'k_rlepso_step<256, 100, 10, 5>',
+                         'kernel': 'k_rlepso_run<256, 100, 10, 5>' if resident else 'k_rlepso_step<256, 100, 10, 5>',
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
-                         'live_instances_per_launch': live_all / world / K,
-                         'valu': valu_roofline(live_per_launch, avg_kernel_s)},
+                         'env_steps_per_launch': live_per_launch, 'generations_per_launch': gens_per_launch,
+                         'avg_generation_us': avg_gen_s * 1e6, 'live_instances_per_generation': live_per_gen,
+                         'valu': valu_roofline(live_per_gen, avg_gen_s, resident)},
         }
         if world == 1 and not args.no_other_configs:
             try:

@@ -231,6 +231,27 @@ int mbx_rlepso_policy_table(mbx_batch* b, const mbx_gauss_mlp* net, float* d_tab
 int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out, double* d_state_out,
                         double* d_reward_out, uint8_t* d_done_out, void* stream);
 
+/* The whole loop of RLEPSO_Agent.rollout_episode (src/agent/rlepso_agent.py:294-303: `while not is_done: action = actor(state);
+ * state, reward, is_done = env.step(action)`), up to n_gens generations of every instance in ONE launch, with the instance's state
+ * ON CHIP between generations: with the actor inside the kernel (d_table from mbx_rlepso_policy_table) nothing has to leave the
+ * workgroup between two generations, so the state block (include/mbx_layout.h section 2) is read once, kept in LDS / registers and
+ * written once per launch instead of once per generation.  Every generation does exactly what mbx_rlepso_act_step does, with the
+ * same Philox counters: n_gens calls of mbx_rlepso_act_step and one call of mbx_rlepso_rollout leave bit-identical states, cost
+ * curves and returns.  A workgroup leaves the launch when its instance terminates (rlepso_optimizer.py:246-249) and its slot goes
+ * to the next workgroup of the grid, so instances that finish early cost nothing afterwards.
+ * Per-generation records for training (rlepso_agent.py:143-190 collects exactly these), each may be NULL:
+ *   d_traj_actions [n_gens, n_instances, out_dim] float32  sampled actions (rows of generations after termination are not written)
+ *   d_traj_state   [n_gens, n_instances] float64           state AFTER the generation (fes / maxFEs)
+ *   d_traj_reward  [n_gens, n_instances] float64           reward (0 after termination)
+ *   d_traj_done    [n_gens, n_instances] uint8             is_done (1 after termination)
+ * d_state_out / d_done_out [n_instances]: state / is_done after the last executed generation; d_reward_out [n_instances]: SUM of
+ * the rewards of the executed generations (like mbx_rlpso_rollout).
+ * The compile-time geometries (NP 100 / D 10 and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
+ * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 forces that route). */
+int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_traj_actions, double* d_traj_state,
+                       double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out, double* d_reward_out,
+                       uint8_t* d_done_out, void* stream);
+
 /* RL-PSO moves ONE particle per env step, so a rollout is maxFEs - NP steps of D-element arithmetic plus one evaluation:
  * launch latency, not work.  mbx_rlpso_rollout runs `n_steps` consecutive steps of every instance in ONE launch with the
  * actor evaluated inside the kernel (the loop of RL_PSO_Agent.rollout_episode, src/agent/rl_pso_agent.py:112-124).  It is

@@ -224,10 +224,12 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': R}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, policy='fused'):
-        """Lock-step rollout of a BatchedPBO_Env: no host sync inside the episode.  ``policy`` selects how the actor runs:
-        'fused' act + step in ONE launch per generation (``mbx_rlepso_act_step``): the actor is evaluated once per rollout at
-                every reachable state (``mbx_rlepso_policy_table``) and the generation kernel draws its own action -- the default;
+    def rollout_batch(self, env, max_steps=None, policy='resident'):
+        """Rollout of a BatchedPBO_Env: no host sync inside the episode.  ``policy`` selects how the actor runs:
+        'resident' the WHOLE episode in one launch (``mbx_rlepso_rollout``): the actor is evaluated once per rollout at every reachable
+                state (``mbx_rlepso_policy_table``), every workgroup draws its own actions and keeps its instance's state on chip from the
+                first generation to the last -- the default; bit-identical to 'fused';
+        'fused' act + step in ONE launch per generation (``mbx_rlepso_act_step``), same table, same draws;
         'hip'   one ``mbx_gauss_policy`` launch per generation (weights in LDS), then ``mbx_step``; bit-identical to 'fused';
         'torch' the two MLPs as batched PyTorch GEMMs (``Actor.act_batch``, torch's generator);
         'table' (mu, sigma) gathered from the per-fes table of the actor evaluated once (``ActorTable``).
@@ -240,12 +242,15 @@ class RLEPSO_Agent(Basic_Agent):
         if max_steps is None:
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         actor = self.__actor
-        if policy == 'fused':
+        if policy in ('fused', 'resident'):
             h1, h2 = actor.hidden_sizes()
             table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
             env.reset()
-            for _ in range(max_steps):
-                env.batch.act_step(table)
+            if policy == 'resident':
+                env.batch.rlepso_rollout(table, max_steps)
+            else:
+                for _ in range(max_steps):
+                    env.batch.act_step(table)
             res = env.results()
             return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
                     'cost_len': res['cost_len']}
@@ -260,7 +265,7 @@ class RLEPSO_Agent(Basic_Agent):
             def act(state):
                 return actor.act_batch(state.to(torch.float32))
         else:
-            raise ValueError(f"policy must be 'fused', 'hip', 'torch' or 'table', not {policy!r}")
+            raise ValueError(f"policy must be 'resident', 'fused', 'hip', 'torch' or 'table', not {policy!r}")
         state = env.reset()
         for _ in range(max_steps):
             state, _, _ = env.step(act(state))

@@ -64,6 +64,7 @@ struct mbx_batch {
     double* d_state = nullptr;
     int32_t* d_order = nullptr;
     double* d_pci = nullptr;
+    double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (allocated on first use)
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
     size_t lds_bytes = 0;
@@ -466,6 +467,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -507,7 +510,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
 extern "C" int mbx_batch_destroy(mbx_batch* b)
 {
     if (!b) return MBX_OK;
-    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order); (void)hipFree(b->d_pci);
+    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order); (void)hipFree(b->d_pci); (void)hipFree(b->d_scratch);
     delete b;
     return MBX_OK;
 }
@@ -738,6 +741,52 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_act_step: the batch is not an RLEPSO batch");
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_act_step: a replay tape carries no policy draws; use mbx_step with recorded actions");
     launch_rlepso_step(b, (hipStream_t)stream, nullptr, d_state_out, d_reward_out, d_done_out, d_table, mbx_rlepso_policy_table_rows(b), d_actions_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+__global__ void k_sum_rewards(double* __restrict__ acc, const double* __restrict__ r, int n, int first)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = first ? r[i] : acc[i] + r[i];
+}
+
+extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_traj_actions, double* d_traj_state,
+                                  double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out, double* d_reward_out,
+                                  uint8_t* d_done_out, void* stream)
+{
+    if (!b || !d_table) return fail(MBX_E_ARG, "mbx_rlepso_rollout: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_RLEPSO) return fail(MBX_E_UNSUPPORTED, "mbx_rlepso_rollout: the batch is not an RLEPSO batch");
+    if (n_gens < 1) return fail(MBX_E_ARG, "mbx_rlepso_rollout: n_gens must be >= 1");
+    if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_rollout: a replay tape holds one generation and no policy draws; use mbx_step with recorded actions");
+    const int rows = mbx_rlepso_policy_table_rows(b);
+    const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");      // tests: force the one-launch-per-generation route
+    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !(per_gen && per_gen[0] == '1')) {
+        const RunOut out{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
+        if (b->fixed_geometry == 1)
+            hipLaunchKernelGGL((k_rlepso_run<kThreads, 100, 10, 5>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream,
+                               make_params(b), d_table, rows, n_gens, out);
+        else
+            hipLaunchKernelGGL((k_rlepso_run<1024, 128, 40, 5>), dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream,
+                               make_params(b), d_table, rows, n_gens, out);
+        HIP_TRY(hipGetLastError());
+        return MBX_OK;
+    }
+    // run-time geometries: one k_rlepso_step launch per generation, same outputs
+    if (d_reward_out && !d_traj_reward && !b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, (size_t)b->B * sizeof(double)));
+    const int64_t B = b->B, A = b->action_dim;
+    for (int g = 0; g < n_gens; ++g) {
+        double* r = d_traj_reward ? d_traj_reward + g * B : (d_reward_out ? b->d_scratch : nullptr);
+        double* st = d_traj_state ? d_traj_state + g * B : d_state_out;
+        uint8_t* dn = d_traj_done ? d_traj_done + g * B : d_done_out;
+        launch_rlepso_step(b, (hipStream_t)stream, nullptr, st, r, dn, d_table, rows, d_traj_actions ? d_traj_actions + g * B * A : nullptr);
+        if (d_reward_out)
+            hipLaunchKernelGGL(k_sum_rewards, dim3((b->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_reward_out, r, b->B, g == 0);
+    }
+    if (d_traj_state && d_state_out)
+        HIP_TRY(hipMemcpyAsync(d_state_out, d_traj_state + (n_gens - 1) * B, B * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (d_traj_done && d_done_out)
+        HIP_TRY(hipMemcpyAsync(d_done_out, d_traj_done + (n_gens - 1) * B, B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

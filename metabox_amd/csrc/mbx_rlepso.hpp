@@ -271,8 +271,9 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
 // Velocity / position update of W adjacent coordinates of particle i (rlepso_optimizer.py:179-195); FDR exemplars from KB.
 // CLPSO (:76-95): one Philox call carries the uniforms of an element PAIR (site ELEM_A, index e >> 1), another one (site TOURN, same
 // index) the two tournament pairs; the latter is only evaluated where a tournament is consumed, i.e. where !(u > pci_i).
-template <int W>
-__device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, const double cur[W], const double vel[W])
+// RES: the caller keeps positions / velocities on chip (k_rlepso_run): the new values come back in cur / vel instead of going to HBM.
+template <int W, bool RES = false>
+__device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, double cur[W], double vel[W])
 {
     const RlLds& L = c.L;
     const int NP = c.NP, D = c.D;
@@ -339,8 +340,8 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, const d
         double np_ = cur[q] + nv;
         np_ = fmin(fmax(np_, c.lb), c.ub);
         L.X[e] = np_;
-        c.gPos[e] = np_;
-        c.gVel[e] = nv;
+        if (RES) { cur[q] = np_; vel[q] = nv; }
+        else { c.gPos[e] = np_; c.gVel[e] = nv; }
     }
 }
 
@@ -576,13 +577,13 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         for (int it = tid; it < NI; it += MBX_NT) {
             const int i = fh.div(it);
             const double2 c2 = *(const double2*)(gPos + 2 * it), v2 = *(const double2*)(gVel + 2 * it);
-            const double cur[2] = {c2.x, c2.y}, vel[2] = {v2.x, v2.y};
+            double cur[2] = {c2.x, c2.y}, vel[2] = {v2.x, v2.y};
             rl_move<2>(mc, i, 2 * (it - i * HD), cur, vel);
         }
     } else {
         for (int e = tid; e < NE; e += MBX_NT) {
             const int i = fd.div(e);
-            const double cur[1] = {gPos[e]}, vel[1] = {gVel[e]};
+            double cur[1] = {gPos[e]}, vel[1] = {gVel[e]};
             rl_move<1>(mc, i, e - i * D, cur, vel);
         }
     }
@@ -650,6 +651,306 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         if (done_out) done_out[b] = done ? 1 : 0;
     }
     MBX_PHASE(8);                                                 // write-back, logging
+}
+
+// ------------------------------------------------------------------------------------------------
+// Agent.rollout_episode's loop (src/agent/rlepso_agent.py:294-303), up to n_gens generations per launch, state ON CHIP in between
+// ------------------------------------------------------------------------------------------------
+// k_rlepso_step streams an instance's 26.5 KB state block in and out once per generation because a policy outside the kernel needs
+// the state between generations.  With the policy inside (actor table, as in mbx_rlepso_act_step) nothing leaves the workgroup between
+// two generations, so this kernel loads the block ONCE, runs up to n_gens generations and stores it ONCE: positions stay in LDS (X is
+// only read by the evaluator), velocities, pbest positions and c_cost stay in registers of the thread that owns the element / particle,
+// the per-particle arrays and the problem constants stay in LDS.  Every generation performs exactly the arithmetic of k_rlepso_step with
+// the same Philox counters (gen is part of the counter), so n_gens launches of mbx_rlepso_act_step and one launch of this kernel give
+// bit-identical states (tests/test_gpu_rlepso.py).  A workgroup leaves as soon as its instance is done and the hardware dispatcher hands
+// its slot to the next workgroup: no lock-step idling, no refill queue needed.
+// Compile-time geometry only (even D, NP <= THREADS: particle i's scalars live in thread i); other geometries are stepped by the host
+// loop in mbx_rlepso_rollout.
+struct RunOut {
+    float* traj_actions;         // [n_gens][B][7 G] sampled actions, or nullptr
+    double* traj_state;          // [n_gens][B] state after the generation (fes / maxFEs), or nullptr
+    double* traj_reward;         // [n_gens][B]
+    uint8_t* traj_done;          // [n_gens][B]
+    double* state_out;           // [B] state after the last executed generation, or nullptr
+    double* reward_out;          // [B] SUM of the rewards of the executed generations, or nullptr
+    uint8_t* done_out;           // [B]
+};
+
+#ifndef MBX_RUN_WAVES
+#define MBX_RUN_WAVES MBX_RL_WAVES
+#endif
+template <int THREADS, int NPC, int DC, int GC>
+__global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParams bp, const float* __restrict__ policy_table, int table_rows,
+                                                                     int n_gens, RunOut out)
+{
+    static_assert(NPC > 0 && DC > 0 && GC > 0 && (DC & 1) == 0 && NPC <= THREADS, "k_rlepso_run: compile-time geometry, even D, NP <= THREADS");
+    constexpr int NP = NPC, D = DC, G = GC, HD = D / 2, NI = NP * HD, IT = (NI + THREADS - 1) / THREADS, A = 7 * G;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = bp.order[blockIdx.x], tid0 = threadIdx.x, tid = tid0;
+    double* S = bp.state + (int64_t)b * bp.state_stride;
+    double* sc = S + MBX_RLEPSO_ST_SCALARS(NP, D);
+    const int64_t B = bp.B;
+
+    if (sc[MBX_SC_DONE] != 0.) {                                  // finished before the launch: what k_rlepso_step reports for it, n_gens times
+        const double st = sc[MBX_SC_FES] / bp.max_fes;
+        for (int g = tid; g < n_gens; g += THREADS) {
+            if (out.traj_state) out.traj_state[g * B + b] = st;
+            if (out.traj_reward) out.traj_reward[g * B + b] = 0.;
+            if (out.traj_done) out.traj_done[g * B + b] = 1;
+        }
+        if (tid == 0) {
+            if (out.state_out) out.state_out[b] = st;
+            if (out.reward_out) out.reward_out[b] = 0.;
+            if (out.done_out) out.done_out[b] = 1;
+        }
+        return;
+    }
+    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    const RlLds L = rl_carve(smem, NP, D);
+    int gen = (int)sc[MBX_SC_GEN];
+    const uint64_t seed = bp.seeds[b];
+    const uint32_t episode = (uint32_t)(int)sc[MBX_SC_EPISODE];
+    const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
+    double gbest = sc[MBX_SC_GBEST];
+    int gbest_idx = (int)sc[MBX_SC_GBEST_IDX];
+    double fes = sc[MBX_SC_FES];
+    int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
+    double* cost = sc + MBX_NSCALAR;
+    double ret = 0.;
+    int n_reinit = 0;
+
+    // ---- load the state block once: positions -> X (LDS), velocities / pbest positions -> registers of the element's owner
+    // (work item it = tid + j THREADS owns the adjacent coordinates 2 it, 2 it + 1 of particle it / HD), c_cost -> register of thread i
+    double* gPos = S + MBX_RLEPSO_ST_POS(NP, D);
+    double* gVel = S + MBX_RLEPSO_ST_VEL(NP, D);
+    double* gPB = S + MBX_RLEPSO_ST_PBPOS(NP, D);
+    double vel[IT][2], pbp[IT][2], cc = 0.;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int it = tid + j * THREADS;
+        vel[j][0] = vel[j][1] = pbp[j][0] = pbp[j][1] = 0.;
+        if (it < NI) {
+            const double2 v2 = *(const double2*)(gVel + 2 * it), p2 = *(const double2*)(gPB + 2 * it);
+            vel[j][0] = v2.x; vel[j][1] = v2.y; pbp[j][0] = p2.x; pbp[j][1] = p2.y;
+            *(double2*)(L.X + 2 * it) = *(const double2*)(gPos + 2 * it);
+        }
+    }
+    if (tid < NP) {
+        L.PBC[tid] = S[MBX_RLEPSO_ST_PBEST(NP, D) + tid];
+        L.PNI[tid] = S[MBX_RLEPSO_ST_PNI(NP, D) + tid];
+        cc = S[MBX_RLEPSO_ST_CCOST(NP, D) + tid];
+    }
+    if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
+    stage_problem<eval_dc(DC)>(P, L.eval());
+    constexpr int per_group = NP / G;
+    const FastDiv fg(per_group), fh(HD);
+    int* ORDER = L.IMPR;          // free until the first commit of a generation
+    int* NLESS = L.MASK;
+    int* RANK = L.RANK;           // doubles as the nle accumulator
+    float* ACT = (float*)L.R1;    // sampled action; R1 is not written before the ranking barrier
+
+    // pbest / gbest bookkeeping of update() and __reinit() (rl_commit with c_cost and the pbest positions in registers)
+    auto commit = [&](bool stagnation, int tid) {
+        if (tid < NP) {
+            const double nc = L.NC[tid];
+            if (stagnation) L.PNI[tid] = nc < cc ? 0. : L.PNI[tid] + 1;
+            const int impr = nc < L.PBC[tid];
+            if (impr) L.PBC[tid] = nc;
+            L.IMPR[tid] = impr;
+            cc = nc;
+        }
+        double cbv; int cb;
+        block_argmin(L.NC, NP, L.RED, cbv, cb);         // contains the barriers that publish IMPR
+        const bool better = cbv < gbest;
+        if (better) { gbest = cbv; gbest_idx = cb; }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int it = tid + j * THREADS;
+            if (it < NI && L.IMPR[fh.div(it)]) { const double2 x2 = *(const double2*)(L.X + 2 * it); pbp[j][0] = x2.x; pbp[j][1] = x2.y; }
+        }
+        if (better && tid < D) L.GB[tid] = L.X[cb * D + tid];
+        __syncthreads();
+    };
+
+    bool done = false;
+    int g = 0;
+    __syncthreads();
+    for (; g < n_gens && !done; ++g) {
+        // the thread index is re-materialised every generation: otherwise the compiler hoists all the index arithmetic of the body out of
+        // the loop and spills it (528 B of scratch per thread), which the one-generation kernel never has to carry
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        gen += 1;
+        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, episode};
+        const double pre_gbest = gbest;
+        // ---- agent.act: the action of this generation from row fes of the actor table (same draws as mbx_gauss_policy)
+        if (tid < A) {
+            int row = (int)fes;
+            row = row < table_rows ? row : table_rows - 1;
+            const float* ms = policy_table + (int64_t)row * 2 * A;
+            const float a = sample_action(rng, tid, ms[tid], ms[A + tid], MBX_POLICY_RLEPSO);
+            ACT[tid] = a;
+            if (out.traj_actions) out.traj_actions[((int64_t)g * B + b) * A + tid] = a;
+        }
+        if (tid < NP) { RANK[tid] = 0; NLESS[tid] = 0; ORDER[tid] = tid; }
+        __syncthreads();
+        if (tid < G) {                                            // __get_coe (:112-132), float32 like k_rlepso_step
+            const float* a = ACT + tid * G;
+            const float cm = a[0] * 0.01f;
+            const float wv = a[1] * 0.8f + 0.1f;
+            float den = a[3] + a[4];
+            den = den + a[5]; den = den + a[6]; den = den + 1e-5f;
+            float scale = 1.f / den;
+            scale = scale * a[2]; scale = scale * 8.f;
+            double* c = L.COEF + tid * 6;
+            c[0] = (double)cm; c[1] = (double)wv;
+            c[2] = (double)(scale * a[3]); c[3] = (double)(scale * a[4]);
+            c[4] = (double)(scale * a[5]); c[5] = (double)(scale * a[6]);
+        }
+        // ---- rank the particles by (pbest cost, index), see k_rlepso_step
+        {
+            constexpr int parts = THREADS / NP > 0 ? THREADS / NP : 1;
+            for (int w = tid; w < parts * NP; w += THREADS) {
+                const int part = w / NP, i = w - part * NP;
+                const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
+                const double fi = L.PBC[i];
+                int nle = 0, nless = 0;
+#pragma unroll 4
+                for (int j = j0; j < j1; ++j) {
+                    const double fj = L.PBC[j];
+                    nless += fj < fi;
+                    nle += fj <= fi;
+                }
+                atomicAdd(&RANK[i], nle); atomicAdd(&NLESS[i], nless);
+            }
+        }
+        __syncthreads();
+        if (tid < NP) {
+            const int i = tid, gi = fg.div(i);
+            L.CMUT[i] = gi < G ? L.COEF[gi * 6] * L.PNI[i] : 0.;
+            const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART);
+            L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w);
+            const double fi = L.PBC[i];
+            int rank = NLESS[i];
+            if (RANK[i] - rank > 1)
+                for (int j = 0; j < i; ++j) rank += L.PBC[j] == fi;
+            RANK[i] = rank;
+            ORDER[rank] = i; L.NC[rank] = fi;
+        }
+        __syncthreads();
+        // ---- pbest positions -> LDS in rank order, from the owners' registers
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int it = tid + j * THREADS;
+            if (it < NI) { const int i = fh.div(it), d0 = 2 * (it - i * HD); *(double2*)(L.PB + RANK[i] * D + d0) = double2{pbp[j][0], pbp[j][1]}; }
+        }
+        __syncthreads();
+        // ---- FDR exemplars -> KB (see k_rlepso_step)
+        for (int base = 0, pass = 0; base < NI; base += THREADS, ++pass) {
+            const int lim = base + THREADS < NI ? base + THREADS : NI;
+            const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
+            if (ps >= base && ps < lim) {
+                const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
+                int kb[2];
+                fdr_exact<2>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
+            }
+        }
+        __syncthreads();
+        // ---- velocity / position update (:179-195): new position -> X, new velocity -> register
+        {
+            const MoveCtx mc{L, bp, nullptr, rng, nullptr, nullptr, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int it = tid + j * THREADS;
+                if (it < NI) {
+                    const int i = fh.div(it);
+                    const double2 c2 = *(const double2*)(L.X + 2 * it);
+                    double cur[2] = {c2.x, c2.y};
+                    rl_move<2, true>(mc, i, 2 * (it - i * HD), cur, vel[j]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- evaluate, update pbest / gbest and the stagnation counters (:198-233)
+        population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+        fes += NP;
+        commit(true, tid);
+        // ---- re-initialisation (:238-239, 134-168)
+        int mine = 0;
+        if (tid < NP) {
+            const U4 w = rng.draw((uint32_t)tid, MBX_SITE_REINIT);
+            const double u = u53(w.x, w.y);
+            mine = u < L.CMUT[tid] * 0.01 * L.PNI[tid];
+            L.MASK[tid] = mine;
+        }
+        n_reinit = __syncthreads_count(mine);
+        if (n_reinit > 0) {
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int it = tid + j * THREADS;
+                if (it < NI && L.MASK[fh.div(it)]) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = 2 * it + q;
+                        const U4 w = rng.draw((uint32_t)e, MBX_SITE_ELEM_R);
+                        const double up = u53(w.x, w.y), uv = u53(w.z, w.w);
+                        L.X[e] = lb + (ub - lb) * up;
+                        vel[j][q] = -vmax + (vmax - (-vmax)) * uv;
+                    }
+                }
+            }
+            __syncthreads();
+            population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+            fes += n_reinit;
+            commit(false, tid);
+        }
+        // ---- logging, termination, reward (:241-261); every thread keeps the (block-uniform) counters, thread 0 writes the curve
+        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; if (tid == 0) cost[cost_len] = gbest; cost_len += 1; }
+        done = fes >= bp.max_fes;
+        if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
+        if (done) {
+            if (cost_len >= bp.n_logpoint + 1) { if (tid == 0) cost[cost_len - 1] = gbest; }
+            else { if (tid == 0) cost[cost_len] = gbest; cost_len += 1; }
+        }
+        const double reward = gbest < pre_gbest ? 1. : -1.;
+        ret += reward;
+        if (tid == 0) {
+            if (out.traj_state) out.traj_state[g * B + b] = fes / bp.max_fes;
+            if (out.traj_reward) out.traj_reward[g * B + b] = reward;
+            if (out.traj_done) out.traj_done[g * B + b] = done ? 1 : 0;
+        }
+    }
+    // ---- store the state block once
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int it = tid + j * THREADS;
+        if (it < NI) {
+            *(double2*)(gPos + 2 * it) = *(const double2*)(L.X + 2 * it);
+            *(double2*)(gVel + 2 * it) = double2{vel[j][0], vel[j][1]};
+            *(double2*)(gPB + 2 * it) = double2{pbp[j][0], pbp[j][1]};
+        }
+    }
+    if (tid < NP) {
+        S[MBX_RLEPSO_ST_PBEST(NP, D) + tid] = L.PBC[tid];
+        S[MBX_RLEPSO_ST_PNI(NP, D) + tid] = L.PNI[tid];
+        S[MBX_RLEPSO_ST_CCOST(NP, D) + tid] = cc;
+    }
+    if (tid < D) S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid] = L.GB[tid];
+    const double st = fes / bp.max_fes;
+    for (int t = g + tid; t < n_gens; t += THREADS) {            // generations after the instance finished
+        if (out.traj_state) out.traj_state[t * B + b] = st;
+        if (out.traj_reward) out.traj_reward[t * B + b] = 0.;
+        if (out.traj_done) out.traj_done[t * B + b] = 1;
+    }
+    if (tid == 0) {
+        sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
+        sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += ret; sc[MBX_SC_GEN] = gen;
+        sc[MBX_SC_GBEST_IDX] = gbest_idx; sc[MBX_SC_REINIT] = n_reinit > 0 ? 1. : 0.;
+        if (out.state_out) out.state_out[b] = st;
+        if (out.reward_out) out.reward_out[b] = ret;
+        if (out.done_out) out.done_out[b] = done ? 1 : 0;
+    }
 }
 
 }  // namespace mbx

@@ -236,6 +236,26 @@ class Batch:
                                                 _stream()))
         return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
 
+    def rlepso_rollout(self, table, n_gens, trajectory=False):
+        """Up to `n_gens` generations of agent.act + env.step per instance in ONE launch with the state on chip in between
+        (``mbx_rlepso_rollout``); bit-identical to `n_gens` calls of act_step.  Returns (state, reward summed over the executed
+        generations, done) and, with ``trajectory=True``, a dict of per-generation records: actions [n_gens, B, action_dim] float32,
+        state / reward [n_gens, B] float64, done [n_gens, B] uint8 (rows after an instance's termination: reward 0, done 1, actions
+        not written)."""
+        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        n_gens = int(n_gens)
+        traj = None
+        if trajectory:
+            traj = {'actions': torch.zeros(n_gens, self.B, self.action_dim, dtype=torch.float32, device=self.device),
+                    'state': torch.empty(n_gens, self.B, dtype=torch.float64, device=self.device),
+                    'reward': torch.empty(n_gens, self.B, dtype=torch.float64, device=self.device),
+                    'done': torch.empty(n_gens, self.B, dtype=torch.uint8, device=self.device)}
+        t = traj or {}
+        _abi.check(self.lib.mbx_rlepso_rollout(self._h, _ptr(table), n_gens, _ptr(t.get('actions')), _ptr(t.get('state')),
+                                               _ptr(t.get('reward')), _ptr(t.get('done')), _ptr(self.state), _ptr(self.reward),
+                                               _ptr(self.done), _stream()))
+        return (self.state, self.reward, self.done, traj) if trajectory else (self.state, self.reward, self.done)
+
     def results(self):
         """-> dict of device tensors: cost [B, n_logpoint+1], fes [B], return [B], steps [B], cost_len [B]."""
         n = self.cfg.n_logpoint + 1

@@ -43,18 +43,38 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_kernel_us'] * 1e-6) / 1e9) <= 1e-6 * r['achieved']
     assert r['algorithmic_bytes_per_env_step'] == 54057 and 0 < r['avg_kernel_us'] < 1e4
-    assert r['traffic'] is None or 0.5 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 2.0
-    # event brackets are net of the empty-pair cost: the kernel cannot take longer than the step that contains it
-    assert r['avg_kernel_us'] <= d['ms_per_step'] * 1e3 * 1.02
-    assert 'generation' in d['config']['timed_window'] and 'every 2 generations' in d['config']['kernel_timing']
+    # default route: the resident rollout kernel, 40 generations in one launch; its state never leaves the chip between generations, so the
+    # measured HBM traffic (when a profile of this kernel is committed) is far BELOW the algorithmic bytes of a per-generation round trip
+    assert r['kernel'].startswith('k_rlepso_run') and r['generations_per_launch'] == 40 and 'mbx_rlepso_rollout' in d['config']['policy']
+    assert abs(r['env_steps_per_launch'] - d['config']['live_env_steps']) <= 1e-6 * r['env_steps_per_launch']
+    assert r['traffic'] is None or 0 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 1.0
+    # event brackets are net of the empty-pair cost: the launch cannot take longer than the steps it contains
+    assert r['avg_kernel_us'] <= d['ms_per_step'] * 1e3 * r['generations_per_launch'] * 1.02
+    assert abs(r['avg_generation_us'] * r['generations_per_launch'] - r['avg_kernel_us']) <= 1e-6 * r['avg_kernel_us']
+    assert 'generation' in d['config']['timed_window'] and 'event pair' in d['config']['kernel_timing']
     v = r['valu']
-    assert v is None or (v['bound'] == 'valu' and 0 < v['frac'][0] <= v['frac'][1] and v['wave_instructions_per_launch'] > 1e6)
+    assert v is None or (v['bound'] == 'valu' and 0 < v['frac'][0] <= v['frac'][1] and v['wave_instructions_per_generation'] > 1e6)
     oc = d['other_configs']
     assert isinstance(oc, list) and len(oc) == 4, oc
     assert [e['config'].split(':')[0] for e in oc] == ['config 3', 'config 3', 'config 4', 'config 5']
     for e in oc:
         assert e['ms_per_step'] > 0 and abs(e['env_steps_per_s'] - e['instances'] / (e['ms_per_step'] * 1e-3)) <= 1e-6 * e['env_steps_per_s']
         assert 0 < e['roofline_frac'] < 1
+
+
+@pytest.mark.gpu
+def test_bench_one_launch_per_generation_route():
+    """--policy fused: one mbx_rlepso_act_step launch per generation (the route the resident kernel is bit-identical to); a launch is a
+    generation, so the per-launch and per-generation figures coincide and the traffic is the state block's round trip."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '24', '--warmup', '4', '--no-cpu-baseline',
+                          '--no-other-configs', '--policy', 'fused'], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-600:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    r = d['roofline']
+    assert r['kernel'].startswith('k_rlepso_step') and r['generations_per_launch'] == 1 and 'mbx_rlepso_act_step' in d['config']['policy']
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_kernel_us'] * 1e-6) / 1e9) <= 1e-6 * r['achieved']
+    assert r['avg_kernel_us'] <= d['ms_per_step'] * 1e3 * 1.02 and 'every 2 generations' in d['config']['kernel_timing']
+    assert r['traffic'] is None or 0.5 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 2.0
 
 
 @pytest.mark.gpu

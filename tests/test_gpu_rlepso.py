@@ -315,9 +315,73 @@ def test_fused_act_step_equals_policy_then_step():
         assert torch.equal(ra_[key], rb_[key]), key
     assert bool(ra_['fes'].max() >= 20000) and bool((ra_['steps'] < 199).any())         # Sphere instances stopped early
     # rollout_batch('fused') is that loop
-    out = agent.rollout_batch(BatchedPBO_Env(ps, RLEPSO_Optimizer(cfg), pidx, seeds), policy='fused')
-    assert torch.equal(out['cost'], ra_['cost']) and torch.equal(out['return'], ra_['return'])
+    for route in ('fused', 'resident'):                # 'resident' (the default) is the same episode in a single launch
+        out = agent.rollout_batch(BatchedPBO_Env(ps, RLEPSO_Optimizer(cfg), pidx, seeds), policy=route)
+        assert torch.equal(out['cost'], ra_['cost']) and torch.equal(out['return'], ra_['return']) and torch.equal(out['fes'], ra_['fes']), route
     env_a.close(); env_b.close()
+
+
+def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None):
+    """One resident launch per chunk (mbx_rlepso_rollout) against one mbx_rlepso_act_step launch per generation on a twin batch:
+    whole state blocks, trajectories and result tables must agree bit for bit."""
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    cfg = get_config(['--problem', 'bbob', '--dim', str(dim), '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    agent = RLEPSO_Agent(cfg).load_exported_weights(load('rlepso_policy.npz')).to('cuda')
+    actor = agent.actor
+    h1, h2 = actor.hidden_sizes()
+    net = (actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+    ps = [problems(suite_name, dim)[f] for f in fids]
+    s = Suite(ps)
+    maxfes = maxfes or 2000 * dim
+    pidx, seeds = np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) * 104729 + 11
+    a = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50)
+    b = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50)
+    table = a.policy_table(*net)
+    a.reset(); b.reset()
+    for n in chunks:
+        st, rw, dn, traj = a.rlepso_rollout(table, n, trajectory=True)
+        st, rw, dn = st.clone(), rw.clone(), dn.clone()
+        rsum = torch.zeros(B, dtype=torch.float64, device='cuda')
+        for g in range(n):
+            live = (b.done == 0).clone()
+            sb, rb, db, acts = b.act_step(table, want_actions=True)
+            assert torch.equal(traj['state'][g], sb[:, 0]) and torch.equal(traj['reward'][g], rb) and torch.equal(traj['done'][g], db), g
+            assert torch.equal(traj['actions'][g][live], acts[live]), g
+            rsum += rb
+        assert torch.equal(st[:, 0], sb[:, 0]) and torch.equal(dn, db) and torch.equal(rw, rsum)
+        torch.cuda.synchronize()
+        for k in range(0, B, max(1, B // 16)):
+            sa_, sb_ = a.read_state(k), b.read_state(k)
+            assert np.array_equal(sa_, sb_, equal_nan=True), (k, np.flatnonzero(sa_ != sb_)[:8])
+    ra, rb_ = a.results(), b.results()
+    for key in ra:
+        assert torch.equal(ra[key], rb_[key]), key
+    out = {'steps': ra['steps'].cpu().numpy(), 'fes': ra['fes'].cpu().numpy()}
+    a.close(); b.close()
+    return out
+
+
+def test_resident_rollout_equals_one_launch_per_generation():
+    """mbx_rlepso_rollout (state on chip across the generations of a launch) == mbx_rlepso_act_step per generation, bit for bit, over
+    whole episodes in uneven chunks: early stops inside a launch, launches that start with finished instances, re-initialisations."""
+    r = _rollout_case('bbob', 10, (1, 3, 5, 16, 21, 24), 100, 96, (1, 7, 60, 3, 140))
+    assert (r['steps'] < 199).any() and (r['fes'] >= 20000).any() and (r['fes'] % 100 != 0).any()      # re-initialisations bill odd FEs
+    r = _rollout_case('bbob-noisy', 10, (101, 105, 115, 122, 128, 130), 100, 60, (25, 180))
+    assert (r['fes'] >= 20000).any()
+
+
+def test_resident_rollout_config5_geometry_and_host_loop_route(monkeypatch):
+    """The 1024-thread instantiation (NP 128 / D 40) of the resident kernel, and the one-launch-per-generation route other geometries
+    take behind the same entry point (NP 60 / D 10 here, and MBX_ROLLOUT_PER_GENERATION=1)."""
+    ps40 = (1, 8, 15, 21)
+    _rollout_case('bbob', 40, ps40, 128, 8, (2, 5), maxfes=80000)
+    _rollout_case('bbob', 10, (1, 16), 60, 8, (3, 4))
+    monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')
+    _rollout_case('bbob', 10, (1, 21), 100, 8, (5, 2))
 
 
 def test_config5_shape_np128_dim40_mixed_suites():

@@ -25,9 +25,17 @@ out = {'command': 'python bench.py --steps 20 --warmup 2 --no-cpu-baseline under
        'unit': 'FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3', 'kernels': {}}
 for k, cs in sorted(vals.items()):
     out['kernels'][k] = {c: {'dispatches': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v)} for c, v in sorted(cs.items())}
-step = out['kernels'].get('mbx::k_rlepso_step', {})
+# The dominant kernel: the resident rollout kernel (bench.py's default route, one dispatch = the --steps generations of the timed window;
+# the shorter warm-up dispatch is left out by taking each counter's maximum over the dispatches) or, with --policy fused, k_rlepso_step.
+GENS = int(os.environ.get('PMC_GENS', '20'))
+INST = int(os.environ.get('PMC_INSTANCES', '4096'))
+kernel = 'mbx::k_rlepso_run' if 'mbx::k_rlepso_run' in out['kernels'] else 'mbx::k_rlepso_step'
+step = out['kernels'].get(kernel, {})
+if kernel == 'mbx::k_rlepso_run':
+    step = {c: dict(v, mean=v['max']) for c, v in step.items()}
 if 'FETCH_SIZE' in step and 'WRITE_SIZE' in step:
     out['calibration'] = {
+        'kernel': kernel, 'env_steps_per_launch': INST * (GENS if kernel == 'mbx::k_rlepso_run' else 1),
         'note': 'PMC passes ran generations 3..22 of an episode, i.e. every instance live.  Calibration (profiles/r01a_*): '
                 'k_rlepso_reset writes 26.5 KB x 4096 = 108.6 MB and reads almost nothing: WRITE_SIZE reported 106.7 MB => 1:1 for '
                 'these 8-byte coalesced stores; k_rlepso_step reads the same 108.6 MB: FETCH_SIZE reported 55.0 MB => the gfx950 x2 '
