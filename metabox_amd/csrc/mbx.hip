@@ -73,7 +73,7 @@ struct mbx_batch {
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
     int fixed_geometry = 0;      // compile-time-geometry instantiation of the generation kernel for the BASELINE.json configs: 1 = RLEPSO NP 100 / D 10 /
-                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10; 0 = geometry read from the batch
+                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10, 6 = LDE NP 100 / D 30 (config 3 as written); 0 = geometry read from the batch
 };
 
 // per-algorithm geometry
@@ -92,7 +92,7 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.state_doubles = MBX_LDE_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
         g.sc_off = MBX_LDE_ST_SCALARS(c.np, c.dim);
         g.tape_stride = MBX_LDE_TAPE_STRIDE(c.np, c.dim);
-        g.lds_doubles = lde_lds_doubles(c.np, c.dim);
+        g.lds_doubles = lde_lds_doubles(c.np, c.dim, lde_maps_in_lds(c.np, c.dim) || (getenv("MBX_GENERIC_GEOMETRY") && getenv("MBX_GENERIC_GEOMETRY")[0] == '1'));
         g.state_dim = c.np + 2 * MBX_LDE_BINS; g.action_dim = 2 * c.np;
     } else if (c.algo == MBX_ALGO_DEDDQN) {
         g.state_doubles = MBX_DQ_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
@@ -438,6 +438,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         }
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
+        if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 100 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 6;
         if (cfg->algo == MBX_ALGO_DEDDQN && cfg->np == 100 && cfg->dim == 12 && !(g && g[0] == '1')) b->fixed_geometry = 4;
         if (cfg->algo == MBX_ALGO_GLEET && cfg->np == 100 && cfg->dim == 10 && !(g && g[0] == '1')) b->fixed_geometry = 5;
     }
@@ -479,6 +480,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step<>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -596,7 +599,9 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
         hipLaunchKernelGGL(k_gleet_reset, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
-        if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
+        if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 6)
+            hipLaunchKernelGGL((k_lde_reset<512, 100, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        else if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
             hipLaunchKernelGGL(k_lde_reset<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
         else if (b->cfg.algo == MBX_ALGO_LDE)
             hipLaunchKernelGGL(k_lde_reset<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
@@ -645,6 +650,9 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 3)
             hipLaunchKernelGGL((k_lde_step<512, 50, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+                               (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
+        else if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 6)
+            hipLaunchKernelGGL((k_lde_step<512, 100, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
             hipLaunchKernelGGL(k_lde_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),

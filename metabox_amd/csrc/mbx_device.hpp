@@ -241,12 +241,18 @@ struct EvalLds {
 #endif
 // (only small dimensions are handed down: with D = 30 / 40 the fully unrolled D-loops of the evaluator spill registers)
 constexpr int eval_dc(int dc) { return dc <= MBX_EVAL_DC_MAX ? dc : 0; }
-template <int DC = 0>
+// MD: the dimension handed to the scalar-operand matvec (matvec_rows_scalar) -- the large compile-time dimensions; 0 = LDS tile route.
+#ifndef MBX_EVAL_MD_MIN
+#define MBX_EVAL_MD_MIN 16
+#endif
+constexpr int eval_md(int dc) { return dc >= MBX_EVAL_MD_MIN ? dc : 0; }
+// MAPS = false: the kernel's matvec reads the maps from global memory (MD > 0), nothing to stage for them
+template <int DC = 0, bool MAPS = true>
 __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds& L)
 {
     const int D = DC ? DC : P.dim;
     const FastDiv fd(D);
-    for (int t = threadIdx.x; t < D * D; t += MBX_NT) {
+    for (int t = threadIdx.x; MAPS && t < D * D; t += MBX_NT) {
         const int d = fd.div(t), k = t - d * D;
         if (P.m1) L.M1T[k * D + d] = P.m1[t];
         if (P.m2) L.M2T[k * D + d] = P.m2[t];
@@ -304,6 +310,42 @@ __device__ __forceinline__ void matvec_rows_impl(const double* MT, const double*
 }
 __device__ __forceinline__ void matvec_rows(const double* MT, const double* In, int n, int D, double* Out) { matvec_rows_impl<false>(MT, In, nullptr, n, D, Out); }
 __device__ __forceinline__ void matvec_rows_shifted(const double* MT, const double* In, const double* sub, int n, int D, double* Out) { matvec_rows_impl<true>(MT, In, sub, n, D, Out); }
+
+// The same product for a compile-time dimension MD >= 16, organised for the large-D geometries (config 3: D = 30, config 5: D = 40) whose
+// tile loop above is LDS-bandwidth bound (48 bytes of LDS per 4 multiply-adds at 128 B/clk per CU: 12.8 k cycles per map at NP = 128, D = 40
+// against 6.4 k of VALU issue):  lane = row, the row's MD values live in registers, a wave owns a block of consecutive outputs d of one
+// 64-row group, and M[d][k] -- wave-uniform -- is read straight from the problem's row-major map in global memory through the constant
+// address space, i.e. as scalar loads into SGPRs that v_mul_f64 takes as an operand.  No LDS read in the inner loop, no LDS copy of the
+// maps at all.  Each output keeps its own k-ascending sum of separate multiplies and adds: bit-identical to matvec_rows_impl.
+template <int MD, bool SUB>
+__device__ __forceinline__ void matvec_rows_scalar(const double* __restrict__ Mg, const double* In, const double* sub, int n, double* Out)
+{
+    typedef const double __attribute__((address_space(4)))* kptr;
+    const kptr M = (kptr)Mg;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+    const int units = ((n + 63) >> 6) * MD;                      // unit u = (row group u / MD, output u % MD)
+    const int per = (units + nw - 1) / nw;
+    const int u0 = wave * per, u1 = u0 + per < units ? u0 + per : units;
+    double y[MD];
+    int loaded = -1;
+    for (int u = u0; u < u1; ++u) {
+        const int g = u / MD, d = u - g * MD;
+        const int i = g * 64 + lane;
+        if (g != loaded) {
+            loaded = g;
+            if (i < n) {
+#pragma unroll
+                for (int k = 0; k < MD; ++k) { const double v = In[i * MD + k]; y[k] = SUB ? v - sub[k] : v; }
+            }
+        }
+        const kptr row = M + d * MD;
+        double acc = 0.;
+#pragma unroll
+        for (int k = 0; k < MD; ++k) acc += row[k] * y[k];
+        if (i < n) Out[i * MD + d] = acc;
+    }
+}
 
 // sum of v over the block (all threads call; result to every thread).  red: >= 16 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* red)
@@ -385,7 +427,7 @@ __device__ __forceinline__ double row_post(const DevProblem& P, const RowPost& r
     return isnan(P.optimum) ? f : f - P.optimum;
 }
 
-template <int DC = 0>
+template <int DC = 0, int MD = 0>
 __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const RowPost* post = nullptr)
 {
     if (P.kind == MBX_KIND_PROTEIN) {
@@ -411,8 +453,13 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
     // Barriers only where a phase exists for this function (the kind is workgroup-uniform, so every thread takes the same path).
     const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
     if (first_map) {
-        if (kind == 21 || kind == 22) matvec_rows(M1T, X, n, D, Z);
-        else matvec_rows_shifted(M1T, X, dsh, n, D, Z);
+        if constexpr (MD > 0) {
+            if (kind == 21 || kind == 22) matvec_rows_scalar<MD, false>(P.m1, X, nullptr, n, Z);
+            else matvec_rows_scalar<MD, true>(P.m1, X, dsh, n, Z);
+        } else {
+            if (kind == 21 || kind == 22) matvec_rows(M1T, X, n, D, Z);
+            else matvec_rows_shifted(M1T, X, dsh, n, D, Z);
+        }
         __syncthreads();
     }
 
@@ -567,13 +614,13 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
     if (kind == 7) {
         for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
-        matvec_rows(M2T, T, n, D, Z);
+        if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 12 || kind == 24) {
-        matvec_rows(M1T, T, n, D, Z);
+        if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
-        matvec_rows(M2T, T, n, D, Z);
+        if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     }
 
@@ -732,7 +779,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
 // cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
 // rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
 // (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
-template <int DC = 0>
+template <int DC = 0, int MD = 0>
 __device__ __forceinline__ void population_costs(const DevProblem& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
@@ -741,7 +788,7 @@ __device__ __forceinline__ void population_costs(const DevProblem& P, const Eval
     for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, post, i, L.X[i * P.dim] * L.X[i * P.dim] + P.bias);
     __syncthreads();
 #else
-    eval_rows<DC>(P, L, n, &post);
+    eval_rows<DC, MD>(P, L, n, &post);
 #endif
 }
 

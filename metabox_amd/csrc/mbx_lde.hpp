@@ -17,17 +17,21 @@ struct LdeLds {
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
 
-__host__ __device__ inline int64_t lde_lds_doubles(int NP, int D)
+// BASELINE config 3 as written (pop = 100 at D = 30): the kernels of this geometry read the two D x D maps from global memory through scalar
+// loads (matvec_rows_scalar) and keep no copy of them in LDS: 90.8 -> 76.4 KB per workgroup, i.e. TWO resident 512-thread workgroups per CU.
+__host__ __device__ constexpr bool lde_maps_in_lds(int NP, int D) { return !(NP == 100 && D == 30); }
+
+__host__ __device__ inline int64_t lde_lds_doubles(int NP, int D, bool maps = true)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = maps ? align2((int64_t)D * D) : 0,
                   P = align2(NP), PI = align2((P + 1) / 2);
     const int64_t TS = eval_t_doubles(NP, D), PT = NE > TS ? NE : TS;     // parents and the evaluator's scratch T share storage
     return NE + PT + SC + 2 * DD + 4 * align2(D) + 2 * P + 16 + 8 + 4 * PI + 8;      // SF and CR live in Z (SC >= 512 >= 2 P)
 }
 
-__device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D)
+__device__ __forceinline__ LdeLds lde_carve(double* base, int NP, int D, bool maps = true)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = align2(NE > 2 * kThreads ? NE : 2 * kThreads), DD = maps ? align2((int64_t)D * D) : 0,
                   P = align2(NP), PI = align2((P + 1) / 2);
     LdeLds L;
     double* p = base;
@@ -122,14 +126,16 @@ __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, do
 }
 
 // ------------------------------------------------------------------------------------------------ reset
-template <int THREADS>
+template <int THREADS, int NPC = 0, int DC = 0>
 __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
-    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    const int NP = NPC ? NPC : bp.NP, D = DC ? DC : bp.D, NE = NP * D;
+    constexpr bool MAPS = lde_maps_in_lds(NPC, DC);
+    constexpr int MD = MAPS ? 0 : DC;
     const DevProblem P = bp.problems[bp.problem_idx[b]];
-    const LdeLds L = lde_carve(smem, NP, D);
+    const LdeLds L = lde_carve(smem, NP, D, MAPS);
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
     const uint64_t seed = bp.seeds[b];
     const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, (uint32_t)episode};
     const double lb = P.lb, ub = P.ub;
-    stage_problem(P, L.eval());
+    stage_problem<0, MAPS>(P, L.eval());
     for (int e = tid; e < NE; e += MBX_NT) {                     // pop = lb + U * (ub - lb)   (:65-71,133)
         double u;
         if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
         L.X[e] = x;
     }
     __syncthreads();
-    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    population_costs<0, MD>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
     for (int e = tid; e < NE; e += MBX_NT) L.P[e] = L.X[e];      // T is free again: the population moves into P for the sort
     for (int i = tid; i < NP; i += MBX_NT) L.FIT[i] = L.NC[i];
     if (tid < 8) { L.HS[tid] = tid < MBX_LDE_BINS ? (double)NP / MBX_LDE_BINS : 0.; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
@@ -164,8 +170,9 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
 // Six waves per SIMD (80 VGPRs): at NP = 50, D = 30 the 512-thread workgroup needs 53.2 KB of LDS, so three of them share a CU (24 waves).
 // The generic kernel fits in 72 VGPRs; the compile-time-geometry instantiation spills (55 VGPRs) and is still the faster one
 // (all 30 noisy functions, 16 384 instances: 792 us at two resident workgroups -> 627 us at three).
+// (pop = 100 / D = 30: two resident workgroups = four waves per SIMD, 128 VGPRs: room for the register-resident rows of matvec_rows_scalar)
 #ifndef MBX_LDE_WAVES
-#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(6)))
+#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(lde_maps_in_lds(NPC, DC) ? 6 : 4)))
 #endif
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int THREADS, int NPC = 0, int DC = 0>
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     }
     const DevProblem P = bp.problems[bp.problem_idx[b]];
     MBX_PHASE_BEGIN
-    const LdeLds L = lde_carve(smem, NP, D);
+    constexpr bool MAPS = lde_maps_in_lds(NPC, DC);
+    constexpr int MD = MAPS ? 0 : DC;
+    const LdeLds L = lde_carve(smem, NP, D, MAPS);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const float* act = actions + (int64_t)b * (2 * NP);
     const int gen = (int)sc[MBX_SC_GEN] + 1;
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     for (int e = tid; e < NE; e += MBX_NT) L.P[e] = gPop[e];
     for (int i = tid; i < NP; i += MBX_NT) L.FIT[i] = S[MBX_LDE_ST_FIT(NP, D) + i];
     if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
-    stage_problem<eval_dc(DC)>(P, L.eval());
+    stage_problem<eval_dc(DC), MAPS>(P, L.eval());
     // p-best bound (:101-105): p = max(0, (P_MIN - P_INI) fes/maxFEs + P_INI), P_MIN = 2/NP, P_INI = 1
     const double p_rate = (2. / NP - 1) * fes / bp.max_fes + 1;
     const int bound = (int)ceil(NP * fmax(0., p_rate));
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     }
     __syncthreads();
     MBX_PHASE(2);                                                 // mutation + crossover
-    population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs<eval_dc(DC), MD>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
     MBX_PHASE(3);                                                 // evaluation
 

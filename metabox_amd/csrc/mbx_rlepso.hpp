@@ -462,7 +462,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
-    stage_problem<eval_dc(DC)>(P, L.eval());
+    stage_problem<eval_dc(DC), eval_md(DC) == 0>(P, L.eval());
     // __get_coe (:112-132): float32 arithmetic (numpy >= 2 keeps float32 for scalar*python-float), group g
     // reads actions[g*n_group : g*n_group+7]
     auto get_coe = [&](const float* a) {
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
     MBX_PHASE(3);                                                 // move (draws, exemplars, FDR scan, velocity)
 
     // ---- evaluate, update pbest/gbest and stagnation counters (:198-233)
-    population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs<eval_dc(DC), eval_md(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE0(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     MBX_PHASE(4);                                                 // evaluation
     fes += NP;
     rl_commit(L, NP, D, true, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         }
         __syncthreads();
         // the whole population is re-evaluated but only the re-initialised particles are billed (:141-143)
-        population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+        population_costs<eval_dc(DC), eval_md(DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
         fes += n_reinit;
         rl_commit(L, NP, D, false, gbest, gbest_idx, S + MBX_RLEPSO_ST_PBPOS(NP, D), S + MBX_RLEPSO_ST_CCOST(NP, D));
     }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         cc = S[MBX_RLEPSO_ST_CCOST(NP, D) + tid];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
-    stage_problem<eval_dc(DC)>(P, L.eval());
+    stage_problem<eval_dc(DC), eval_md(DC) == 0>(P, L.eval());
     constexpr int per_group = NP / G;
     const FastDiv fg(per_group), fh(HD);
     int* ORDER = L.IMPR;          // free until the first commit of a generation
@@ -815,12 +815,16 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
                 const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
                 const double fi = L.PBC[i];
                 int nle = 0, nless = 0;
+#ifndef MBX_ABLATE_RANK
 #pragma unroll 4
                 for (int j = j0; j < j1; ++j) {
                     const double fj = L.PBC[j];
                     nless += fj < fi;
                     nle += fj <= fi;
                 }
+#else
+                if (part == 0) { nle = i + 1; nless = i; }
+#endif
                 atomicAdd(&RANK[i], nle); atomicAdd(&NLESS[i], nless);
             }
         }
@@ -846,6 +850,9 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         }
         __syncthreads();
         // ---- FDR exemplars -> KB (see k_rlepso_step)
+#ifdef MBX_ABLATE_FDR
+        for (int e = tid; e < NP * D; e += THREADS) L.KB[e] = 0;
+#else
         for (int base = 0, pass = 0; base < NI; base += THREADS, ++pass) {
             const int lim = base + THREADS < NI ? base + THREADS : NI;
             const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
@@ -856,6 +863,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
                 L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
             }
         }
+#endif
         __syncthreads();
         // ---- velocity / position update (:179-195): new position -> X, new velocity -> register
         {
@@ -873,7 +881,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         }
         __syncthreads();
         // ---- evaluate, update pbest / gbest and the stagnation counters (:198-233)
-        population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+        population_costs<eval_dc(DC), eval_md(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
         fes += NP;
         commit(true, tid);
         // ---- re-initialisation (:238-239, 134-168)
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
                 }
             }
             __syncthreads();
-            population_costs<eval_dc(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+            population_costs<eval_dc(DC), eval_md(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
             fes += n_reinit;
             commit(false, tid);
         }

@@ -136,8 +136,9 @@ def test_lde_large_batch_properties(NP):
     def run(sel):
         b = Batch(s, ALGO_LDE, pidx[sel], seeds[sel], NP, 60000, 1200, 50)
         info = b.launch_info()
-        assert info['threads'] == 512 and info['fixed_geometry'] == (3 if NP == 50 else 0), info
-        assert info['lds_bytes'] == {50: 53248, 100: 90816}[NP], info      # three workgroups per CU at NP = 50, one at NP = 100
+        assert info['threads'] == 512 and info['fixed_geometry'] == (3 if NP == 50 else 6), info
+        # three workgroups per CU at NP = 50; two at NP = 100 (the maps stay in global memory: 90 816 B with them)
+        assert info['lds_bytes'] == {50: 53248, 100: 76416}[NP] and 2 * info['lds_bytes'] <= 160 * 1024, info
         assert b.state_dim == NP + 10 and b.action_dim == 2 * NP
         b.reset()
         for _ in range(6):
@@ -198,9 +199,11 @@ def test_lde_end_to_end_statistics_match_the_reference():
             assert np.all(fes[k] == 20000)
 
 
-def test_lde_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch):
-    """BASELINE config 3 (NP = 50, D = 30) runs k_lde_step with the geometry fixed at compile time; MBX_GENERIC_GEOMETRY=1 keeps
-    the run-time-geometry kernel.  Every state word must be identical after 40 generations on the 30 noisy functions."""
+@pytest.mark.parametrize('NP', [50, 100])
+def test_lde_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch, NP):
+    """BASELINE config 3 (D = 30; NP = 50 as in the reference, NP = 100 as written) runs k_lde_step with the geometry fixed at compile time --
+    at NP = 100 also with the scalar-operand matvec (maps read from global memory instead of LDS); MBX_GENERIC_GEOMETRY=1 keeps the
+    run-time-geometry kernel.  Every state word must be identical after 40 generations on the 30 noisy functions."""
     from metabox_amd.suite import Batch
     from metabox_amd._abi import ALGO_LDE
     s, ids = _suite('bbob-noisy', 30)
