@@ -298,12 +298,11 @@ def other_configs(budget_s=60.0):
             b.reset()
 
             def run5(n, b=b, table=table):
-                for _ in range(n):
-                    b.act_step(table)
+                b.rlepso_rollout(table, n)                 # n generations in ONE resident launch (k_rlepso_run<1024, 128, 40, 5>)
             run5(2)
             dt = _bracket(run5, 8)
             S5 = (3 * NP5 * D5 + 3 * NP5 + D5 + 1) * 8 + 16
-            entry('config 5: RLEPSO mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances (one GPU of eight), policy fused', B, dt,
+            entry('config 5: RLEPSO mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances (one GPU of eight), mbx_rlepso_rollout (8 generations per launch)', B, dt,
                   2 * S5 + 4 * 35 + (D5 * D5 + D5 + 2) * 8 + 13, {'launch_info': b.launch_info()})
             b.close()
     return out

@@ -142,6 +142,17 @@ __device__ __forceinline__ double apply_noise(const DevProblem& P, double ftrue,
     return fu >= 1e-8 ? fn + P.optimum + 1.01 * 1e-8 : ftrue;
 }
 
+// threadIdx.x behind an empty volatile asm: the block-cooperative helpers below take their thread index through this, so that nothing
+// derived from it looks loop-invariant to the compiler.  k_rlepso_run calls them once per generation inside its generation loop; with a
+// plain threadIdx.x all their index arithmetic was hoisted out of that loop and spilled (96 - 208 B of scratch per thread, re-read every
+// generation: 37 KB of HBM traffic per env-step for a kernel whose state never leaves the chip).  In the one-generation kernels it is a no-op.
+__device__ __forceinline__ int opaque_tid()
+{
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------ reductions
 // lexicographic (value, index) minimum across a wave: smallest value, lowest index on ties (np.argmin)
 __device__ __forceinline__ void wave_argmin(double& v, int& i)
@@ -157,7 +168,7 @@ __device__ __forceinline__ void wave_argmin(double& v, int& i)
 // argmin over a[0..n) in LDS (first index on ties).  All threads call; result broadcast through red[0..1].
 __device__ __forceinline__ void block_argmin(const double* a, int n, double* red, double& vmin, int& imin)
 {
-    const int tid = threadIdx.x;
+    const int tid = opaque_tid();
     if (tid < 64) {
         double v = INFINITY; int idx = 0x7fffffff;
         for (int j = tid; j < n; j += 64) {
@@ -271,13 +282,14 @@ __device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds
 template <bool SUB>
 __device__ __forceinline__ void matvec_rows_impl(const double* MT, const double* In, const double* sub, int n, int D, double* Out)
 {
+    const int tid0 = opaque_tid();
     if ((D & 1) == 0) {
         // Register tile of 2 rows x 2 dimensions per thread: the plain loop below reads 16 bytes of LDS per multiply-add (M[d][k] and
         // In[i][k]) and is LDS-bandwidth bound (128 B/clk per CU feed 8 MAC/clk, the four SIMDs could issue 32); the tile reads one
         // 16-byte pair of M and two row values per four multiply-adds, 8 bytes each.  Every output keeps its own k-ascending sum.
         const int HD = D >> 1, tiles = ((n + 1) >> 1) * HD;
         const FastDiv fh(HD);
-        for (int t = threadIdx.x; t < tiles; t += MBX_NT) {
+        for (int t = tid0; t < tiles; t += MBX_NT) {
             const int rp = fh.div(t), d = 2 * (t - rp * HD), i0 = 2 * rp;
             const bool two = i0 + 1 < n;
             const double* r0 = In + i0 * D;
@@ -298,7 +310,7 @@ __device__ __forceinline__ void matvec_rows_impl(const double* MT, const double*
     }
     const int NE = n * D;
     const FastDiv fd(D);
-    for (int e = threadIdx.x; e < NE; e += MBX_NT) {
+    for (int e = tid0; e < NE; e += MBX_NT) {
         const int i = fd.div(e), d = e - i * D;
         const double* row = In + i * D;
         const double* col = MT + d;
@@ -322,8 +334,8 @@ __device__ __forceinline__ void matvec_rows_scalar(const double* __restrict__ Mg
 {
     typedef const double __attribute__((address_space(4)))* kptr;
     const kptr M = (kptr)Mg;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+    const int tid0 = opaque_tid(), lane = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
     const int units = ((n + 63) >> 6) * MD;                      // unit u = (row group u / MD, output u % MD)
     const int per = (units + nw - 1) / nw;
     const int u0 = wave * per, u1 = u0 + per < units ? u0 + per : units;
@@ -435,7 +447,7 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
         if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
         return;
     }
-    const int D = DC ? DC : P.dim, NE = n * D, kind = P.kind, tid = threadIdx.x;
+    const int D = DC ? DC : P.dim, NE = n * D, kind = P.kind, tid = opaque_tid();
     const double ub = P.ub, bias = P.bias;
     const double* X = L.X;
     double* Z = L.Z;
