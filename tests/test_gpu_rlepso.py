@@ -374,6 +374,44 @@ def test_resident_rollout_equals_one_launch_per_generation():
     assert (r['fes'] >= 20000).any()
 
 
+@pytest.mark.parametrize('suite_name', ['bbob', 'bbob-noisy'])
+def test_resident_rollout_matches_the_oracle(env, suite_name):
+    """The resident kernel against the C oracle directly (not through k_rlepso_step): 12 generations in ONE launch; the oracle, on the same
+    Philox seeds, replays the actions the kernel drew (trajectory record) and must see the same state / reward / done after every generation
+    and the same population at the end.  (The long-horizon proof -- exact up to proven near-ties -- is test_philox_parity_with_oracle on
+    k_rlepso_step, to which test_resident_rollout_equals_one_launch_per_generation ties this kernel bit for bit; in the first dozen
+    generations the swarm is wide and no comparison is anywhere near a tie.)"""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_RLEPSO
+    s, ids = env[suite_name]
+    B, G = len(ids), 12
+    seeds = np.arange(B, dtype=np.uint64) * 6151 + 17
+    batch = Batch(s, ALGO_RLEPSO, np.arange(B), seeds, NP, MAXFES, LOGI, NLOG)
+    table = torch.rand(MAXFES + 2 * NP + 1, 2, 35, generator=torch.Generator().manual_seed(4)).cuda()
+    table[:, 1] = 0.05 + 0.3 * table[:, 1]                                      # sigma
+    table = table.contiguous()
+    batch.reset()
+    _, _, _, traj = batch.rlepso_rollout(table, G, trajectory=True)
+    torch.cuda.synchronize()
+    acts, st, rw, dn = (traj[k].cpu().numpy() for k in ('actions', 'state', 'reward', 'done'))
+    cfg = oracle.make_cfg(1, NP, D, MAXFES, LOGI, NLOG)
+    for b in range(B):
+        p = s.problems[b]
+        o = oracle.RlepsoOracle(p.desc(), p.bias, cfg, seed=int(seeds[b]))
+        o.reset()
+        for g in range(G):
+            so, ro, do = o.step(acts[g, b])
+            assert so == st[g, b] and ro == rw[g, b] and bool(do) == bool(dn[g, b]), (ids[b], g)
+            assert not do, ids[b]
+        want = oracle.split_rlepso_state(o.state(), NP, D, NLOG)
+        got = oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG)
+        assert close(got['scalars'][oracle.SC_GBEST], want['scalars'][oracle.SC_GBEST]), ids[b]
+        assert got['scalars'][oracle.SC_FES] == want['scalars'][oracle.SC_FES], ids[b]
+        assert close(got['pbest'], want['pbest']) and np.abs(got['pos'] - want['pos']).max() <= 1e-9, ids[b]
+        assert np.array_equal(got['pni'], want['pni']), ids[b]
+    batch.close()
+
+
 def test_resident_rollout_config5_geometry_and_host_loop_route(monkeypatch):
     """The 1024-thread instantiation (NP 128 / D 40) of the resident kernel, and the one-launch-per-generation route other geometries
     take behind the same entry point (NP 60 / D 10 here, and MBX_ROLLOUT_PER_GENERATION=1)."""

@@ -842,7 +842,7 @@ def gen_mte():
 # somewhere (tests/helpers.py: prove_tie shows at the first such generation that the reference's own margin is smaller than the deviation
 # between the two implementations' operands).  Episodes with c_cost: those where the C oracle diverges (found here by running it next to
 # the reference) plus EXTRA_TIE_CASES (episodes where only the HIP kernel diverges; the GPU test names them when they are missing).
-EXTRA_TIE_CASES = set()
+EXTRA_TIE_CASES = {'bbob/15/2/actor'}     # round 2: the single-polynomial sin / cos (<= 2 ulp) moves this episode's generation-195 near-tie on the device
 
 
 def _ties_worker(case):
