@@ -273,8 +273,23 @@ class RLEPSO_Agent(Basic_Agent):
         return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'],
                 'cost_len': res['cost_len']}
 
+    @torch.no_grad()
+    def collect_segment_resident(self, env, state, alive, n_step):
+        """The n_step transitions of one PPO segment (rlepso_agent.py:143-190) from ONE ``mbx_rlepso_rollout`` launch with the CURRENT
+        weights: -> (S [T, B, 1] float32 state before each generation, A [T, B, 35] float32 actions the kernel drew, M [T, B] bool alive
+        before each generation, R [T, B] float64 rewards, state after the segment [B, 1] float32, alive after the segment [B])."""
+        actor, batch = self.__actor, env.batch
+        h1, h2 = actor.hidden_sizes()
+        table = batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+        _, _, _, traj = batch.rlepso_rollout(table, n_step, trajectory=True)
+        after = traj['state'].to(torch.float32)                                   # state after generation t
+        done_after = traj['done'] != 0                                            # absorbing: stays 1 once the instance terminated
+        S = torch.cat([state[None], after[:-1, :, None]], 0)
+        M = torch.cat([alive[None], alive[None] & ~done_after[:-1]], 0)
+        return S, traj['actions'], M, traj['reward'], after[-1][:, None].clone(), alive & ~done_after[-1]
+
     # ---- training: PPO (reference rlepso_agent.py:113-292), one implementation for B >= 1 -------------------------------------
-    def train_batch(self, env, max_updates=None, forced_actions=None):
+    def train_batch(self, env, max_updates=None, forced_actions=None, collect='auto'):
         """PPO over a lock-step batch of environments: n_step = 10 segments, K_epochs = 3 optimizer steps per segment, clipped
         surrogate + clipped value loss, n-step returns bootstrapped from the critic at the segment's last state (rlepso_agent.py:140-276).
         Every quantity carries a leading [T, B] shape and the losses average over the (step, instance) pairs that were still running;
@@ -285,6 +300,13 @@ class RLEPSO_Agent(Basic_Agent):
 
         env: BatchedPBO_Env-like (B, reset() -> [B, 1], step(actions [B, 35]) -> (state, reward, done), results()).
         forced_actions: optional [T_total, B, 35] tensor replayed instead of sampling (parity tests).
+        collect: how a segment's n_step transitions are gathered.  'step': actor forward + sampling in PyTorch and one env.step per
+                 generation (the reference's loop, rlepso_agent.py:143-190).  'resident': ONE ``mbx_rlepso_rollout`` launch per segment --
+                 the current weights' (mu, sigma) table is rebuilt (``mbx_rlepso_policy_table``), the kernel draws the actions itself
+                 (the instance's Philox stream instead of torch's generator: same distribution), keeps the state on chip for the n_step
+                 generations and hands back the per-generation records (actions, state, reward, done); log-probabilities and values are
+                 then evaluated over the whole [n_step, B] block at once.  'auto' (default): 'resident' when the environment is a
+                 BatchedPBO_Env on the GPU and no actions are forced, else 'step'.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps', 'last_losses'})."""
         from ..distributed import all_ranks_any, average_gradients
         config = self.__config
@@ -303,9 +325,24 @@ class RLEPSO_Agent(Basic_Agent):
             mu, sigma = actor.distribution(states)
             return Normal(mu, sigma).log_prob(actions).sum(-1), critic.value_head(states).squeeze(-1)
 
+        batch = getattr(env, 'batch', None)
+        if collect == 'auto':
+            collect = 'resident' if (forced_actions is None and hasattr(batch, 'rlepso_rollout') and state.is_cuda) else 'step'
+        if collect not in ('step', 'resident') or (collect == 'resident' and (forced_actions is not None or not hasattr(batch, 'rlepso_rollout'))):
+            raise ValueError("collect must be 'auto', 'step' or 'resident' (the latter needs a BatchedPBO_Env and no forced actions)")
+
         while all_ranks_any(bool(alive.any()), dev) and not exceed:
             S, A, LP, V, R, M = [], [], [], [], [], []
-            for _ in range(n_step):
+            if collect == 'resident':
+                S_blk, A_blk, M_blk, R_blk, state, alive_next = self.collect_segment_resident(env, state, alive, n_step)
+                logp_blk, val_blk = evaluate(S_blk.reshape(-1, S_blk.shape[-1]), A_blk.reshape(-1, A_blk.shape[-1]))
+                S, A, M = list(S_blk), list(A_blk), list(M_blk)
+                LP, V = list(logp_blk.view(M_blk.shape)), list(val_blk.view(M_blk.shape))
+                R = list(R_blk.to(torch.float32))
+                ret_sum += (R_blk * M_blk).sum(0)
+                alive = alive_next
+                t_all += n_step
+            for _ in range(n_step if collect == 'step' else 0):
                 if forced_actions is not None:
                     action = forced_actions[t_all].to(dev)
                 else:
