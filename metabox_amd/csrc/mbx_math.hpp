@@ -19,6 +19,21 @@ namespace fm {
 __device__ __forceinline__ double from_bits(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t to_bits(double d) { return (uint64_t)__double_as_longlong(d); }
 
+// Horner step p z + c with the 64-bit coefficient c as the SGPR-pair operand of v_fma_f64.  Written with the builtin, clang emits
+// v_mov_b32 x 2 (the literal into a VGPR pair) + v_fmac_f64 for every coefficient -- three VALU instructions per step; the coefficient
+// belongs on the scalar unit (s_mov_b32 x 2, issued beside the vector pipe), which leaves ONE VALU instruction per step.  Same fused
+// multiply-add, same rounding.
+__device__ __forceinline__ double fma_k(double p, double z, double c)
+{
+#ifdef MBX_PLAIN_HORNER
+    return __builtin_fma(p, z, c);
+#else
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+    return r;
+#endif
+}
+
 // 1 / a for normal a: hardware estimate + two Newton steps (quadratic: 2^-13 -> 2^-26 -> 2^-52)
 __device__ __forceinline__ double recip(double a)
 {
@@ -52,10 +67,10 @@ __device__ __forceinline__ double log_pos(double x)
     const double s = divide(f, 2.0 + f);
     const double z = s * s;
     double p = 2.0 / 23.0;
-    p = __builtin_fma(p, z, 2.0 / 21.0); p = __builtin_fma(p, z, 2.0 / 19.0); p = __builtin_fma(p, z, 2.0 / 17.0);
-    p = __builtin_fma(p, z, 2.0 / 15.0); p = __builtin_fma(p, z, 2.0 / 13.0); p = __builtin_fma(p, z, 2.0 / 11.0);
-    p = __builtin_fma(p, z, 2.0 / 9.0);  p = __builtin_fma(p, z, 2.0 / 7.0);  p = __builtin_fma(p, z, 2.0 / 5.0);
-    p = __builtin_fma(p, z, 2.0 / 3.0);
+    p = fma_k(p, z, 2.0 / 21.0); p = fma_k(p, z, 2.0 / 19.0); p = fma_k(p, z, 2.0 / 17.0);
+    p = fma_k(p, z, 2.0 / 15.0); p = fma_k(p, z, 2.0 / 13.0); p = fma_k(p, z, 2.0 / 11.0);
+    p = fma_k(p, z, 2.0 / 9.0);  p = fma_k(p, z, 2.0 / 7.0);  p = fma_k(p, z, 2.0 / 5.0);
+    p = fma_k(p, z, 2.0 / 3.0);
     const double dk = (double)k;
     // 2 s + s z p + k ln2: the small terms first
     const double tail = __builtin_fma(s * z, p, dk * kLn2Lo);
@@ -75,10 +90,10 @@ __device__ __forceinline__ double exp_mid(double x)
     double r = __builtin_fma(-kd, kLn2Hi, x);
     r = __builtin_fma(-kd, kLn2Lo, r);
     double p = 1.0 / 6227020800.0;
-    p = __builtin_fma(p, r, 1.0 / 479001600.0); p = __builtin_fma(p, r, 1.0 / 39916800.0); p = __builtin_fma(p, r, 1.0 / 3628800.0);
-    p = __builtin_fma(p, r, 1.0 / 362880.0);    p = __builtin_fma(p, r, 1.0 / 40320.0);    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);       p = __builtin_fma(p, r, 1.0 / 120.0);      p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);         p = __builtin_fma(p, r, 0.5);
+    p = fma_k(p, r, 1.0 / 479001600.0); p = fma_k(p, r, 1.0 / 39916800.0); p = fma_k(p, r, 1.0 / 3628800.0);
+    p = fma_k(p, r, 1.0 / 362880.0);    p = fma_k(p, r, 1.0 / 40320.0);    p = fma_k(p, r, 1.0 / 5040.0);
+    p = fma_k(p, r, 1.0 / 720.0);       p = fma_k(p, r, 1.0 / 120.0);      p = fma_k(p, r, 1.0 / 24.0);
+    p = fma_k(p, r, 1.0 / 6.0);         p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p * r, r, r);                                    // r + r^2 (1/2 + ...)
     return ldexp(1.0 + p, (int)kd);
 }
@@ -111,11 +126,11 @@ __device__ __forceinline__ double sincos_fast(double x)
     r = __builtin_fma(-md, kPio2Lo, r);
     const double z = r * r;
     double p = -1.0 / 51090942171709440000.0;                                                               // -1/21!
-    p = __builtin_fma(p, z, 1.0 / 121645100408832000.0); p = __builtin_fma(p, z, -1.0 / 355687428096000.0);    // 1/19!, -1/17!
-    p = __builtin_fma(p, z, 1.0 / 1307674368000.0);      p = __builtin_fma(p, z, -1.0 / 6227020800.0);         // 1/15!, -1/13!
-    p = __builtin_fma(p, z, 1.0 / 39916800.0);           p = __builtin_fma(p, z, -1.0 / 362880.0);             // 1/11!, -1/9!
-    p = __builtin_fma(p, z, 1.0 / 5040.0);               p = __builtin_fma(p, z, -1.0 / 120.0);                // 1/7!, -1/5!
-    p = __builtin_fma(p, z, 1.0 / 6.0);                                                                        // 1/3!
+    p = fma_k(p, z, 1.0 / 121645100408832000.0); p = fma_k(p, z, -1.0 / 355687428096000.0);    // 1/19!, -1/17!
+    p = fma_k(p, z, 1.0 / 1307674368000.0);      p = fma_k(p, z, -1.0 / 6227020800.0);         // 1/15!, -1/13!
+    p = fma_k(p, z, 1.0 / 39916800.0);           p = fma_k(p, z, -1.0 / 362880.0);             // 1/11!, -1/9!
+    p = fma_k(p, z, 1.0 / 5040.0);               p = fma_k(p, z, -1.0 / 120.0);                // 1/7!, -1/5!
+    p = fma_k(p, z, 1.0 / 6.0);                                                                // 1/3!
     const double s = __builtin_fma(-(r * z), p, r);                   // r - r^3 (1/3! - r^2/5! + ...)
     // sign: (-1)^n for the sine, (-1)^(n + 1) for the cosine -- the parity bit of n moved into the sign bit
     const uint64_t flip = (uint64_t)(((uint32_t)(int)nd + (COS ? 1u : 0u)) & 1u) << 63;
