@@ -52,6 +52,11 @@ struct DevProblem {
     const double* plogw; // Gallagher: log(w_k), precomputed at upload
 };
 
+// The same record read through the constant address space: every field access is a scalar load (s_load_dword*) of memory the compiler knows
+// to be invariant, so a long-running kernel (k_rlepso_run) keeps no copy of the 54-dword record in SGPRs -- with the by-value copy the SGPR file
+// overflowed into VGPR lanes and every spilled value came back through a v_readlane, a VALU instruction (861 of them in that kernel).
+typedef const DevProblem __attribute__((address_space(4))) ConstProblem;
+
 // Division of small non-negative integers by a loop-invariant divisor without the ~35-instruction software divide:
 // e / D == umulhi(e, floor((2^32-1)/D) + 1) for e < 2^20, D <= 256 (checked exhaustively on the host).
 struct FastDiv {
@@ -88,12 +93,19 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
 
 struct Rng {                      // per-instance stream: key = seed, counter = (index, site, gen, episode)
     uint32_t k0, k1, gen, episode;
+    // uniform_fresh: key and counter words are workgroup-uniform and the caller wants their share of the rounds recomputed at every call.
+    // Three of the four counter words and the key are uniform, so the compiler folds their part of every round into scalar constants -- per
+    // draw site and generation -- and keeps them all alive across the generation body; in k_rlepso_run they overflow the SGPR file and come
+    // back one v_readlane (a VALU instruction) at a time.  Behind an empty asm the scalar unit recomputes them where they are used.
+    bool uniform_fresh = false;
     __device__ __forceinline__ U4 draw(uint32_t idx, uint32_t site) const
     {
 #ifdef MBX_ABLATE_RNG
         return U4{idx * 2654435761u, site + 0x9E3779B9u * idx, gen ^ (idx << 7), episode + idx};   // timing experiments only
 #else
-        return philox4x32_10(idx, site, gen, episode, k0, k1);
+        uint32_t a = k0, b = k1;
+        if (uniform_fresh) asm volatile("" : "+s"(a), "+s"(b));
+        return philox4x32_10(idx, site, gen, episode, a, b);
 #endif
     }
 };
@@ -127,7 +139,8 @@ __device__ __forceinline__ void philox_noise(const Rng& rng, uint32_t row, uint3
 }
 
 // NoisyProblem.noisy for one value (bbob.py:108-146)
-__device__ __forceinline__ double apply_noise(const DevProblem& P, double ftrue, double a, double b, double c)
+template <class PT>
+__device__ __forceinline__ double apply_noise(const PT& P, double ftrue, double a, double b, double c)
 {
     if (P.noise_kind == MBX_NOISE_NONE) return ftrue;
     const double fu = ftrue - P.optimum;
@@ -258,8 +271,8 @@ constexpr int eval_dc(int dc) { return dc <= MBX_EVAL_DC_MAX ? dc : 0; }
 #endif
 constexpr int eval_md(int dc) { return dc >= MBX_EVAL_MD_MIN ? dc : 0; }
 // MAPS = false: the kernel's matvec reads the maps from global memory (MD > 0), nothing to stage for them
-template <int DC = 0, bool MAPS = true>
-__device__ __forceinline__ void stage_problem(const DevProblem& P, const EvalLds& L)
+template <int DC = 0, bool MAPS = true, class PT = DevProblem>
+__device__ __forceinline__ void stage_problem(const PT& P, const EvalLds& L)
 {
     const int D = DC ? DC : P.dim;
     const FastDiv fd(D);
@@ -378,8 +391,8 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // n^2 atom pairs are spread over the block (pair index == address in the [n,n] tables: coalesced L2 reads) and the
 // energy mean_j sum_i term_ij = (sum of all terms)/n is reduced with wave shuffles.
 // P.v0 = 1/sqrt(eigval), P.py = basis [D,3n], P.pc = coor_init [3n], P.pw = sqrt(e) | q | r tables.
-template <int DC = 0>
-__device__ void eval_rows_protein(const DevProblem& P, const EvalLds& L, int n_rows)
+template <int DC = 0, class PT = DevProblem>
+__device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
 {
     const int D = DC ? DC : P.dim, n = P.n_peaks, m3 = 3 * n, tid = threadIdx.x;
     double* COOR = L.Z;
@@ -428,7 +441,8 @@ struct RowPost {
     const Rng* rng; const double* tape_noise; uint32_t siteA, siteB; int n_total;
 };
 
-__device__ __forceinline__ double row_post(const DevProblem& P, const RowPost& rp, int i, double f)
+template <class PT>
+__device__ __forceinline__ double row_post(const PT& P, const RowPost& rp, int i, double f)
 {
     if (P.noise_kind != MBX_NOISE_NONE) {
         double a, b, c;
@@ -439,11 +453,11 @@ __device__ __forceinline__ double row_post(const DevProblem& P, const RowPost& r
     return isnan(P.optimum) ? f : f - P.optimum;
 }
 
-template <int DC = 0, int MD = 0>
-__device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const RowPost* post = nullptr)
+template <int DC = 0, int MD = 0, class PT = DevProblem>
+__device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* post = nullptr)
 {
     if (P.kind == MBX_KIND_PROTEIN) {
-        eval_rows_protein<DC>(P, L, n);
+        eval_rows_protein<DC, PT>(P, L, n);
         if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
         return;
     }
@@ -791,8 +805,8 @@ __device__ void eval_rows(const DevProblem& P, const EvalLds& L, int n, const Ro
 // cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
 // rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
 // (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
-template <int DC = 0, int MD = 0>
-__device__ __forceinline__ void population_costs(const DevProblem& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
+template <int DC = 0, int MD = 0, class PT = DevProblem>
+__device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
     const RowPost post{&rng, tape_noise, siteA, siteB, n};
@@ -800,7 +814,7 @@ __device__ __forceinline__ void population_costs(const DevProblem& P, const Eval
     for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, post, i, L.X[i * P.dim] * L.X[i * P.dim] + P.bias);
     __syncthreads();
 #else
-    eval_rows<DC, MD>(P, L, n, &post);
+    eval_rows<DC, MD, PT>(P, L, n, &post);
 #endif
 }
 

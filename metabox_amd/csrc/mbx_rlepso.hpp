@@ -29,7 +29,8 @@ struct BatchParams {
 // optimizer.cost bookkeeping shared by every update() of the reference (e.g. rlepso_optimizer.py:241-261): append gbest when fes
 // reaches the next log point (one append per call at most), decide termination, and on termination overwrite the last entry if the
 // curve is already n_logpoint + 1 long, else append.  `cost` is the instance's curve in HBM; returns is_done.
-__device__ __forceinline__ bool log_and_terminate(const BatchParams& bp, const DevProblem& P, double fes, double gbest, int& log_index,
+template <class PT>
+__device__ __forceinline__ bool log_and_terminate(const BatchParams& bp, const PT& P, double fes, double gbest, int& log_index,
                                                   int& cost_len, double* __restrict__ cost)
 {
     if (fes >= (double)log_index * bp.log_interval) { log_index += 1; cost[cost_len++] = gbest; }
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         }
         return;
     }
-    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);
     const RlLds L = rl_carve(smem, NP, D);
     int gen = (int)sc[MBX_SC_GEN];
     const uint64_t seed = bp.seeds[b];
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         cc = S[MBX_RLEPSO_ST_CCOST(NP, D) + tid];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
-    stage_problem<eval_dc(DC), eval_md(DC) == 0>(P, L.eval());
+    stage_problem<eval_dc(DC), eval_md(DC) == 0, ConstProblem>(P, L.eval());
     constexpr int per_group = NP / G;
     const FastDiv fg(per_group), fh(HD);
     int* ORDER = L.IMPR;          // free until the first commit of a generation
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         gen += 1;
-        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, episode};
+        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, episode, true};
         const double pre_gbest = gbest;
         // ---- agent.act: the action of this generation from row fes of the actor table (same draws as mbx_gauss_policy)
         if (tid < A) {
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         }
         __syncthreads();
         // ---- evaluate, update pbest / gbest and the stagnation counters (:198-233)
-        population_costs<eval_dc(DC), eval_md(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+        population_costs<eval_dc(DC), eval_md(DC), ConstProblem>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
         fes += NP;
         commit(true, tid);
         // ---- re-initialisation (:238-239, 134-168)
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
                 }
             }
             __syncthreads();
-            population_costs<eval_dc(DC), eval_md(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+            population_costs<eval_dc(DC), eval_md(DC), ConstProblem>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
             fes += n_reinit;
             commit(false, tid);
         }
