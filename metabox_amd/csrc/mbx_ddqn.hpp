@@ -46,8 +46,8 @@ __device__ __forceinline__ int dq_slot(int g, int gen) { return (((g - gen) % MB
 
 // __get_state (:76-129).  cost in L.COST, records in L.REC; row(k) gives a pointer to X[k] (global, post-selection).
 // Draws r[5] for the next update (Philox counter `ctr` or tape) and stores it at gR.  All threads call.
-template <class RowFn>
-__device__ __forceinline__ void dq_features(const DevProblem& P, const DqLds& L, int NP, int D, const BatchParams& bp, const Rng& rng,
+template <class RowFn, class PT>
+__device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP, int D, const BatchParams& bp, const Rng& rng,
                                             const double* tape, RowFn row, const double* gbpos, const double* prepos, double gbest,
                                             double gworst, double cpre, int pointer, int gen, double stag, double fes, int omw_len,
                                             double* gR, double* state_out)
@@ -205,13 +205,13 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
         if (tid == 0) { if (reward_out) reward_out[b] = 0.; if (done_out) done_out[b] = 1; }
         return;
     }
-    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
     const DqLds L = dq_carve(smem, 1, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const int action = actions[b];
     const int steps = (int)sc[MBX_SC_GEN] + 1;
     const uint64_t seed = bp.seeds[b];
-    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)steps, (uint32_t)(int)sc[MBX_SC_EPISODE]};
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)steps, (uint32_t)(int)sc[MBX_SC_EPISODE], true};
     const double lb = P.lb, ub = P.ub, F = 0.5;
     double* gX = S + MBX_DQ_ST_X(NP, D);
     double* gGB = S + MBX_DQ_ST_GBPOS(NP, D);

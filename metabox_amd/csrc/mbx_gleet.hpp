@@ -135,13 +135,13 @@ __global__ __launch_bounds__(kThreads) MBX_GLEET_WAVES void k_gleet_step(BatchPa
         if (tid == 0) { if (reward_out) reward_out[b] = 0.; if (done_out) done_out[b] = 1; }
         return;
     }
-    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
     const GlLds L = gl_carve(smem, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const float* act = actions + (int64_t)b * NP;
     const int gen = (int)sc[MBX_SC_GEN] + 1;
     const uint64_t seed = bp.seeds[b];
-    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE]};
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE], true};
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
     double* gPos = S + MBX_GLEET_ST_POS(NP, D);
     double* gVel = S + MBX_GLEET_ST_VEL(NP, D);

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
         if (tid == 0) { if (reward_out) reward_out[b] = 0.; if (done_out) done_out[b] = 1; }
         return;
     }
-    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
     MBX_PHASE_BEGIN
     constexpr bool MAPS = lde_maps_in_lds(NPC, DC);
     constexpr int MD = MAPS ? 0 : DC;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     const float* act = actions + (int64_t)b * (2 * NP);
     const int gen = (int)sc[MBX_SC_GEN] + 1;
     const uint64_t seed = bp.seeds[b];
-    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE]};
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE], true};
     const double lb = P.lb, ub = P.ub;
     double fes = sc[MBX_SC_FES];
     const double hcount = sc[MBX_SC_HCOUNT];

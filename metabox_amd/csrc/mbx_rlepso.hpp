@@ -428,14 +428,14 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         return;
     }
     MBX_PHASE_BEGIN
-    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
     const RlLds L = rl_carve(smem, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const float* act = actions + (int64_t)b * (7 * G);
 
     const int gen = (int)sc[MBX_SC_GEN] + 1;
     const uint64_t seed = bp.seeds[b];
-    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE]};
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)(int)sc[MBX_SC_EPISODE], true};
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
     double gbest = sc[MBX_SC_GBEST];
     int gbest_idx = (int)sc[MBX_SC_GBEST_IDX];

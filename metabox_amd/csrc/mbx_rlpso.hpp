@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kThreads) MBX_N4_WAVES void k_rlpso_step(BatchParam
         if (tid == 0) { if (reward_out) reward_out[b] = 0.; if (done_out) done_out[b] = 1; }
         return;
     }
-    const DevProblem P = bp.problems[bp.problem_idx[b]];
+    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
     const RpLds L = rp_carve(smem, 1, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const uint64_t seed = bp.seeds[b];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kThreads) MBX_N4_WAVES void k_rlpso_step(BatchParam
     MBX_PHASE_BEGIN
     for (int it = 0; it < (MULTI ? n_steps : 1) && !done; ++it) {
         const int step = (int)L.SC[MBX_SC_GEN] + 1, j = (int)L.SC[MBX_SC_RLPSO_CUR];
-        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)episode};
+        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)episode, true};
         float action;
         if (net.w) {
             action = rp_policy(net, L, D, rng);
