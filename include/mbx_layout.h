@@ -72,10 +72,12 @@
  * r = sqrt(-2 ln(1-ua)), n0 = r cos(2 pi ub), n1 = r sin(2 pi ub).
  *
  *   site                 index        words
- *   MBX_SITE_ELEM_A      e >> 1       u53(w0,w1) = clpso_u[e] for even e, u53(w2,w3) = clpso_u[e] for odd e (one call per element pair)
+ *   MBX_SITE_ELEM_A      e >> 1       RLEPSO: ONE call per element pair carries its four element-wise uniforms, 32 bits each, u32(w) = w / 2^32:
+ *                                     u32(w0) = clpso_u[e] and u32(w2) = fdr_u[e] for the even element, u32(w1) / u32(w3) for the odd one
+ *                                     (the CLPSO mask compares against pci in [0.05, 0.5] and both act as step weights: 2^-32 resolution)
  *   MBX_SITE_TOURN       e >> 1       mulhi(w0,NP), mulhi(w1,NP) = tournament pair of the even element, mulhi(w2,NP), mulhi(w3,NP) = of the odd one;
  *                                     only consumed where !(clpso_u[e] > pci_i)
- *   MBX_SITE_ELEM_B      e >> 1       u53(w0,w1) = fdr_u[e] for even e, u53(w2,w3) = fdr_u[e] for odd e (one call per element pair)
+ *   MBX_SITE_ELEM_B      -            (RLEPSO: not drawn any more; the FDR weights ride in the ELEM_A call)
  *   MBX_SITE_PART        i            u53(w0,w1) = rand1[i];    u53(w2,w3) = rand2[i]
  *   MBX_SITE_REINIT      i            u53(w0,w1) = reinit_u[i]
  *   MBX_SITE_ELEM_R      e            u53(w0,w1) = pos_u[e];    u53(w2,w3) = vel_u[e]   (init + reinit)

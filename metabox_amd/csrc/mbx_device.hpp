@@ -91,6 +91,8 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b)
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+__device__ __forceinline__ double u32d(uint32_t a) { return (double)a * 2.3283064365386963e-10; }      // a / 2^32 in [0, 1)
+
 struct Rng {                      // per-instance stream: key = seed, counter = (index, site, gen, episode)
     uint32_t k0, k1, gen, episode;
     // uniform_fresh: key and counter words are workgroup-uniform and the caller wants their share of the rounds recomputed at every call.

@@ -280,16 +280,17 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, double 
     const int NP = c.NP, D = c.D;
     const int rk = c.RANK[i], e0 = i * D + d0, es0 = rk * D + d0;
     const double r1 = L.R1[i], r2 = L.R2[i];
+    // one Philox call carries the four element-wise uniforms of an element PAIR, 32 bits each (site ELEM_A, index e >> 1: words 0 / 2 = CLPSO
+    // uniform / FDR weight of the even element, 1 / 3 of the odd one); a two-coordinate work item starts on an even element (D even, d0 even)
     double uf[W];
+    U4 wa{0, 0, 0, 0};
     if (c.tape) {
 #pragma unroll
         for (int q = 0; q < W; ++q) uf[q] = c.tape[MBX_RLEPSO_TAPE_FDR(NP, D) + e0 + q];
     } else {
-        // one Philox call carries the FDR weights of an element PAIR (site ELEM_B, index e >> 1: words 0-1 for the even element,
-        // 2-3 for the odd one); a two-coordinate work item starts on an even element (D even, d0 even)
-        const U4 w = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_ELEM_B);
-        if (W == 2) { uf[0] = u53(w.x, w.y); uf[W - 1] = u53(w.z, w.w); }
-        else uf[0] = (e0 & 1) ? u53(w.z, w.w) : u53(w.x, w.y);
+        wa = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_ELEM_A);
+        if (W == 2) { uf[0] = u32d(wa.z); uf[W - 1] = u32d(wa.w); }
+        else uf[0] = u32d((e0 & 1) ? wa.w : wa.z);
     }
     const int g = c.fg.div(i);
     double cw = 0., c1 = 0., c2 = 0., c3 = 0., c4 = 0.;
@@ -297,14 +298,12 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, double 
     double ucs[W]; int xrs[W];
     {
         const double pci = c.bp.pci[i];
-        U4 wa{0, 0, 0, 0};
-        if (!c.tape) wa = c.rng.draw((uint32_t)e0 >> 1, MBX_SITE_ELEM_A);
         bool need = false;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             const int e = e0 + q;
             if (c.tape) ucs[q] = c.tape[MBX_RLEPSO_TAPE_CLPSO(NP, D) + e];
-            else ucs[q] = (W == 2 ? q == 1 : (e & 1)) ? u53(wa.z, wa.w) : u53(wa.x, wa.y);
+            else ucs[q] = u32d((W == 2 ? q == 1 : (e & 1)) ? wa.y : wa.x);
             xrs[q] = rk;
             need = need || !(ucs[q] > pci);
         }

@@ -477,6 +477,16 @@ def test_single_instance_batch_and_error_paths():
         Batch(s, ALGO_RLEPSO, [3], [5], NP, MAXFES, LOGI, NLOG)          # problem index out of range
     with pytest.raises(_abi.MbxError):
         Batch(s, ALGO_RLEPSO, [0], [5], 1000, MAXFES, LOGI, NLOG)        # population larger than a workgroup
+    # mbx_rlepso_rollout: argument checks (same error behaviour as mbx_rlepso_act_step)
+    table = torch.full((MAXFES + 2 * NP + 1, 2, 35), 0.3, device='cuda')
+    with pytest.raises(_abi.MbxError):
+        b.rlepso_rollout(table, 0)                                        # n_gens < 1
+    b.set_tape(torch.zeros(1, b.tape_stride, dtype=torch.float64, device='cuda'))
+    with pytest.raises(_abi.MbxError):
+        b.rlepso_rollout(table, 2)                                        # a replay tape holds one generation and no policy draws
+    b.set_tape(None)
+    st2, rw2, dn2 = b.rlepso_rollout(table, 2)
+    assert int(b.results()['steps'][0]) == 5 and abs(float(rw2[0])) in (0.0, 2.0)   # two more generations, rewards summed
     b.close()
 
 
