@@ -108,7 +108,8 @@
  * hist_sum accumulates past_histo (:139,186), scalars[MBX_SC_HCOUNT] its length.
  * Philox: MBX_SITE_LDE_PART(i): mulhi(w0,bound)=pbest_idx, w1 -> r0 over the NP-1 indices != i, w2 -> r1 over the
  * NP-2 indices not in {i,r0} (same distribution as the reference's rejection loop), mulhi(w3,D)=jrand;
- * MBX_SITE_LDE_ELEM(e): u53(w0,w1) = crossover / initial-position uniform.                                   */
+ * MBX_SITE_LDE_ELEM: reset (generation 0), index e: u53(w0,w1) = initial-position uniform;  step (generation >= 1), index e >> 2: ONE call per
+ * four consecutive elements, u32(w[e & 3]) = w / 2^32 = crossover uniform of element e (compared against the float32 rate CR_i).               */
 #define MBX_LDE_TAPE_PIDX(NP, D)   ((int64_t)0)
 #define MBX_LDE_TAPE_R0(NP, D)     ((int64_t)(NP))
 #define MBX_LDE_TAPE_R1(NP, D)     ((int64_t)2 * (NP))

@@ -239,28 +239,38 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     MBX_PHASE(1);                                                 // histogram of the parents
     // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
     const FastDiv fd(D);
-    // The parents' storage doubles as evaluator scratch; a thread's own (up to four) parent coordinates stay in registers across the
+    // The parents' storage doubles as evaluator scratch; a thread's own four parent coordinates stay in registers across the
     // evaluation, so the rows that lose the selection need no second trip to HBM (larger populations re-read them).
     const bool kept = NE <= 4 * MBX_NT;
     double keep[4] = {0., 0., 0., 0.};
-    for (int e = tid, q = 0; e < NE; e += MBX_NT, ++q) {
-        const int i = fd.div(e), d = e - i * D;
-        double u;
-        if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
-        else { const U4 w = rng.draw((uint32_t)e, MBX_SITE_LDE_ELEM); u = u53(w.x, w.y); }
-        if (d == L.JR[i]) u = 0.;
-        const double xi = L.P[e], sf = L.SF[i], om = (double)(1.f - (float)sf);      // 1 - sf in float32, like the policy's tensor
-        if (kept) { if (q == 0) keep[0] = xi; else if (q == 1) keep[1] = xi; else if (q == 2) keep[2] = xi; else keep[3] = xi; }
-        const int pidx = L.PIDX[i];
-        double m;
-        if (pidx == i) m = xi;
-        else if (pidx < i) m = sf * L.P[pidx * D + d] + om * xi;
-        else m = om * xi + sf * L.P[pidx * D + d];
-        m = m + sf * (L.P[L.R0[i] * D + d] - L.P[L.R1[i] * D + d]);
-        double c = u <= L.CR[i] ? m : xi;
-        if (c < lb) c = (xi + lb) / 2.;
-        else if (c > ub) c = (xi + ub) / 2.;
-        L.X[e] = c;
+    // A thread owns groups of four consecutive elements: ONE Philox call (site LDE_ELEM, index e >> 2) carries their four crossover uniforms,
+    // 32 bits each (u <= CR against a float32 rate: 2^-32 resolution; include/mbx_layout.h section 3) -- a call per element spent a quarter of
+    // the kernel's integer work on draws of which half the words were thrown away.
+    for (int t = tid; 4 * t < NE; t += MBX_NT) {
+        U4 w{0, 0, 0, 0};
+        if (!tape) w = rng.draw((uint32_t)t, MBX_SITE_LDE_ELEM);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 4 * t + q;
+            if (e >= NE) continue;
+            const int i = fd.div(e), d = e - i * D;
+            double u;
+            if (tape) u = tape[MBX_LDE_TAPE_CROSS(NP, D) + e];
+            else u = u32d(q == 0 ? w.x : q == 1 ? w.y : q == 2 ? w.z : w.w);
+            if (d == L.JR[i]) u = 0.;
+            const double xi = L.P[e], sf = L.SF[i], om = (double)(1.f - (float)sf);      // 1 - sf in float32, like the policy's tensor
+            if (kept) keep[q] = xi;
+            const int pidx = L.PIDX[i];
+            double m;
+            if (pidx == i) m = xi;
+            else if (pidx < i) m = sf * L.P[pidx * D + d] + om * xi;
+            else m = om * xi + sf * L.P[pidx * D + d];
+            m = m + sf * (L.P[L.R0[i] * D + d] - L.P[L.R1[i] * D + d]);
+            double c = u <= L.CR[i] ? m : xi;
+            if (c < lb) c = (xi + lb) / 2.;
+            else if (c > ub) c = (xi + ub) / 2.;
+            L.X[e] = c;
+        }
     }
     __syncthreads();
     MBX_PHASE(2);                                                 // mutation + crossover
@@ -277,9 +287,14 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     }
     __syncthreads();
     // survivors take the trial vector; the other rows come back from the registers above (P's storage served as evaluator scratch meanwhile)
-    for (int e = tid, q = 0; e < NE; e += MBX_NT, ++q) {
-        const double parent = !kept ? gPop[e] : q == 0 ? keep[0] : q == 1 ? keep[1] : q == 2 ? keep[2] : keep[3];
-        L.P[e] = L.R0[fd.div(e)] ? L.X[e] : parent;
+    for (int t = tid; 4 * t < NE; t += MBX_NT) {                   // same element ownership as the mutation loop
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = 4 * t + q;
+            if (e >= NE) continue;
+            const double parent = !kept ? gPop[e] : keep[q];
+            L.P[e] = L.R0[fd.div(e)] ? L.X[e] : parent;
+        }
     }
     double bsf_next; int bi;
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
