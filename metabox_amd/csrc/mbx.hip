@@ -427,7 +427,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     b->suite = s; b->cfg = *cfg; b->B = n_instances; b->lds_bytes = lds;
     // More than half a CU's LDS per workgroup means one resident workgroup per CU: give it 8 or 16 waves instead of 4 (D >= 16 / 32 keeps the
     // evaluator's per-wave scratch inside its T region).
-    if (cfg->algo == MBX_ALGO_LDE && lds > 40 * 1024 && cfg->dim >= 16) b->threads = 512;   // objective-bound at D = 30: 8 waves per workgroup, -21 %
+    if (cfg->algo == MBX_ALGO_LDE && (size_t)lde_lds_doubles(cfg->np, cfg->dim, true) * sizeof(double) > 40 * 1024 && cfg->dim >= 16) b->threads = 512;   // objective-bound at D = 30: 8 waves per workgroup, -21 %
     if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
     // MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
     {
@@ -482,6 +482,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_dq_step<>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -601,6 +602,8 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_reset: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 6)
             hipLaunchKernelGGL((k_lde_reset<512, 100, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
+        else if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 3)
+            hipLaunchKernelGGL((k_lde_reset<512, 50, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
         else if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
             hipLaunchKernelGGL(k_lde_reset<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
         else if (b->cfg.algo == MBX_ALGO_LDE)

@@ -106,7 +106,11 @@ struct Rng {                      // per-instance stream: key = seed, counter = 
         return U4{idx * 2654435761u, site + 0x9E3779B9u * idx, gen ^ (idx << 7), episode + idx};   // timing experiments only
 #else
         uint32_t a = k0, b = k1;
-        if (uniform_fresh) asm volatile("" : "+s"(a), "+s"(b));
+        if (uniform_fresh) {
+            // (readfirstlane: a no-op when the key already sits in SGPRs; instrumented builds load it with vector loads)
+            a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a); b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            asm volatile("" : "+s"(a), "+s"(b));
+        }
         return philox4x32_10(idx, site, gen, episode, a, b);
 #endif
     }
@@ -374,6 +378,52 @@ __device__ __forceinline__ void matvec_rows_scalar(const double* __restrict__ Mg
     }
 }
 
+// The same scheme for kernels with a tight register budget (k_lde_step<512, 50, 30>: 80 VGPRs): the row is taken in chunks of KC values and up to
+// UMAX outputs of the wave are accumulated side by side, so 2 KC + 2 UMAX registers replace the 2 MD of matvec_rows_scalar.  Every output still adds
+// its products in ascending k: bit-identical.
+template <int MD, bool SUB, int KC, int UMAX>
+__device__ __forceinline__ void matvec_rows_scalar_kc(const double* __restrict__ Mg, const double* In, const double* sub, int n, double* Out)
+{
+    static_assert(MD % KC == 0, "the chunk must divide the dimension");
+    typedef const double __attribute__((address_space(4)))* kptr;
+    const kptr M = (kptr)Mg;
+    const int tid0 = opaque_tid(), lane = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+    const int units = ((n + 63) >> 6) * MD;
+    const int per = (units + nw - 1) / nw;
+    const int u0 = wave * per, u1 = u0 + per < units ? u0 + per : units;
+    for (int ub = u0; ub < u1;) {
+        const int g = ub / MD, ge = (g + 1) * MD, ue = u1 < ge ? u1 : ge;      // this wave's units inside row group g: [ub, ue)
+        const int i = g * 64 + lane;
+        for (int us = ub; us < ue; us += UMAX) {
+            const int cnt = ue - us < UMAX ? ue - us : UMAX, d0 = us - g * MD;
+            double acc[UMAX];
+#pragma unroll
+            for (int j = 0; j < UMAX; ++j) acc[j] = 0.;
+#pragma unroll 1
+            for (int c = 0; c < MD; c += KC) {
+                double y[KC];
+                if (i < n) {
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) { const double v = In[i * MD + c + k]; y[k] = SUB ? v - sub[c + k] : v; }
+                }
+#pragma unroll
+                for (int j = 0; j < UMAX; ++j) {
+                    if (j < cnt) {
+                        const kptr row = M + (d0 + j) * MD + c;
+#pragma unroll
+                        for (int k = 0; k < KC; ++k) acc[j] += row[k] * y[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UMAX; ++j)
+                if (j < cnt && i < n) Out[i * MD + d0 + j] = acc[j];
+        }
+        ub = ue;
+    }
+}
+
 // sum of v over the block (all threads call; result to every thread).  red: >= 16 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
@@ -455,7 +505,7 @@ __device__ __forceinline__ double row_post(const PT& P, const RowPost& rp, int i
     return isnan(P.optimum) ? f : f - P.optimum;
 }
 
-template <int DC = 0, int MD = 0, class PT = DevProblem>
+template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0>
 __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* post = nullptr)
 {
     if (P.kind == MBX_KIND_PROTEIN) {
@@ -481,7 +531,10 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     // Barriers only where a phase exists for this function (the kind is workgroup-uniform, so every thread takes the same path).
     const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
     if (first_map) {
-        if constexpr (MD > 0) {
+        if constexpr (MD > 0 && KC > 0) {
+            if (kind == 21 || kind == 22) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m1, X, nullptr, n, Z);
+            else matvec_rows_scalar_kc<MD, true, KC, 4>(P.m1, X, dsh, n, Z);
+        } else if constexpr (MD > 0) {
             if (kind == 21 || kind == 22) matvec_rows_scalar<MD, false>(P.m1, X, nullptr, n, Z);
             else matvec_rows_scalar<MD, true>(P.m1, X, dsh, n, Z);
         } else {
@@ -642,13 +695,13 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     if (kind == 7) {
         for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
-        if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 12 || kind == 24) {
-        if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
+        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
-        if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     }
 
@@ -807,7 +860,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
 // cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
 // rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
 // (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
-template <int DC = 0, int MD = 0, class PT = DevProblem>
+template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0>
 __device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
@@ -816,7 +869,7 @@ __device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, 
     for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, post, i, L.X[i * P.dim] * L.X[i * P.dim] + P.bias);
     __syncthreads();
 #else
-    eval_rows<DC, MD, PT>(P, L, n, &post);
+    eval_rows<DC, MD, PT, KC>(P, L, n, &post);
 #endif
 }
 

@@ -19,7 +19,12 @@ struct LdeLds {
 
 // BASELINE config 3 as written (pop = 100 at D = 30): the kernels of this geometry read the two D x D maps from global memory through scalar
 // loads (matvec_rows_scalar) and keep no copy of them in LDS: 90.8 -> 76.4 KB per workgroup, i.e. TWO resident 512-thread workgroups per CU.
-__host__ __device__ constexpr bool lde_maps_in_lds(int NP, int D) { return !(NP == 100 && D == 30); }
+#ifndef MBX_LDE50_MAPS_IN_LDS
+#define MBX_LDE50_MAPS_IN_LDS 0
+#endif
+__host__ __device__ constexpr bool lde_maps_in_lds(int NP, int D) { return !((NP == 100 || (NP == 50 && !MBX_LDE50_MAPS_IN_LDS)) && D == 30); }
+// chunk of the register-resident row in matvec_rows_scalar_kc (0: whole row, for the 128-VGPR instantiation)
+__host__ __device__ constexpr int lde_matvec_chunk(int NP, int D) { return NP == 50 && D == 30 ? 15 : 0; }
 
 __host__ __device__ inline int64_t lde_lds_doubles(int NP, int D, bool maps = true)
 {
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
 // (all 30 noisy functions, 16 384 instances: 792 us at two resident workgroups -> 627 us at three).
 // (pop = 100 / D = 30: two resident workgroups = four waves per SIMD, 128 VGPRs: room for the register-resident rows of matvec_rows_scalar)
 #ifndef MBX_LDE_WAVES
-#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(lde_maps_in_lds(NPC, DC) ? 6 : 4)))
+#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(NPC == 100 ? 4 : 6)))
 #endif
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int THREADS, int NPC = 0, int DC = 0>
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     }
     __syncthreads();
     MBX_PHASE(2);                                                 // mutation + crossover
-    population_costs<eval_dc(DC), MD>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+    population_costs<eval_dc(DC), MD, ConstProblem, lde_matvec_chunk(NPC, DC)>(P, L.eval(), NP, rng, tape ? tape + MBX_LDE_TAPE_NOISE(NP, D) : nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
     fes += NP;
     MBX_PHASE(3);                                                 // evaluation
 
