@@ -278,7 +278,12 @@ def other_configs(budget_s=60.0):
             run4(5)
             dt = _bracket(run4, 100)
             entry('config 4: DE-DDQN protein-docking d=12 pop=100, 2240 instances = 35 problems x 64 runs (one GPU of eight), Q-net included', B, dt,
-                  15 * 1024, {'note': 'compute-bound (10^4 atom pairs per evaluation), the HBM fraction is nominal', 'launch_info': env.batch.launch_info()})
+                  15 * 1024, {'note': 'compute-bound (10^4 atom pairs per evaluation), the HBM fraction is nominal', 'launch_info': env.batch.launch_info(),
+                              # float64 VALU roofline of the protein energy (one evaluation per env-step): per atom pair ~35 flop (dot product 5, distance 4 + sqrt,
+                              # two divisions, Lennard-Jones / Coulomb / switching terms ~24; eval_rows_protein in mbx_device.hpp) x 10^4 pairs + 300 x 12 x 3 for the
+                              # displaced coordinates; peak = 1024 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz (f64 FMA issues in 4 cycles, profiles/r02_valu_issue_rates.txt)
+                              'compute_roofline': {'bound': 'valu_f64', 'flops_per_env_step': 3.6e5, 'achieved': B * 3.6e5 / dt / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s',
+                                                   'frac': B * 3.6e5 / dt / 1e12 / 78.6, 'note': 'whole step, Q-network launches included'}})
             env.close()
         # ---- config 5: RLEPSO on the mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances per GPU, act + step fused
         if time.perf_counter() - t_start <= budget_s:
