@@ -246,7 +246,7 @@ int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out
  *   d_traj_done    [n_gens, n_instances] uint8             is_done (1 after termination)
  * d_state_out / d_done_out [n_instances]: state / is_done after the last executed generation; d_reward_out [n_instances]: SUM of
  * the rewards of the executed generations (like mbx_rlpso_rollout).
- * The compile-time geometries (NP 100 / D 10 and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
+ * The compile-time geometries (NP 100 / D 10, NP 100 / D 30 and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
  * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 forces that route). */
 int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_traj_actions, double* d_traj_state,
                        double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out, double* d_reward_out,

@@ -73,7 +73,7 @@ struct mbx_batch {
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
     int fixed_geometry = 0;      // compile-time-geometry instantiation of the generation kernel for the BASELINE.json configs: 1 = RLEPSO NP 100 / D 10 /
-                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10, 6 = LDE NP 100 / D 30 (config 3 as written); 0 = geometry read from the batch
+                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10, 6 = LDE NP 100 / D 30 (config 3 as written), 7 = RLEPSO NP 100 / D 30 / 5 groups (bbob --dim 30); 0 = geometry read from the batch
 };
 
 // per-algorithm geometry
@@ -86,7 +86,11 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.state_doubles = MBX_RLEPSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
         g.sc_off = MBX_RLEPSO_ST_SCALARS(c.np, c.dim);
         g.tape_stride = MBX_RLEPSO_TAPE_STRIDE(c.np, c.dim);
-        g.lds_doubles = rl_lds_doubles(c.np, c.dim);
+        {   // compile-time geometries that read their maps from global memory need no LDS for them (unless the generic kernels are forced)
+            const char* gg = getenv("MBX_GENERIC_GEOMETRY");
+            const bool generic = gg && gg[0] == '1';
+            g.lds_doubles = rl_lds_doubles(c.np, c.dim, generic || c.n_group != 5 || rl_maps_in_lds(c.np, c.dim));
+        }
         g.state_dim = 1; g.action_dim = 7 * c.n_group;
     } else if (c.algo == MBX_ALGO_LDE) {
         g.state_doubles = MBX_LDE_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
@@ -428,13 +432,14 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     // More than half a CU's LDS per workgroup means one resident workgroup per CU: give it 8 or 16 waves instead of 4 (D >= 16 / 32 keeps the
     // evaluator's per-wave scratch inside its T region).
     if (cfg->algo == MBX_ALGO_LDE && (size_t)lde_lds_doubles(cfg->np, cfg->dim, true) * sizeof(double) > 40 * 1024 && cfg->dim >= 16) b->threads = 512;   // objective-bound at D = 30: 8 waves per workgroup, -21 %
-    if (cfg->algo == MBX_ALGO_RLEPSO && lds > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
+    if (cfg->algo == MBX_ALGO_RLEPSO && (size_t)rl_lds_doubles(cfg->np, cfg->dim, true) * sizeof(double) > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
     // MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
     {
         const char* g = getenv("MBX_GENERIC_GEOMETRY");
         if (cfg->algo == MBX_ALGO_RLEPSO && cfg->n_group == 5 && !(g && g[0] == '1')) {
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 10) b->fixed_geometry = 1;
             if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
+            if (b->threads == 512 && cfg->np == 100 && cfg->dim == 30) b->fixed_geometry = 7;
         }
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
@@ -470,6 +475,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -571,6 +579,7 @@ static void launch_rlepso_step(mbx_batch* b, hipStream_t stream, const float* d_
                        d_state_out, d_reward_out, d_done_out, d_table, table_rows, d_actions_out)
     if (b->fixed_geometry == 1) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
     else if (b->fixed_geometry == 2) MBX_RLEPSO_LAUNCH(1024, 128, 40, 5);
+    else if (b->fixed_geometry == 7) MBX_RLEPSO_LAUNCH(512, 100, 30, 5);
     else if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024);
     else if (b->threads == 512) MBX_RLEPSO_LAUNCH(512);
     else MBX_RLEPSO_LAUNCH(kThreads);
@@ -583,6 +592,8 @@ extern "C" int mbx_reset(mbx_batch* b, double* d_state_out, void* stream)
     if (b->cfg.algo == MBX_ALGO_RANDOM_SEARCH)
         hipLaunchKernelGGL(k_rs_population, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b), 1, d_state_out,
                            (double*)nullptr, (uint8_t*)nullptr);
+    else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->fixed_geometry == 7)
+        hipLaunchKernelGGL((k_rlepso_reset<512, 100, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 1024)
         hipLaunchKernelGGL(k_rlepso_reset<1024>, dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream, make_params(b), d_state_out);
     else if (b->cfg.algo == MBX_ALGO_RLEPSO && b->threads == 512)
@@ -772,10 +783,13 @@ extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_rollout: a replay tape holds one generation and no policy draws; use mbx_step with recorded actions");
     const int rows = mbx_rlepso_policy_table_rows(b);
     const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");      // tests: force the one-launch-per-generation route
-    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !(per_gen && per_gen[0] == '1')) {
+    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7) && !(per_gen && per_gen[0] == '1')) {
         const RunOut out{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
         if (b->fixed_geometry == 1)
             hipLaunchKernelGGL((k_rlepso_run<kThreads, 100, 10, 5>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream,
+                               make_params(b), d_table, rows, n_gens, out);
+        else if (b->fixed_geometry == 7)
+            hipLaunchKernelGGL((k_rlepso_run<512, 100, 30, 5>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream,
                                make_params(b), d_table, rows, n_gens, out);
         else
             hipLaunchKernelGGL((k_rlepso_run<1024, 128, 40, 5>), dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream,

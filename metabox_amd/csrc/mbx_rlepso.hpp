@@ -67,9 +67,13 @@ __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
     return align2(NE > need ? NE : need);
 }
 
-__host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
+// The bbob D = 30 geometry of the reference (NP = 100, rlepso_optimizer.py:9; `--dim 30`): its kernels read the two D x D maps from global memory
+// (matvec_rows_scalar) and keep no LDS copy: 90.0 -> 75.6 KB per workgroup, i.e. TWO resident 512-thread workgroups per CU instead of one.
+__host__ __device__ constexpr bool rl_maps_in_lds(int NP, int D) { return !(NP == 100 && D == 30); }
+
+__host__ __device__ inline int64_t rl_lds_doubles(int NP, int D, bool maps = true)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = maps ? align2((int64_t)D * D) : 0,
                   P = align2(NP), TS = eval_t_doubles(NP, D);
     // PB (aliased by the evaluator's scratch T once the velocity phase is over), X: NE each; Z: SC (R1, R2, COEF and the byte tables of
     // the move phase, all dead before the first evaluation, live in it); M1T, M2T; DSH, V0, V1, V2, GB: D each; PBC, NC, PNI, CMUT: P each;
@@ -77,9 +81,9 @@ __host__ __device__ inline int64_t rl_lds_doubles(int NP, int D)
     return TS + NE + SC + 2 * DD + 4 * P + 5 * align2(D) + 16 + 3 * align2((P + 1) / 2);
 }
 
-__device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D)
+__device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D, bool maps = true)
 {
-    const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = align2((int64_t)D * D),
+    const int64_t NE = align2((int64_t)NP * D), SC = rl_z_doubles(NP, D), DD = maps ? align2((int64_t)D * D) : 0,
                   P = align2(NP), TS = eval_t_doubles(NP, D);
     RlLds L;
     double* p = base;
@@ -349,14 +353,16 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, double 
 // PBO_Env.reset(): init_population (rlepso_optimizer.py:39-65)
 // ------------------------------------------------------------------------------------------------
 // THREADS = 256, or 512 when the geometry leaves room for one workgroup per CU only (see rl_block_threads)
-template <int THREADS>
+template <int THREADS, int NPC = 0, int DC = 0>
 __global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double* __restrict__ state_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = bp.order[blockIdx.x], tid = threadIdx.x;
-    const int NP = bp.NP, D = bp.D, NE = NP * D;
+    const int NP = NPC ? NPC : bp.NP, D = DC ? DC : bp.D, NE = NP * D;
+    constexpr bool MAPS = rl_maps_in_lds(NPC, DC);
+    constexpr int MD = MAPS ? 0 : DC;
     const DevProblem P = bp.problems[bp.problem_idx[b]];
-    const RlLds L = rl_carve(smem, NP, D);
+    const RlLds L = rl_carve(smem, NP, D, MAPS);
     double* S = bp.state + (int64_t)b * bp.state_stride;
     double* sc = S + MBX_RLEPSO_ST_SCALARS(NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double
     const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), 0u, (uint32_t)episode};
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
 
-    stage_problem(P, L.eval());
+    stage_problem<0, MAPS>(P, L.eval());
     for (int e = tid; e < NE; e += MBX_NT) {
         double up, uv;
         if (tape) { up = tape[MBX_RLEPSO_TAPE_REPOS(NP, D) + e]; uv = tape[MBX_RLEPSO_TAPE_REVEL(NP, D) + e]; }
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double
         S[MBX_RLEPSO_ST_VEL(NP, D) + e] = -vmax + (vmax - (-vmax)) * uv;
     }
     __syncthreads();
-    population_costs(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+    population_costs<0, MD>(P, L.eval(), NP, rng, tape ? tape + MBX_RLEPSO_TAPE_NOISE1(NP, D) : nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
     double gb; int gi;
     block_argmin(L.NC, NP, L.RED, gb, gi);
     for (int i = tid; i < NP; i += MBX_NT) {
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
     }
     MBX_PHASE_BEGIN
     ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
-    const RlLds L = rl_carve(smem, NP, D);
+    const RlLds L = rl_carve(smem, NP, D, rl_maps_in_lds(NPC, DC));
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const float* act = actions + (int64_t)b * (7 * G);
 
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         return;
     }
     ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);
-    const RlLds L = rl_carve(smem, NP, D);
+    const RlLds L = rl_carve(smem, NP, D, rl_maps_in_lds(NPC, DC));
     int gen = (int)sc[MBX_SC_GEN];
     const uint64_t seed = bp.seeds[b];
     const uint32_t episode = (uint32_t)(int)sc[MBX_SC_EPISODE];

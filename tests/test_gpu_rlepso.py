@@ -417,6 +417,7 @@ def test_resident_rollout_config5_geometry_and_host_loop_route(monkeypatch):
     take behind the same entry point (NP 60 / D 10 here, and MBX_ROLLOUT_PER_GENERATION=1)."""
     ps40 = (1, 8, 15, 21)
     _rollout_case('bbob', 40, ps40, 128, 8, (2, 5), maxfes=80000)
+    _rollout_case('bbob', 30, (1, 7, 16, 22), 100, 8, (3, 9), maxfes=60000)          # k_rlepso_run<512, 100, 30, 5>
     _rollout_case('bbob', 10, (1, 16), 60, 8, (3, 4))
     monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')
     _rollout_case('bbob', 10, (1, 21), 100, 8, (5, 2))
@@ -567,8 +568,9 @@ def test_compile_time_geometry_kernel_equals_generic_kernel(env, monkeypatch):
     from metabox_amd._abi import ALGO_RLEPSO
     c5 = [problems('bbob', 40)[k] for k in sorted(problems('bbob', 40))] + \
          [problems('bbob-noisy', 40)[k] for k in sorted(problems('bbob-noisy', 40))]
-    cases = [(env['bbob'][0], 24, 2, 60, NP, MAXFES, LOGI), (env['bbob-noisy'][0], 30, 2, 60, NP, MAXFES, LOGI),
-             (Suite(c5), len(c5), 1, 8, 128, 80000, 1600)]
+    c30 = [problems('bbob', 30)[k] for k in sorted(problems('bbob', 30))]            # bbob --dim 30, NP = 100: two 512-thread workgroups per CU,
+    cases = [(env['bbob'][0], 24, 2, 60, NP, MAXFES, LOGI), (env['bbob-noisy'][0], 30, 2, 60, NP, MAXFES, LOGI),   # maps read from global memory
+             (Suite(c5), len(c5), 1, 8, 128, 80000, 1600), (Suite(c30), len(c30), 1, 12, 100, 60000, 1200)]
     for s, n, reps, G, np_, maxfes, logi in cases:
         B = reps * n
         pidx = np.arange(B) % n
@@ -596,6 +598,12 @@ def test_launch_info_routes_baseline_geometries_to_their_instantiations(env):
     info = b.launch_info()
     assert info['threads'] == 256 and info['fixed_geometry'] == 1 and 5 * info['lds_bytes'] <= 160 * 1024, info
     assert info['state_doubles'] >= len(b.read_state(0))
+    b.close()
+    from metabox_amd.suite import Suite
+    s30 = Suite([problems('bbob', 30)[1], problems('bbob', 30)[16]])
+    b = Batch(s30, ALGO_RLEPSO, [0, 1], [1, 2], NP, 60000, 1200, NLOG)          # bbob --dim 30: no maps in LDS, two 512-thread workgroups per CU
+    info = b.launch_info()
+    assert info['threads'] == 512 and info['fixed_geometry'] == 7 and 2 * info['lds_bytes'] <= 160 * 1024, info
     b.close()
     b = Batch(s, ALGO_RLEPSO, [0, 1], [1, 2], 60, MAXFES, LOGI, NLOG)          # not a BASELINE geometry
     assert b.launch_info()['fixed_geometry'] == 0
