@@ -532,8 +532,8 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
     if (first_map) {
         if constexpr (MD > 0 && KC > 0) {
-            if (kind == 21 || kind == 22) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m1, X, nullptr, n, Z);
-            else matvec_rows_scalar_kc<MD, true, KC, 4>(P.m1, X, dsh, n, Z);
+            if (kind == 21 || kind == 22) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, X, nullptr, n, Z);
+            else matvec_rows_scalar_kc<MD, true, KC, (MD == 40 ? 5 : 4)>(P.m1, X, dsh, n, Z);
         } else if constexpr (MD > 0) {
             if (kind == 21 || kind == 22) matvec_rows_scalar<MD, false>(P.m1, X, nullptr, n, Z);
             else matvec_rows_scalar<MD, true>(P.m1, X, dsh, n, Z);
@@ -695,13 +695,13 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     if (kind == 7) {
         for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
-        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 12 || kind == 24) {
-        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
+        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
-        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, 4>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     }
 

@@ -67,6 +67,17 @@ __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
     return align2(NE > need ? NE : need);
 }
 
+// chunk of the register-resident row in the resident kernel's matvec (matvec_rows_scalar_kc; 0: whole row): at D = 40 the 80 row registers collide
+// with the resident velocities / pbest positions
+// (config 5, A/B on one box: whole row 2.00 ms, chunks of 20 / 10 / 8: 1.886 / 1.830 / 1.854 ms per generation of 8192 instances)
+#ifndef MBX_RUN_KC40
+#define MBX_RUN_KC40 10
+#endif
+#ifndef MBX_RUN_KC30
+#define MBX_RUN_KC30 0
+#endif
+__host__ __device__ constexpr int rl_run_matvec_chunk(int D) { return D == 40 ? MBX_RUN_KC40 : D == 30 ? MBX_RUN_KC30 : 0; }
+
 // The bbob D = 30 geometry of the reference (NP = 100, rlepso_optimizer.py:9; `--dim 30`): its kernels read the two D x D maps from global memory
 // (matvec_rows_scalar) and keep no LDS copy: 90.0 -> 75.6 KB per workgroup, i.e. TWO resident 512-thread workgroups per CU instead of one.
 __host__ __device__ constexpr bool rl_maps_in_lds(int NP, int D) { return !(NP == 100 && D == 30); }
@@ -887,7 +898,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         }
         __syncthreads();
         // ---- evaluate, update pbest / gbest and the stagnation counters (:198-233)
-        population_costs<eval_dc(DC), eval_md(DC), ConstProblem>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+        population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
         fes += NP;
         commit(true, tid);
         // ---- re-initialisation (:238-239, 134-168)
@@ -915,7 +926,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
                 }
             }
             __syncthreads();
-            population_costs<eval_dc(DC), eval_md(DC), ConstProblem>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+            population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
             fes += n_reinit;
             commit(false, tid);
         }
