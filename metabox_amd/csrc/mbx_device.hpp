@@ -216,19 +216,6 @@ __device__ __forceinline__ double div_by_tenth(double L)
     return __builtin_fma(__builtin_fma(-0.1, q, L), 10.0, q);
 }
 
-// ONE out-of-line call per coordinate with the four transcendentals inline inside it (same routines, same arithmetic as four m_* calls: each call
-// costs argument moves, a jump pair and a full s_waitcnt at the callee's entry).
-#if defined(MBX_NOINLINE_MATH) && !defined(MBX_LIBM_MATH) && !defined(MBX_OSC_FOUR_CALLS)
-__device__ __noinline__ double osc1(double x)
-{
-    if (x == 0.) return x;
-    const bool pos = x > 0.;
-    const double y = div_by_tenth(fm::log_fast(fabs(x)));
-    const double c1 = pos ? 1.0 : 0.55, c2 = pos ? 0.79 : 0.31;
-    const double r = fm::exp_fast(0.1 * (y + 0.49 * (fm::sincos_fast<false>(c1 * y) + fm::sincos_fast<false>(c2 * y))));
-    return pos ? r : -r;
-}
-#else
 __device__ __forceinline__ double osc1(double x)
 {
     // One code path for both signs: the coordinates of a wave have mixed signs, so an if / else over x > 0 / x < 0 executes BOTH sides
@@ -241,32 +228,6 @@ __device__ __forceinline__ double osc1(double x)
     const double r = m_exp(0.1 * (y + 0.49 * (m_sin(c1 * y) + m_sin(c2 * y))));
     return pos ? r : -r;
 }
-#endif
-
-// Weierstrass series (bbob.py:623) and Schaffers term (bbob.py:642-643) of one coordinate: likewise one out-of-line call each instead of 12 / 3.
-#if defined(MBX_NOINLINE_MATH) && !defined(MBX_LIBM_MATH) && !defined(MBX_OSC_FOUR_CALLS)
-__device__ __noinline__ double weierstrass_series(double base)
-{
-    double s = 0., ak = 1., bk = 1.;
-#pragma unroll 1
-    for (int k = 0; k < 12; ++k) { s += ak * fm::sincos_fast<true>(base * bk); ak *= 0.5; bk *= 3.; }
-    return s;
-}
-__device__ __noinline__ double schaffers_term(double s)
-{
-    const double w = fm::sincos_fast<false>(50 * fm::pow_fast(s, 0.2));
-    return sqrt(s) * (w * w + 1);                                 // pow(w, 2) is the correctly rounded square in numpy, libm and pow_fast alike
-}
-#else
-__device__ __forceinline__ double weierstrass_series(double base)
-{
-    double s = 0., ak = 1., bk = 1.;
-#pragma unroll 1
-    for (int k = 0; k < 12; ++k) { s += ak * m_cos(base * bk); ak *= 0.5; bk *= 3.; }
-    return s;
-}
-__device__ __forceinline__ double schaffers_term(double s) { return sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1); }
-#endif
 
 __device__ __forceinline__ double asy1(double x, double beta_lin)  // asy_transform, bbob.py:70-82
 {
@@ -749,14 +710,18 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
         for (int e = tid; e < NE; e += MBX_NT) T[e] = m_cos(kTwoPi * Z[e]);
     } else if (kind == 16) {                                        // Weierstrass series, bbob.py:623
         for (int e = tid; e < NE; e += MBX_NT) {
-            T[e] = weierstrass_series(kTwoPi * (Z[e] + 0.5));
+            const double base = kTwoPi * (Z[e] + 0.5);
+            double s = 0., ak = 1., bk = 1.;
+#pragma unroll 1
+            for (int k = 0; k < 12; ++k) { s += ak * m_cos(base * bk); ak *= 0.5; bk *= 3.; }
+            T[e] = s;
         }
     } else if (kind == 17 || kind == 18) {                          // Schaffers, bbob.py:642-643
         for (int e = tid; e < NE; e += MBX_NT) {
             const int d = fd.mod(e);
             if (d < D - 1) {
                 const double s = sqrt(Z[e] * Z[e] + Z[e + 1] * Z[e + 1]);
-                T[e] = schaffers_term(s);
+                T[e] = sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1);
             }
         }
     } else if (kind == 19) {                                        // Griewank-Rosenbrock, bbob.py:702-703
