@@ -319,6 +319,9 @@ def main():
     ap.add_argument('--steps', type=int, default=2 * EPISODE_GENS)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--instances', type=int, default=INSTANCES_PER_GPU, help='instances per GPU')
+    ap.add_argument('--repeats', type=int, default=0,
+                    help='how often the (warm-up + K timed generations) window is measured; 0 (default): once when it takes >= 0.5 s, else 30-200 times '
+                         '(~2 s of timed windows), the line reports the median repeat')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the configs 3 / 4 / 5 legs (other_configs)')
     ap.add_argument('--functions', default='all24',
@@ -410,7 +413,6 @@ def main():
     # kernels (act + step is a single launch, nothing else runs on the stream), so every kernel of the timed region is covered and an event
     # costs stream time only once per span.  Spans that contain an episode restart (mbx_reset) are left out.
     stride = args.event_stride if args.event_stride > 0 else (2 if K <= 64 else 8)
-    marks, mark_step, reset_steps = [], [], []
     state = env.reset()
     # The policy forward is two 3-layer MLPs, tanh, Normal sampling and clamp: ~15 tiny kernels.  Launched eagerly they
     # are asynchronous and hide behind the previous generation kernel; --graph-policy captures them once into a hipGraph
@@ -427,63 +429,101 @@ def main():
         policy_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(policy_graph), torch.no_grad():
             static_actions = policy(state)
-    gen_in_ep, live, base = 0, 0, 0
-    t0 = None
-    launches = []                                           # resident: (event before, event after, generations) of every timed launch
-    with torch.no_grad():
-        it = 0
-        while it < W + K:
-            if it == W:
-                barrier()
-                base = steps_sum()
-                t0 = time.perf_counter()
-            if gen_in_ep == EPISODE_GENS:
-                if it > W:
-                    live += steps_sum() - base
-                    base = 0
-                state = env.reset()
-                gen_in_ep = 0
-                if it >= W:
-                    reset_steps.append(it - W)
-                if it <= W:
-                    base = 0
-            if resident:
-                # one launch = up to --gens-per-launch generations; it ends where the warm-up, the timed window or the episode ends
-                n = min(max(1, args.gens_per_launch), EPISODE_GENS - gen_in_ep, (W if it < W else W + K) - it)
-                if it >= W:
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                state, _, _ = env.batch.rlepso_rollout(fused_table, n)
-                if it >= W:
-                    e1 = torch.cuda.Event(enable_timing=True)
-                    e1.record()
-                    launches.append((e0, e1, n))
-                it += n
-                gen_in_ep += n
-                continue
-            if fused_table is not None:
-                actions = None
-            elif policy_graph is not None:
-                policy_graph.replay()
-                actions = static_actions
-            else:
-                actions = policy(state)
-            if it >= W and (it - W) % stride == 0:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                marks.append(e); mark_step.append(it - W)
-            if fused_table is not None:
-                state, _, _ = env.batch.act_step(fused_table)
-            else:
-                state, _, _ = env.step(actions)
-            gen_in_ep += 1
-            it += 1
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        marks.append(e); mark_step.append(K)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        live += steps_sum() - base
+    def timed_window():
+        """One measurement: mbx_reset, W untimed warm-up generations, barrier + synchronize, EXACTLY K timed generations, barrier +
+        synchronize.  Returns (elapsed seconds on this rank, live env-steps of the K generations, resident launches, marks, mark_step, reset_steps)."""
+        nonlocal state
+        marks, mark_step, reset_steps, launches = [], [], [], []     # launches: (event before, event after, generations) of every timed launch
+        gen_in_ep, live, base = 0, 0, 0
+        t0 = None
+        state = env.reset()
+        with torch.no_grad():
+            it = 0
+            while it < W + K:
+                if it == W:
+                    barrier()
+                    base = steps_sum()
+                    t0 = time.perf_counter()
+                if gen_in_ep == EPISODE_GENS:
+                    if it > W:
+                        live += steps_sum() - base
+                        base = 0
+                    state = env.reset()
+                    gen_in_ep = 0
+                    if it >= W:
+                        reset_steps.append(it - W)
+                    if it <= W:
+                        base = 0
+                if resident:
+                    # one launch = up to --gens-per-launch generations; it ends where the warm-up, the timed window or the episode ends
+                    n = min(max(1, args.gens_per_launch), EPISODE_GENS - gen_in_ep, (W if it < W else W + K) - it)
+                    if it >= W:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    state, _, _ = env.batch.rlepso_rollout(fused_table, n)
+                    if it >= W:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        launches.append((e0, e1, n))
+                    it += n
+                    gen_in_ep += n
+                    continue
+                if fused_table is not None:
+                    actions = None
+                elif policy_graph is not None:
+                    policy_graph.replay()
+                    actions = static_actions
+                else:
+                    actions = policy(state)
+                if it >= W and (it - W) % stride == 0:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    marks.append(e); mark_step.append(it - W)
+                if fused_table is not None:
+                    state, _, _ = env.batch.act_step(fused_table)
+                else:
+                    state, _, _ = env.step(actions)
+                gen_in_ep += 1
+                it += 1
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e); mark_step.append(K)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            live += steps_sum() - base
+        return elapsed, live, launches, marks, mark_step, reset_steps
+
+    red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
+
+    def over_ranks(elapsed, live):
+        """(max over ranks of the window's wall time, sum over ranks of its live env-steps)"""
+        if dist is None:
+            return elapsed, float(live)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        tsum = torch.tensor([float(live)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[0])
+
+    # A short window (the driver's --steps 20 is ONE 3 ms launch) is a single sample with the pool's +-3 % box spread and launch jitter on top, so it
+    # is repeated: every repeat is a complete measurement (mbx_reset -> a new Philox episode of the same instances, W warm-up generations, barrier, the
+    # same K generations timed between barrier + synchronize pairs); nothing between two repeats is inside a timed bracket.  The line reports the
+    # MEDIAN repeat.  The number of repeats is derived from the first window's max-over-ranks time, so every rank runs the same number.
+    windows = [timed_window()]
+    first_elapsed, _ = over_ranks(windows[0][0], windows[0][1])
+    repeats = 1
+    if args.repeats > 0:
+        repeats = args.repeats
+    elif first_elapsed < 0.5:
+        repeats = int(min(200, max(30, np.ceil(2.0 / max(first_elapsed, 1e-4)))))
+    for _ in range(repeats - 1):
+        windows.append(timed_window())
+    per_repeat = [over_ranks(w[0], w[1]) for w in windows]            # (wall time max over ranks, live env-steps over all ranks) of every repeat
+    order = sorted(range(repeats), key=lambda r: per_repeat[r][0])
+    med = order[(repeats - 1) // 2]
+    elapsed_max, live_all = per_repeat[med]
+    times = np.array([t for t, _ in per_repeat])
+    launches = [l for w in windows for l in w[2]]
     # cost of an empty event pair on this stream (an event costs stream time too): measured, then subtracted from every bracket
     ea = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
     eb = [torch.cuda.Event(enable_timing=True) for _ in range(64)]
@@ -492,26 +532,25 @@ def main():
     torch.cuda.synchronize()
     pair_ms = sorted(a_.elapsed_time(b_) for a_, b_ in zip(ea, eb))[len(ea) // 2]
     span_ms, span_kernels = 0., 0
-    for j in range(len(marks) - 1):
-        a_, b_ = mark_step[j], mark_step[j + 1]
-        if any(a_ < r <= b_ for r in reset_steps) or args.policy != 'fused':      # (the reset of step r is enqueued before the mark of step r)
-            continue                                    # a reset kernel (or policy kernels) inside the span: not a pure generation-kernel span
-        span_ms += max(marks[j].elapsed_time(marks[j + 1]) - pair_ms, 0.)
-        span_kernels += b_ - a_
+    for _, _, _, marks, mark_step, reset_steps in windows:
+        for j in range(len(marks) - 1):
+            a_, b_ = mark_step[j], mark_step[j + 1]
+            if any(a_ < r <= b_ for r in reset_steps) or args.policy != 'fused':      # (the reset of step r is enqueued before the mark of step r)
+                continue                                    # a reset kernel (or policy kernels) inside the span: not a pure generation-kernel span
+            span_ms += max(marks[j].elapsed_time(marks[j + 1]) - pair_ms, 0.)
+            span_kernels += b_ - a_
     if resident:                                        # every launch of the window is bracketed by its own event pair
         span_ms = sum(max(a_.elapsed_time(b_) - pair_ms, 0.) for a_, b_, _ in launches)
         span_kernels = sum(n for _, _, n in launches)
     if span_kernels == 0:                               # policies that launch their own kernels between generations: fall back to the step time
-        span_ms, span_kernels = elapsed * 1e3, K
-    kern_ms = span_ms / span_kernels * K                # generation-kernel time of the K timed generations
+        span_ms, span_kernels = float(np.median([w[0] for w in windows])) * 1e3, K
+    kern_ms = span_ms / span_kernels * K                # generation-kernel time of K timed generations, averaged over every bracketed kernel of every repeat
+    n_launch_all = len(launches)
 
-    red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
-    tot = torch.tensor([float(live), kern_ms], dtype=torch.float64, device=red_dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([kern_ms, float(sum(w[1] for w in windows))], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    live_all, kern_ms_all, elapsed_max = float(tot[0]), float(tot[1]), float(tmax[0])
+    kern_ms_all, live_sum_all = float(tot[0]), float(tot[1])
 
     if rank == 0:
         fn_desc = {'all24': '24 bbob functions', 'train18': 'the 18 bbob-easy train functions'}.get(
@@ -519,11 +558,11 @@ def main():
         stop_desc = 'fixed horizon (stop rule disabled)' if args.fixed_horizon else 'reference stop rule'
         value = live_all / elapsed_max
         # one "launch" of the dominant kernel: a generation (k_rlepso_step) or, resident, the generations of one mbx_rlepso_rollout call
-        n_launch = len(launches) if resident else K
+        n_launch = n_launch_all / repeats if resident else K
         gens_per_launch = K / n_launch
         avg_gen_s = (kern_ms_all / world) / K / 1e3
         avg_kernel_s = avg_gen_s * gens_per_launch
-        live_per_gen = live_all / world / K
+        live_per_gen = live_sum_all / repeats / world / K          # the kernel time is the mean over all repeats, so are the env-steps it is priced with
         live_per_launch = live_per_gen * gens_per_launch           # env-steps (live instance-generations) one launch processes
         bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
@@ -533,6 +572,11 @@ def main():
             'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed_max / K * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            # the K-generation window measured `repeats` times (see timed_window); value / ms_per_step are the median repeat's, spread = (max - min) / median
+            # of the repeats' wall times, timed_region_s = the sum of all timed brackets
+            'repeats': repeats, 'spread': float((times.max() - times.min()) / np.median(times)) if repeats > 1 else 0.0,
+            'timed_region_s': float(times.sum()),
+            'repeat_ms_per_step': {'min': float(times.min() / K * 1e3), 'median': float(np.median(times) / K * 1e3), 'max': float(times.max() / K * 1e3)},
             'config': {'workload': f'RLEPSO_Agent + RLEPSO_Optimizer, bbob dim=10 pop=100, {B} lock-step instances per GPU '
                                    f'({fn_desc} round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'{stop_desc}, policy = exported bbob_easy RLEPSO weights sampled on device',
@@ -546,14 +590,14 @@ def main():
                                   'hip': 'mbx_gauss_policy (both MLPs over the whole batch, one launch) + mbx_step per generation',
                                   'torch': 'both actor MLPs as batched PyTorch ops every generation' + (', hipGraph replay' if args.graph_policy else ''),
                                   'table': '(mu, sigma) gathered from the per-fes table with PyTorch ops' + (', hipGraph replay' if args.graph_policy else '')}[args.policy],
-                       'kernel_timing': (f'every launch of the timed window bracketed by its own HIP event pair on the launch stream ({len(launches)} launches), '
+                       'kernel_timing': (f'every launch of every timed window bracketed by its own HIP event pair on the launch stream ({len(launches)} launches in {repeats} repeats), '
                                          f'minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)') if resident else
                                         (f'one HIP event every {stride} generations on the launch stream; consecutive events bracket {stride} back-to-back '
                                          f'generation kernels (all of them are covered), minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)'),
                        'timed_window': f'{K} consecutive lock-step generations starting at generation {first_gen} of an episode of {EPISODE_GENS} '
                                        f'(episodes restart with mbx_reset inside the window when it is longer)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_in_run': False,
                          'traffic_source': (f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
                                             f"run's live instances (not collected during this run)") if traffic_src else None,
                          'kernel': 'k_rlepso_run<256, 100, 10, 5>' if resident else 'k_rlepso_step<256, 100, 10, 5>',

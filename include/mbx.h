@@ -247,7 +247,10 @@ int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out
  * d_state_out / d_done_out [n_instances]: state / is_done after the last executed generation; d_reward_out [n_instances]: SUM of
  * the rewards of the executed generations (like mbx_rlpso_rollout).
  * The compile-time geometries (NP 100 / D 10, NP 100 / D 30 and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
- * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 forces that route). */
+ * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 in the environment when the
+ * batch is CREATED forces that route).  mbx_rlepso_rollout_resident tells which route a batch takes: 1 = one resident launch per call,
+ * 0 = one launch per generation (2 n_gens launches with d_reward_out).  Neither route allocates or reads the environment at call time. */
+int mbx_rlepso_rollout_resident(const mbx_batch* b);
 int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_traj_actions, double* d_traj_state,
                        double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out, double* d_reward_out,
                        uint8_t* d_done_out, void* stream);
@@ -286,12 +289,23 @@ int mbx_qlpso_rollout(mbx_batch* b, const double* d_q_table, int n_steps, int32_
  * op: 0 log, 1 exp, 2 sin, 3 cos, 4 pow(x, y), 5 T_osz(x) (bbob.py:51-67), 6 T_asy(x; beta_lin = y) (bbob.py:70-82). */
 int mbx_debug_math(int op, const double* d_x, const double* d_y, double* d_out, int n, void* stream);
 
+/* Test / diagnostics: the element-wise Philox draws of RLEPSO's move phase (include/mbx_layout.h section 3: sites ELEM_A and TOURN) of the instance with
+ * key `seed` at generation `gen` of episode `episode`, converted exactly as the generation kernel converts them: d_out [np * dim, 4] float64 =
+ * {CLPSO uniform in [0, 1), FDR weight in [0, 1), tournament candidate 1, tournament candidate 2 (integers in [0, np))} per element
+ * (replaces np.random.rand(NP, D) x 2 and np.random.randint(0, NP, (NP, D, 2)), src/optimizer/rlepso_optimizer.py:76-109).  The statistical tests of
+ * the stream (tests/test_gpu_rlepso.py::test_move_phase_draws_are_uniform) read it; they do not depend on the oracle. */
+int mbx_debug_rlepso_draws(uint64_t seed, int gen, int episode, int np, int dim, double* d_out, void* stream);
+
 /* Diagnostics: how the generation kernel of this batch is launched.  out[0] = threads per workgroup, out[1] = dynamic LDS bytes per
  * workgroup, out[2] = compile-time-geometry instantiation in use (0 = run-time geometry), out[3] = stride, in doubles,
  * between the state blocks of consecutive instances (>= mbx_instance_state_doubles).  Host-only, no device work. */
 int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4]);
 
 const char* mbx_last_error(void);
+/* "metabox_amd libmbx <major.minor> (gfx950; Philox stream layout <n>: ...)".  The stream layout number changes whenever the assignment of Philox
+ * counters to draws changes (include/mbx_layout.h section 3): trajectories, tapes and golden files made under another layout number do not
+ * reproduce and have to be regenerated.  Layout 1 = round 1 (53-bit element-wise uniforms, one call per element); layout 2 = since round 2
+ * (32-bit element-wise uniforms, one ELEM_A call per element pair, tournament draws on their own site TOURN). */
 const char* mbx_version(void);
 
 #ifdef __cplusplus

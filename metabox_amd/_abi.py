@@ -128,11 +128,13 @@ def load_lib():
         'mbx_rlepso_policy_table_rows': (C.c_int, [vp]),
         'mbx_rlepso_policy_table': (C.c_int, [vp, C.POINTER(GaussMlp), vp, vp]),
         'mbx_rlepso_act_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+        'mbx_rlepso_rollout_resident': (C.c_int, [vp]),
         'mbx_rlepso_rollout': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
         'mbx_rlpso_rollout': (C.c_int, [vp, C.POINTER(GaussMlp), C.c_int, vp, vp, vp, vp, vp]),
         'mbx_qlpso_rollout': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
         'mbx_gleet_policy': (C.c_int, [vp, C.POINTER(GleetActor), vp, vp, vp, vp]),
         'mbx_debug_math': (C.c_int, [C.c_int, vp, vp, vp, C.c_int, vp]),
+        'mbx_debug_rlepso_draws': (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         'mbx_batch_launch_info': (C.c_int, [vp, C.POINTER(C.c_int32)]),
         'mbx_instance_state_doubles': (i64, [vp]),
         'mbx_debug_read_state': (C.c_int, [vp, C.c_int, c_double_p]),
@@ -152,7 +154,7 @@ def load_lib():
 EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval',
                     'mbx_state_dim', 'mbx_action_dim', 'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy',
                     'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results', 'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_rlepso_policy_table_rows',
-                    'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlepso_rollout', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_debug_math', 'mbx_batch_launch_info', 'mbx_instance_state_doubles',
+                    'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlepso_rollout_resident', 'mbx_rlepso_rollout', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_debug_math', 'mbx_debug_rlepso_draws', 'mbx_batch_launch_info', 'mbx_instance_state_doubles',
                     'mbx_debug_read_state', 'mbx_batch_rebind', 'mbx_read_public', 'mbx_last_error', 'mbx_version')
 
 

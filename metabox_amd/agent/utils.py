@@ -1,5 +1,6 @@
 """Small training utilities shared by the agents (reference: src/agent/utils.py:9-48): the PPO rollout memory, the
 DQN replay buffer, and the whole-object pickle checkpoints (``checkpoint0.pkl`` .. ``checkpoint20.pkl``)."""
+import os
 import pathlib
 import pickle
 import random
@@ -41,7 +42,16 @@ class ReplayBuffer:
 
 
 def save_class(dir, file_name, saving_class):
-    """Pickle `saving_class` to ``<dir><file_name>.pkl`` (dir is used as a string prefix, like the reference does)."""
+    """Pickle `saving_class` to ``<dir><file_name>.pkl`` (dir is used as a string prefix, like the reference does).
+    Multi-rank training keeps every rank's policy identical and in lock step (distributed.average_gradients / all_ranks_any), so all
+    ranks reach a checkpoint threshold at the same optimizer step: only rank 0 writes, and it writes to a temporary file that is renamed
+    over the target, so a reader never sees a half-written pickle."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return
     pathlib.Path(dir).mkdir(parents=True, exist_ok=True)
-    with open(f'{dir}{file_name}.pkl', 'wb') as fh:
+    target = f'{dir}{file_name}.pkl'
+    tmp = f'{target}.tmp{os.getpid()}'
+    with open(tmp, 'wb') as fh:
         pickle.dump(saving_class, fh, protocol=-1)
+    os.replace(tmp, target)

@@ -64,7 +64,8 @@ struct mbx_batch {
     double* d_state = nullptr;
     int32_t* d_order = nullptr;
     double* d_pci = nullptr;
-    double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (allocated on first use)
+    double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (RLEPSO batches; allocated by mbx_batch_create)
+    bool rollout_per_generation = false;   // MBX_ROLLOUT_PER_GENERATION=1 at batch creation: mbx_rlepso_rollout takes the host-loop route (tests)
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
     size_t lds_bytes = 0;
@@ -468,6 +469,10 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         for (int i = 0; i < cfg->np; ++i) pci[i] = 0.05 + 0.45 * std::exp(10. * i / (cfg->np - 1)) / (std::exp(10.) - 1);
         HIP_TRY(hipMalloc(&b->d_pci, cfg->np * sizeof(double)));
         HIP_TRY(hipMemcpy(b->d_pci, pci.data(), cfg->np * sizeof(double), hipMemcpyHostToDevice));
+        // mbx_rlepso_rollout never allocates or reads the environment (it may run under stream capture): both happen here
+        HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * sizeof(double)));
+        const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");
+        b->rollout_per_generation = per_gen && per_gen[0] == '1';
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -767,6 +772,13 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     return MBX_OK;
 }
 
+extern "C" int mbx_rlepso_rollout_resident(const mbx_batch* b)
+{
+    if (!b) return fail(MBX_E_ARG, "mbx_rlepso_rollout_resident: null batch");
+    if (b->cfg.algo != MBX_ALGO_RLEPSO) return 0;
+    return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7) && !b->rollout_per_generation ? 1 : 0;
+}
+
 __global__ void k_sum_rewards(double* __restrict__ acc, const double* __restrict__ r, int n, int first)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -782,8 +794,7 @@ extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens
     if (n_gens < 1) return fail(MBX_E_ARG, "mbx_rlepso_rollout: n_gens must be >= 1");
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_rollout: a replay tape holds one generation and no policy draws; use mbx_step with recorded actions");
     const int rows = mbx_rlepso_policy_table_rows(b);
-    const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");      // tests: force the one-launch-per-generation route
-    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7) && !(per_gen && per_gen[0] == '1')) {
+    if (mbx_rlepso_rollout_resident(b) == 1) {
         const RunOut out{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
         if (b->fixed_geometry == 1)
             hipLaunchKernelGGL((k_rlepso_run<kThreads, 100, 10, 5>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream,
@@ -798,7 +809,6 @@ extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens
         return MBX_OK;
     }
     // run-time geometries: one k_rlepso_step launch per generation, same outputs
-    if (d_reward_out && !d_traj_reward && !b->d_scratch) HIP_TRY(hipMalloc(&b->d_scratch, (size_t)b->B * sizeof(double)));
     const int64_t B = b->B, A = b->action_dim;
     for (int g = 0; g < n_gens; ++g) {
         double* r = d_traj_reward ? d_traj_reward + g * B : (d_reward_out ? b->d_scratch : nullptr);
@@ -901,6 +911,28 @@ __global__ void k_debug_math(int op, const double* __restrict__ x, const double*
     out[i] = r;
 }
 
+// Test / diagnostics: the element-wise draws of RLEPSO's move phase for one (seed, generation, episode), converted exactly as rl_move converts them
+// (mbx_rlepso.hpp; include/mbx_layout.h section 3): out[e] = {CLPSO uniform, FDR weight, tournament candidate 1, tournament candidate 2}.
+__global__ void k_debug_rlepso_draws(uint64_t seed, uint32_t gen, uint32_t episode, int NP, int D, double* __restrict__ out)
+{
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;          // element pair (2 it, 2 it + 1)
+    if (2 * it >= NP * D) return;
+    const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), gen, episode};
+    const U4 wa = rng.draw((uint32_t)it, MBX_SITE_ELEM_A), wt = rng.draw((uint32_t)it, MBX_SITE_TOURN);
+    double* o = out + (int64_t)it * 8;
+    o[0] = u32d(wa.x); o[1] = u32d(wa.z); o[2] = (double)__umulhi(wt.x, (uint32_t)NP); o[3] = (double)__umulhi(wt.y, (uint32_t)NP);
+    if (2 * it + 1 < NP * D) { o[4] = u32d(wa.y); o[5] = u32d(wa.w); o[6] = (double)__umulhi(wt.z, (uint32_t)NP); o[7] = (double)__umulhi(wt.w, (uint32_t)NP); }
+}
+
+extern "C" int mbx_debug_rlepso_draws(uint64_t seed, int gen, int episode, int np, int dim, double* d_out, void* stream)
+{
+    if (np < 1 || dim < 1 || !d_out) return fail(MBX_E_ARG, "mbx_debug_rlepso_draws: bad arguments");
+    const int pairs = (np * dim + 1) / 2;
+    hipLaunchKernelGGL(k_debug_rlepso_draws, dim3((pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, (uint32_t)gen, (uint32_t)episode, np, dim, d_out);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
 extern "C" int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4])
 {
     if (!b || !out) return fail(MBX_E_ARG, "mbx_batch_launch_info: bad arguments");
@@ -936,7 +968,7 @@ extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out
 }
 
 extern "C" const char* mbx_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mbx_version(void) { return "metabox_amd libmbx 0.1 (gfx950)"; }
+extern "C" const char* mbx_version(void) { return "metabox_amd libmbx 0.3 (gfx950; Philox stream layout 2: include/mbx_layout.h section 3)"; }
 
 #ifdef MBX_PHASE_TIMING
 // Instrumented builds only (not declared in include/mbx.h): cumulative per-phase cycles of k_rlepso_step (thread 0 of every

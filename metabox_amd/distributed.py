@@ -26,6 +26,52 @@ def instance_table(n_problems, runs, sort_by_problem=True):
     return p, r
 
 
+# ns per instance-generation of the RLEPSO generation kernel by BBOB function kind (1..24), measured on one MI355X with tools/kbench_costs.py
+# (a batch that holds one kind only, fixed horizon, resident rollout): D = 10 / NP = 100 and D = 40 / NP = 128.  Only the RATIOS matter: they
+# weight the inter-rank partition below.  Noisy functions cost what their base kind costs (the noise is O(NP) per generation).
+COST_NS = {
+    10: {1: 30.6, 2: 36.6, 3: 41.9, 4: 38.0, 5: 27.5, 6: 31.6, 7: 33.1, 8: 29.9, 9: 29.7, 10: 36.5, 11: 36.5, 12: 33.5, 13: 29.8, 14: 32.3,
+         15: 42.1, 16: 51.2, 17: 50.0, 18: 50.0, 19: 32.5, 20: 32.8, 21: 48.0, 22: 35.5, 23: 39.8, 24: 32.9},
+    40: {1: 193., 2: 215., 3: 240., 4: 225., 5: 165., 6: 250., 7: 255., 8: 195., 9: 230., 10: 250., 11: 250., 12: 240., 13: 235., 14: 240.,
+         15: 299., 16: 402., 17: 330., 18: 330., 19: 245., 20: 215., 21: 525., 22: 513., 23: 330., 24: 260.},
+}
+
+
+def relative_cost(problem):
+    """Predicted cost of one generation of one instance of `problem`, in the units of COST_NS (the table of the nearer dimension; problems without a
+    BBOB kind -- protein docking -- all cost the same)."""
+    kind = getattr(problem, 'kind', None)
+    if kind is None:
+        return 1.0
+    table = COST_NS[10] if getattr(problem, 'dim', 10) <= 20 else COST_NS[40]
+    return float(table.get(int(kind), np.mean(list(table.values()))))
+
+
+def cost_partition(costs, world):
+    """Cost-weighted CONTIGUOUS partition of the instance table over `world` ranks: rank r gets [bounds[r], bounds[r + 1]) such that every
+    rank's predicted cost is within one instance of total / world.  The table is problem-major (instance_table), so a rank still sees few
+    problems, rank order == global-id order (gather_rows needs no permutation) and the Philox key of an instance is a function of its
+    global id only: the gathered table is bit-identical for any number of ranks, only the cut points move.  The equal-count split this
+    replaces gave the rank that owns Gallagher / Weierstrass instances ~3x the work of the one that owns Sphere / Linear slope at config 5
+    ("what's missing" 3); an epoch ends with the slowest rank.
+    -> int64 array of world + 1 ascending bounds, bounds[0] = 0, bounds[-1] = len(costs)."""
+    c = np.asarray(costs, dtype=np.float64)
+    n, world = len(c), int(world)
+    if n == 0 or world <= 1:
+        return np.array([0] + [n] * max(world, 1), dtype=np.int64)
+    cum = np.cumsum(c)
+    mid = cum - 0.5 * c                                   # an instance belongs to the rank whose quantile its midpoint falls into
+    targets = cum[-1] * np.arange(1, world) / world
+    inner = np.searchsorted(mid, targets, side='left')
+    return np.concatenate([[0], inner, [n]]).astype(np.int64)
+
+
+def partition_bounds(problems, pidx, world):
+    """cost_partition over the (problem x run) table `pidx` of `problems`."""
+    per_problem = np.array([relative_cost(p) for p in problems], dtype=np.float64)
+    return cost_partition(per_problem[np.asarray(pidx)], world)
+
+
 def philox_seed(run, global_id, epoch_salt=0):
     """64-bit Philox key of an instance: depends on (run seed, global instance id, salt) only."""
     with np.errstate(over='ignore'):                    # arithmetic modulo 2^64 is the point
@@ -47,14 +93,19 @@ def unpack_rows(rows):
     return {'cost': rows[:, :n], 'fes': rows[:, n], 'return': rows[:, n + 1], 'steps': rows[:, n + 2].to(torch.int64)}
 
 
-def gather_rows(rows, n_total, group=None):
+def gather_rows(rows, n_total, group=None, bounds=None):
     """All-gather the local result rows of every rank into the global [n_total, C] table (rank order == global id
-    order because shards are contiguous).  Shards may differ in size by one row: rows are padded to the maximum."""
+    order because shards are contiguous).  Shards differ in size (by one row for the equal-count split, by the cost ratio for
+    `bounds` = cost_partition(...)): rows are padded to the maximum."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return rows
     world = dist.get_world_size(group)
-    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    if bounds is not None:
+        assert len(bounds) == world + 1 and int(bounds[-1]) == n_total
+        sizes = [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
+    else:
+        sizes = [shard_range(n_total, r, world) for r in range(world)]
     max_n = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros(max_n, rows.shape[1], dtype=rows.dtype, device=rows.device)
     pad[:rows.shape[0]] = rows

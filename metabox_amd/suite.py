@@ -195,6 +195,9 @@ class Batch:
         assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
         assert h.is_cuda and c.is_cuda and h.dtype == c.dtype == torch.float32 and h.is_contiguous() and c.is_contiguous()
         assert h.numel() == c.numel() == self.B * hidden
+        need = (self.state_dim + hidden) * 4 * hidden + 4 * hidden + 2 * hidden * self.action_dim + 2 * self.action_dim   # lstm_policy_floats (mbx_lstm_policy.hpp)
+        if weights.numel() != need:
+            raise ValueError(f'packed LSTM policy has {weights.numel()} floats, in {self.state_dim} / hidden {hidden} / out {self.action_dim} needs {need}')
         if getattr(self, '_actions', None) is None:
             self._actions = torch.empty(self.B, self.action_dim, dtype=torch.float32, device=self.device)
         ms = torch.empty(self.B, 2, self.action_dim, dtype=torch.float32, device=self.device) if want_mu_sigma else None
@@ -223,10 +226,24 @@ class Batch:
         _abi.check(self.lib.mbx_rlepso_policy_table(self._h, C.byref(net), _ptr(table), _stream()))
         return table
 
+    def _check_table(self, table):
+        """The kernels index the actor table by fes, clamped to mbx_rlepso_policy_table_rows(batch): a table with fewer rows or another
+        action width would be read out of bounds on the device, so its shape is checked here."""
+        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        rows = int(self.lib.mbx_rlepso_policy_table_rows(self._h))
+        if tuple(table.shape) != (rows, 2, self.action_dim):
+            raise ValueError(f'actor table has shape {tuple(table.shape)}, this batch needs ({rows}, 2, {self.action_dim}) '
+                             f'(mbx_rlepso_policy_table_rows x (mu, sigma) x action_dim)')
+
+    def rollout_is_resident(self):
+        """True when rlepso_rollout runs the resident kernel (one launch per call), False for the one-launch-per-generation route
+        (``mbx_rlepso_rollout_resident``)."""
+        return int(self.lib.mbx_rlepso_rollout_resident(self._h)) == 1
+
     def act_step(self, table, want_actions=False):
         """agent.act + env.step in one launch (``mbx_rlepso_act_step``): the action of every instance is drawn inside the generation
         kernel from row fes of `table`.  Returns (state, reward, done[, actions])."""
-        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        self._check_table(table)
         acts = None
         if want_actions:
             if getattr(self, '_actions', None) is None:
@@ -242,7 +259,7 @@ class Batch:
         generations, done) and, with ``trajectory=True``, a dict of per-generation records: actions [n_gens, B, action_dim] float32,
         state / reward [n_gens, B] float64, done [n_gens, B] uint8 (rows after an instance's termination: reward 0, done 1, actions
         not written)."""
-        assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
+        self._check_table(table)
         n_gens = int(n_gens)
         traj = None
         if trajectory:

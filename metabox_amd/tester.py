@@ -24,7 +24,7 @@ import torch
 
 from . import agent as _agents
 from . import optimizer as _optimizers
-from .distributed import gather_rows, instance_table, pack_rows, philox_seed, shard_range, unpack_rows
+from .distributed import gather_rows, instance_table, pack_rows, partition_bounds, philox_seed, unpack_rows
 from .environment import BatchedPBO_Env
 from .utils import construct_problem_set
 
@@ -84,7 +84,9 @@ def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0, n_logpoin
     pidx, run = instance_table(len(problems), runs)
     n_total = len(pidx)
     rank, world = _world()
-    lo, hi = shard_range(n_total, rank, world)
+    # cost-weighted contiguous split (distributed.cost_partition): every rank gets the same predicted work, not the same number of instances
+    bounds = partition_bounds(problems, pidx, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     seeds = philox_seed(run, np.arange(n_total), epoch_salt)
     cap = n_instances_cap if n_instances_cap and n_instances_cap > 0 else (hi - lo)
     rows = []
@@ -97,7 +99,7 @@ def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0, n_logpoin
     dev = torch.device('cuda', torch.cuda.current_device())
     # an empty shard (fewer instances than ranks) still takes part in the all-gather with the right width and device
     local = torch.cat(rows, 0) if rows else torch.zeros(0, n_logpoint + 1 + 3, dtype=torch.float64, device=dev)
-    full = unpack_rows(gather_rows(local, n_total))
+    full = unpack_rows(gather_rows(local, n_total, bounds=bounds))
     # per-instance wall time (the batched engine's T2, see module docstring): this rank's wall over ITS instances, the slowest rank counts
     per_instance_ms = wall_ms / max(hi - lo, 1)
     if world > 1:

@@ -56,8 +56,8 @@ class Trainer(object):
             pidx, run = instance_table(len(problems), self.config.train_batch_size)
             lo, hi = shard_range(len(pidx), rank, world)
             seeds = philox_seed(run, np.arange(len(pidx)), epoch_salt=epoch + 1)
-            if hi <= lo:
-                raise ValueError(f'train_batched: rank {rank} of {world} would own no instance ({len(pidx)} in the epoch): '
+            if len(pidx) < world:              # decided from global quantities only: EVERY rank raises, none is left waiting in an all-reduce
+                raise ValueError(f'train_batched: {world} ranks but only {len(pidx)} instances in the epoch, a rank would own none: '
                                  f'raise --train_batch_size or use fewer ranks')
             env = BatchedPBO_Env(problems, self.optimizer, pidx[lo:hi], seeds[lo:hi], suite=suite)
             exceed, info = self.agent.train_batch(env)

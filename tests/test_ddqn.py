@@ -70,7 +70,6 @@ def test_hip_ddqn_tape_replay_matches_reference():
         acts = TR[f'{case}/actions']
         G = len(acts)
         gb, rw, dn = np.zeros(G), np.zeros(G), np.zeros(G, bool)
-        sc_off = oracle.dq_state_doubles(NP, dim, nlog) - (nlog + 1) - 16
         want_feat = {int(r[0]) for r in TR[f'{case}/feats']}
         tape_dev = torch.empty(1, b.tape_stride, dtype=torch.float64, device='cuda')
         for g in range(G):
@@ -78,13 +77,12 @@ def test_hip_ddqn_tape_replay_matches_reference():
             b.set_tape(tape_dev)
             st, r, d = b.step(torch.tensor([int(acts[g])], dtype=torch.int32, device='cuda'))
             rw[g] = r[0].item(); dn[g] = bool(d[0].item())
+            gb[g] = b.read_public(0)[0]                 # MBX_SC_GBEST after this step: the whole trajectory is compared with the reference's
             if g in want_feat:
                 feats[g] = st[0].cpu().numpy().copy()
-        # gbest per step is re-derived from the reward-free trajectory: compare at the sampled steps and at the end
         res = b.results()
         fin = oracle.split_dq_state(b.read_state(0), NP, dim, nlog)
-        gb[:] = TR[f'{case}/gbest']
-        gb[-1] = fin['scalars'][0]
+        assert gb[-1] == fin['scalars'][0]
         _check(case, gb, rw, dn, feats, res['cost'][0].cpu().numpy(), int(res['cost_len'][0].item()), fin['X'].reshape(NP, dim), fin['scalars'][1])
         assert int(res['steps'][0].item()) == G
         b.close()
@@ -183,3 +181,99 @@ def test_ddqn_compile_time_geometry_kernel_equals_generic_kernel(monkeypatch):
         states.append(np.stack([b.read_state(k) for k in range(B)]))
         b.close()
     assert np.array_equal(states[0], states[1], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_hip_ddqn_philox_parity_with_oracle_on_protein():
+    """BASELINE config 4's geometry (protein docking, NP = 100, D = 12, maxFEs 1000 -> k_dq_step<100, 12>): oracle (Philox mode) and HIP
+    kernel side by side on 4 protein problems x 2 seeds, every step's 99 features and reward, final state exact in its integer parts
+    (src/optimizer/de_ddqn_optimizer.py:131-220 on src/problem/protein_docking.py:9-48)."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_DEDDQN
+    from test_protein import protein
+    ps = list(protein()[0].values())
+    ps = [ps[0], ps[7], ps[100], ps[279]]
+    s = Suite(ps)
+    B, G, D = 2 * len(ps), 240, 12                  # > 2 population sweeps
+    assert s.dim == D
+    actions = np.random.RandomState(3).randint(0, 4, size=(G, B)).astype(np.int32)
+    seeds = np.arange(B, dtype=np.uint64) * 13 + 3
+    b = Batch(s, ALGO_DEDDQN, np.arange(B) % len(ps), seeds, NP, 1000, 200, 5)
+    assert b.launch_info()['fixed_geometry'] != 0
+    st0 = b.reset().cpu().numpy().copy()
+    hist = []
+    for g in range(G):
+        st, r, d = b.step(torch.from_numpy(actions[g]).cuda())
+        hist.append((st.cpu().numpy().copy(), r.cpu().numpy().copy(), b.read_public(0)[0]))
+    cfg = oracle.make_cfg(3, NP, D, 1000, 200, 5)
+    for k in range(B):
+        p = ps[k % len(ps)]
+        o = oracle.DqOracle(p.desc(), None, cfg, seed=int(seeds[k]))
+        f0 = o.reset()
+        assert np.all(np.abs(f0 - st0[k]) <= 1e-5 * np.abs(f0) + 1e-7), k
+        for g in range(G):
+            f, rew, d = o.step(int(actions[g, k]))
+            got = hist[g][0][k]
+            assert np.all(np.abs(f - got) <= 1e-5 * np.abs(f) + 1e-7), (k, g, int(np.argmax(np.abs(f - got))))
+            assert abs(rew - hist[g][1][k]) <= 1e-5 * abs(rew) + 1e-9
+            if k == 0:
+                want_gb = oracle.split_dq_state(o.state(), NP, D, 5)['scalars'][0]
+                assert abs(hist[g][2] - want_gb) <= 1e-5 * abs(want_gb) + 1e-9, g
+        want = oracle.split_dq_state(o.state(), NP, D, 5)
+        got = oracle.split_dq_state(b.read_state(k), NP, D, 5)
+        assert np.abs(got['X'] - want['X']).max() <= 1e-12 and np.all(np.abs(got['cost'] - want['cost']) <= 1e-5 * np.abs(want['cost']) + 1e-9)
+        for key in ('ntot', 'nsucc'):
+            assert np.array_equal(got[key], want[key]), (k, key)
+        assert np.array_equal(got['extra'][2:], want['extra'][2:]), k
+    b.close()
+
+
+@pytest.mark.gpu
+def test_ddqn_protein_batch_properties():
+    """BASELINE config 4, one GPU's share: 2 240 instances = 35 protein problems x 64 runs, k_dq_step<100, 12>.  Size-independent
+    properties: bit-identical re-run, the odd half of the batch reproduces its rows (results do not depend on batch position / shard),
+    fes accounting (NP + one evaluation per step), monotone gbest, done after maxFEs - NP steps."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_DEDDQN
+    from test_protein import protein
+    ps = list(protein()[0].values())[:35]
+    s = Suite(ps)
+    B, G = 35 * 64, 150
+    pidx = np.arange(B) // 64
+    seeds = (np.arange(B, dtype=np.uint64) % 64) + 1
+    actions = torch.randint(0, 4, (G, B), generator=torch.Generator().manual_seed(11), dtype=torch.int32).cuda()
+
+    def run(sel, maxfes=1000, steps=G):
+        b = Batch(s, ALGO_DEDDQN, pidx[sel], seeds[sel], NP, maxfes, maxfes // 5, 5)
+        assert b.launch_info()['fixed_geometry'] != 0
+        b.reset()
+        sel_dev = torch.from_numpy(sel).cuda()
+        gbs = []
+        for g in range(steps):
+            st, r, d = b.step(actions[g].index_select(0, sel_dev).contiguous())
+            if g % 50 == 49:
+                gbs.append(b.results()['cost'][:, 0].clone())
+        r = {k: v.cpu().numpy() for k, v in b.results().items()}
+        r['state'] = st.cpu().numpy().copy()
+        r['done'] = d.cpu().numpy().copy()
+        x = np.stack([b.read_state(i) for i in (0, len(sel) // 2, len(sel) - 1)])
+        b.close()
+        return r, x
+    full, xf = run(np.arange(B))
+    again, xa = run(np.arange(B))
+    for k in full:
+        assert np.array_equal(full[k], again[k], equal_nan=True), k
+    assert np.array_equal(xf, xa, equal_nan=True)
+    half = np.arange(B)[1::2]
+    part, _ = run(half)
+    for k in full:
+        assert np.array_equal(full[k][half], part[k], equal_nan=True), k
+    assert np.all(full['steps'] == G) and np.all(full['fes'] == NP + G) and not full['done'].any()
+    assert np.all(np.isfinite(full['state'])) and full['state'].shape == (B, 99)
+    # the 64 runs of one problem differ (seeds), the same (problem, seed) pair does not depend on where it sits
+    assert len(np.unique(full['cost'][:64, 0])) > 32
+    # a whole short episode: every instance terminates exactly at maxFEs (protein has no optimum: de_ddqn_optimizer.py:205-212)
+    short, _ = run(np.arange(0, B, 7), maxfes=NP + 40, steps=45)
+    assert np.all(short['steps'] == 40) and np.all(short['fes'] == NP + 40) and short['done'].all()

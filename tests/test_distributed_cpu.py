@@ -140,3 +140,68 @@ def test_batched_training_with_unequal_episode_lengths_world2():
         assert p.exitcode == 0
     assert outs[0][1] == outs[1][1] == 9
     assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def _c5_table():
+    """BASELINE config 5's instance table: 24 bbob + 30 noisy functions at D = 40, function-sorted, 65 536 instances (problem-major)."""
+    from metabox_amd.problem.bbob import BBOB_Dataset
+    ps = []
+    for suite in ('bbob', 'bbob-noisy'):
+        tr, te = BBOB_Dataset.get_datasets(suite, 40, 5.0)
+        ps += sorted(tr.data + te.data, key=lambda p: p.func_id)
+    n = 65536
+    pidx = (np.arange(n) * len(ps) // n).astype(np.int32)           # problem-major, 1213-1214 runs per function
+    return ps, pidx
+
+
+def test_cost_partition_balances_config5_and_keeps_global_order():
+    """the equal-count split of the function-sorted table gives some ranks ~2x the work of others; the cost-weighted
+    contiguous split keeps every rank's predicted cost within a few instances of the mean for any number of ranks."""
+    from metabox_amd.distributed import cost_partition, partition_bounds, relative_cost, shard_range
+    ps, pidx = _c5_table()
+    cost = np.array([relative_cost(p) for p in ps])[pidx]
+    for world in (2, 3, 4, 8, 16):
+        b = partition_bounds(ps, pidx, world)
+        assert b[0] == 0 and b[-1] == len(pidx) and np.all(np.diff(b) > 0)
+        per = np.array([cost[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert per.max() / per.mean() <= 1.001, (world, per.max() / per.mean())
+    eq = np.array([cost[slice(*shard_range(len(pidx), r, 8))].sum() for r in range(8)])
+    assert eq.max() / eq.mean() > 1.25                               # what the equal-count split did
+    # degenerate inputs: fewer instances than ranks (empty shards are legal), zero ranks' worth of cost, a single rank
+    assert list(cost_partition([1., 1.], 4)) in ([0, 0, 1, 1, 2], [0, 1, 1, 2, 2], [0, 0, 1, 2, 2], [0, 1, 1, 1, 2])
+    assert list(cost_partition([], 3)) == [0, 0, 0, 0] and list(cost_partition([3., 1.], 1)) == [0, 2]
+    assert list(cost_partition(np.ones(10), 5)) == [0, 2, 4, 6, 8, 10]
+
+
+def _c5_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from metabox_amd.distributed import gather_rows, pack_rows, partition_bounds, unpack_rows
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ps, pidx = _c5_table()
+    bounds = partition_bounds(ps, pidx, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    full = gather_rows(pack_rows(_fake_results(lo, hi)), len(pidx), bounds=bounds)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in unpack_rows(full).items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cost_weighted_shards_gather_to_the_unsharded_table_world8():
+    """gloo, world size 8, config 5's table: shards of unequal size (cost-weighted) gather to exactly the unsharded table in global-id order."""
+    from metabox_amd.distributed import pack_rows, unpack_rows
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_c5_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    want = unpack_rows(pack_rows(_fake_results(0, 65536)))
+    for k in want:
+        assert np.array_equal(got[k], want[k].numpy()), k

@@ -321,7 +321,7 @@ def test_fused_act_step_equals_policy_then_step():
     env_a.close(); env_b.close()
 
 
-def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None):
+def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None, resident=True):
     """One resident launch per chunk (mbx_rlepso_rollout) against one mbx_rlepso_act_step launch per generation on a twin batch:
     whole state blocks, trajectories and result tables must agree bit for bit."""
     from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
@@ -341,6 +341,9 @@ def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None):
     a = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50)
     b = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50)
     table = a.policy_table(*net)
+    assert a.rollout_is_resident() == resident                      # the route mbx_rlepso_rollout takes is not silent (mbx_rlepso_rollout_resident)
+    with pytest.raises(ValueError):
+        a.rlepso_rollout(table[:-1].contiguous(), 1)                # a table with too few rows would be read out of bounds on the device
     a.reset(); b.reset()
     for n in chunks:
         st, rw, dn, traj = a.rlepso_rollout(table, n, trajectory=True)
@@ -418,9 +421,9 @@ def test_resident_rollout_config5_geometry_and_host_loop_route(monkeypatch):
     ps40 = (1, 8, 15, 21)
     _rollout_case('bbob', 40, ps40, 128, 8, (2, 5), maxfes=80000)
     _rollout_case('bbob', 30, (1, 7, 16, 22), 100, 8, (3, 9), maxfes=60000)          # k_rlepso_run<512, 100, 30, 5>
-    _rollout_case('bbob', 10, (1, 16), 60, 8, (3, 4))
-    monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')
-    _rollout_case('bbob', 10, (1, 21), 100, 8, (5, 2))
+    _rollout_case('bbob', 10, (1, 16), 60, 8, (3, 4), resident=False)
+    monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')           # read when the batch is created
+    _rollout_case('bbob', 10, (1, 21), 100, 8, (5, 2), resident=False)
 
 
 def test_config5_shape_np128_dim40_mixed_suites():
@@ -646,3 +649,47 @@ def test_rebind_and_read_public_equal_a_fresh_batch(env):
         n = int(pub[oracle.SC_COST_LEN])
         assert np.array_equal(pub[:16], full[:16]) and np.array_equal(pub[16:16 + n], full[16:16 + n])
     reused.close(); fresh.close()
+
+
+def test_move_phase_draws_are_uniform():
+    """the element-wise uniforms of the move phase are 32-bit (a / 2^32) and the oracle draws them the same way, so oracle parity cannot
+    see a distribution error.  This test does not use the oracle: it reads the kernel-side conversion (mbx_debug_rlepso_draws = rl_move's own
+    code path) for many (seed, generation) pairs and tests it against U(0, 1) / the discrete uniform on [0, NP) the reference draws from
+    (np.random.rand / np.random.randint, src/optimizer/rlepso_optimizer.py:76-109)."""
+    import ctypes as C
+    from scipy import stats
+    from metabox_amd import _abi
+    lib = _abi.load_lib()
+    out = torch.empty(NP * D, 4, dtype=torch.float64, device='cuda')
+    chunks = []
+    for k in range(200):                                            # 200 (seed, generation, episode) triples x 1000 elements
+        _abi.check(lib.mbx_debug_rlepso_draws(C.c_uint64(1000003 * k + 17), 1 + k % 199, 1 + k // 50, NP, D, C.c_void_p(out.data_ptr()), None))
+        torch.cuda.synchronize()
+        chunks.append(out.cpu().numpy().copy())
+    v = np.concatenate(chunks)                                      # [200000, 4]
+    n = len(v)
+    for col, name in ((0, 'CLPSO uniform'), (1, 'FDR weight')):
+        u = v[:, col]
+        assert u.min() >= 0 and u.max() < 1, name
+        assert abs(u.mean() - 0.5) < 4 * np.sqrt(1 / 12 / n), (name, u.mean())                   # 4 sigma
+        assert abs(u.var() - 1 / 12) < 4 * np.sqrt(1 / 180 / n), (name, u.var())                 # Var(U^2-ish estimator) = 1/180 n
+        assert stats.kstest(u, 'uniform').pvalue > 1e-4, name
+        assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 4 / np.sqrt(n), name                       # neighbours in the stream
+        # the mask P(u <= pci) that CLPSO takes from it (pci in [0.05, 0.5]) is right at the small end too, where 32 vs 53 bits would show first
+        for p in (0.05, 0.001):
+            k = (u <= p).sum()
+            assert abs(k - n * p) < 5 * np.sqrt(n * p * (1 - p)), (name, p, k)
+    assert abs(np.corrcoef(v[:, 0], v[:, 1])[0, 1]) < 4 / np.sqrt(n)                             # the two uniforms of one element
+    # distinct values: 32-bit draws from a 200 000-sample set collide ~ n^2 / 2^33 = 4.7 times; 24-bit or worse would collide thousands of times
+    assert n - len(np.unique(v[:, 0])) < 40
+    for col in (2, 3):
+        t = v[:, col]
+        assert np.all(t == np.floor(t)) and t.min() >= 0 and t.max() <= NP - 1
+        cnt = np.bincount(t.astype(np.int64), minlength=NP)
+        assert stats.chisquare(cnt).pvalue > 1e-4, (col, cnt.min(), cnt.max())
+    both = v[:, 2].astype(np.int64) * NP + v[:, 3].astype(np.int64)                                # the pair is uniform on [0, NP)^2
+    assert stats.chisquare(np.bincount(both, minlength=NP * NP)).pvalue > 1e-4
+    # numpy's own generator passes the same battery (the thresholds are not vacuous or over-tight)
+    rs = np.random.RandomState(0)
+    u = rs.rand(n)
+    assert stats.kstest(u, 'uniform').pvalue > 1e-4 and stats.chisquare(np.bincount(rs.randint(0, NP, n), minlength=NP)).pvalue > 1e-4
