@@ -296,7 +296,7 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
             for (int k = 0; k < d.n_peaks; ++k)
                 for (int r = 0; r < D; ++r) {
                     double acc = 0.;
-                    for (int j = 0; j < D; ++j) acc += d.m1[(size_t)r * D + j] * d.py[(size_t)k * D + j];
+                    for (int j = 0; j < D; ++j) acc = std::fma(d.m1[(size_t)r * D + j], d.py[(size_t)k * D + j], acc);   // the kernels' matvec chain
                     ry[(size_t)k * D + r] = acc;
                 }
             o.o[9] = push(ry.data(), NA * D);

@@ -295,7 +295,11 @@ __device__ __forceinline__ void stage_problem(const PT& P, const EvalLds& L)
     }
 }
 
-// Out[i][d] = sum_k M[d][k] * (In[i][k] - sub[k])   (sr_func, bbob.py:6-8: shift, then the matmul), k ascending, no FMA contraction.
+// Out[i][d] = sum_k M[d][k] * (In[i][k] - sub[k])   (sr_func, bbob.py:6-8: shift, then the matmul) as ONE fused multiply-add per term:
+// acc = +0; acc = fma(M[d][k], y_k, acc) for k ascending.  Every matvec variant below (and the CPU oracle) evaluates exactly this chain, so
+// they stay bit-identical to each other; it is also, bit for bit, what v_mfma_f64_16x16x4_f64 computes (tools/ubench/mfma_f64_probe.hip:
+// 76 800 outputs, K = 12 chained, none differs), and the reference's np.matmul is FMA-based BLAS itself.  Half the instructions of the
+// separate multiply + add of rounds 1-2.
 // sub == nullptr: plain matvec.  Subtracting inside the product loop instead of in a pass of its own saves a barrier interval per
 // evaluation (in the short phases of the generation kernels an interval costs more than the NP*D subtractions repeated per output pair).
 template <bool SUB>
@@ -305,7 +309,7 @@ __device__ __forceinline__ void matvec_rows_impl(const double* MT, const double*
     if ((D & 1) == 0) {
         // Register tile of 2 rows x 2 dimensions per thread: the plain loop below reads 16 bytes of LDS per multiply-add (M[d][k] and
         // In[i][k]) and is LDS-bandwidth bound (128 B/clk per CU feed 8 MAC/clk, the four SIMDs could issue 32); the tile reads one
-        // 16-byte pair of M and two row values per four multiply-adds, 8 bytes each.  Every output keeps its own k-ascending sum.
+        // 16-byte pair of M and two row values per four multiply-adds, 8 bytes each.  Every output keeps its own k-ascending fma chain.
         const int HD = D >> 1, tiles = ((n + 1) >> 1) * HD;
         const FastDiv fh(HD);
         for (int t = tid0; t < tiles; t += MBX_NT) {
@@ -320,7 +324,7 @@ __device__ __forceinline__ void matvec_rows_impl(const double* MT, const double*
                 const double m0 = col[k * D], m1 = col[k * D + 1];
                 double y0 = r0[k], y1 = r1[k];
                 if (SUB) { const double sh = sub[k]; y0 = y0 - sh; y1 = y1 - sh; }
-                s00 += m0 * y0; s01 += m1 * y0; s10 += m0 * y1; s11 += m1 * y1;
+                s00 = __builtin_fma(m0, y0, s00); s01 = __builtin_fma(m1, y0, s01); s10 = __builtin_fma(m0, y1, s10); s11 = __builtin_fma(m1, y1, s11);
             }
             Out[i0 * D + d] = s00; Out[i0 * D + d + 1] = s01;
             if (two) { Out[(i0 + 1) * D + d] = s10; Out[(i0 + 1) * D + d + 1] = s11; }
@@ -335,7 +339,7 @@ __device__ __forceinline__ void matvec_rows_impl(const double* MT, const double*
         const double* col = MT + d;
         double s = 0.;
 #pragma unroll 5
-        for (int k = 0; k < D; ++k) s += col[k * D] * (SUB ? row[k] - sub[k] : row[k]);
+        for (int k = 0; k < D; ++k) s = __builtin_fma(col[k * D], SUB ? row[k] - sub[k] : row[k], s);
         Out[e] = s;
     }
 }
@@ -347,7 +351,7 @@ __device__ __forceinline__ void matvec_rows_shifted(const double* MT, const doub
 // against 6.4 k of VALU issue):  lane = row, the row's MD values live in registers, a wave owns a block of consecutive outputs d of one
 // 64-row group, and M[d][k] -- wave-uniform -- is read straight from the problem's row-major map in global memory through the constant
 // address space, i.e. as scalar loads into SGPRs that v_mul_f64 takes as an operand.  No LDS read in the inner loop, no LDS copy of the
-// maps at all.  Each output keeps its own k-ascending sum of separate multiplies and adds: bit-identical to matvec_rows_impl.
+// maps at all.  Each output keeps its own k-ascending fma chain: bit-identical to matvec_rows_impl.
 template <int MD, bool SUB>
 __device__ __forceinline__ void matvec_rows_scalar(const double* __restrict__ Mg, const double* In, const double* sub, int n, double* Out)
 {
@@ -373,14 +377,14 @@ __device__ __forceinline__ void matvec_rows_scalar(const double* __restrict__ Mg
         const kptr row = M + d * MD;
         double acc = 0.;
 #pragma unroll
-        for (int k = 0; k < MD; ++k) acc += row[k] * y[k];
+        for (int k = 0; k < MD; ++k) acc = __builtin_fma(row[k], y[k], acc);
         if (i < n) Out[i * MD + d] = acc;
     }
 }
 
 // The same scheme for kernels with a tight register budget (k_lde_step<512, 50, 30>: 80 VGPRs): the row is taken in chunks of KC values and up to
-// UMAX outputs of the wave are accumulated side by side, so 2 KC + 2 UMAX registers replace the 2 MD of matvec_rows_scalar.  Every output still adds
-// its products in ascending k: bit-identical.
+// UMAX outputs of the wave are accumulated side by side, so 2 KC + 2 UMAX registers replace the 2 MD of matvec_rows_scalar.  Every output still runs
+// its fma chain in ascending k: bit-identical.
 template <int MD, bool SUB, int KC, int UMAX>
 __device__ __forceinline__ void matvec_rows_scalar_kc(const double* __restrict__ Mg, const double* In, const double* sub, int n, double* Out)
 {
@@ -412,7 +416,7 @@ __device__ __forceinline__ void matvec_rows_scalar_kc(const double* __restrict__
                     if (j < cnt) {
                         const kptr row = M + (d0 + j) * MD + c;
 #pragma unroll
-                        for (int k = 0; k < KC; ++k) acc[j] += row[k] * y[k];
+                        for (int k = 0; k < KC; ++k) acc[j] = __builtin_fma(row[k], y[k], acc[j]);
                     }
                 }
             }
@@ -439,10 +443,18 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 }
 
 // Protein-docking energy (src/problem/protein_docking.py:28-48) of n individuals X[n][D] -> F[n].  The individuals
-// are processed one after the other; for each, the 3n displaced coordinates are built cooperatively in LDS, then the
-// n^2 atom pairs are spread over the block (pair index == address in the [n,n] tables: coalesced L2 reads) and the
-// energy mean_j sum_i term_ij = (sum of all terms)/n is reduced with wave shuffles.
+// are processed one after the other; for each, the 3n displaced coordinates are built cooperatively in LDS, then the atom pairs are
+// spread over the block and the energy mean_j sum_i term_ij = (sum of all terms) / n is reduced with wave shuffles.
 // P.v0 = 1/sqrt(eigval), P.py = basis [D,3n], P.pc = coor_init [3n], P.pw = sqrt(e) | q | r tables.
+//
+// Only the pairs i < j are visited.  The three tables are symmetric by construction (protein_docking.py:175-181: q = q^T q, e = sqrt(e^T e),
+// r = (r + r^T) / 2) and so is the distance, hence term_ij = term_ji; on the diagonal the distance is sqrt(0.01) = 0.1, outside both
+// distance windows (0.11, 7) and (7, 9), so term_ii = 0 exactly.  The sum over all n^2 pairs is therefore 2 x the sum over the n (n - 1) / 2
+// pairs above the diagonal (the doubling is exact) -- 4950 instead of 10^4 pair terms at n = 100.  Pair index t of the folded rectangle
+// ceil(n / 2) x (n - 1): row a holds the n - 1 - a pairs of atom a followed by the a pairs of atom n - 1 - a.
+// sqrt and the two divisions by the distance (the reference's `r / pair_dis` and `q / (4 pair_dis)`) come from ONE v_rsq_f64 estimate:
+// two coupled Goldschmidt steps give sqrt(s) and 1 / (2 sqrt(s)), one residual correction each brings both to <= 1 ulp -- 13 instructions
+// instead of a library sqrt and two IEEE divisions (~70).  The energy is pinned at 1e-9 relative against the reference's own outputs.
 template <int DC = 0, class PT = DevProblem>
 __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
 {
@@ -453,6 +465,8 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
     const double* __restrict__ se = P.pw;
     const double* __restrict__ qm = P.pw + (size_t)n * n;
     const double* __restrict__ rm = P.pw + 2 * (size_t)n * n;
+    const int W = n - 1, n_pairs = ((n + 1) >> 1) * W;
+    const FastDiv fw(W);
     for (int r = 0; r < n_rows; ++r) {
         const double* x = L.X + r * D;
         for (int m = tid; m < m3; m += MBX_NT) {
@@ -465,19 +479,37 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
             P2[i] = COOR[3 * i] * COOR[3 * i] + COOR[3 * i + 1] * COOR[3 * i + 1] + COOR[3 * i + 2] * COOR[3 * i + 2];
         __syncthreads();
         double acc = 0.;
-        for (int w = tid; w < n * n; w += MBX_NT) {
-            const int i = w / n, j = w - i * n;
+        for (int t = tid; t < n_pairs; t += MBX_NT) {
+            const int a = fw.div(t), b = t - a * W, La = W - a;
+            const bool lower = b >= La;                            // second part of the folded row: the pairs of atom n - 1 - a
+            const int i = lower ? W - a : a, j = i + 1 + (lower ? b - La : b);
+            if (lower && i == a) continue;                         // odd n: the middle atom's pairs are all in the first part
             const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
-            double pd = sqrt(P2[i] - 2 * p3 + P2[j] + 0.01);
-            const double m1 = (pd > 0.11 && pd < 7.0) ? 1. : 0., m2 = (pd > 7.0 && pd < 9.0) ? 1. : 0.;
-            if (i == j) pd += 1.;
-            const double rr = rm[w] / pd;
+            const double s = P2[i] - 2 * p3 + P2[j] + 0.01;        // >= 0.01 up to rounding: always a positive normal number
+            double g, h;
+            {
+                const double y = __builtin_amdgcn_rsq(s);
+                g = s * y; h = 0.5 * y;
+                double e = __builtin_fma(-h, g, 0.5);
+                g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+                e = __builtin_fma(-h, g, 0.5);
+                g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+                g = __builtin_fma(__builtin_fma(-g, g, s), h, g);  // sqrt(s) + (s - g^2) / (2 sqrt(s))
+            }
+            const double pd = g;
+            double inv = h + h;
+            inv = __builtin_fma(inv, __builtin_fma(-pd, inv, 1.0), inv);                       // 1 / pd
+            const int w = i * n + j;
+            const double rr = rm[w] * inv;
             const double r2 = rr * rr, r6 = r2 * r2 * r2;
-            const double coeff = qm[w] / (4. * pd) + se[w] * (r6 * r6 - r6);
-            acc += 10 * m1 * coeff + 10 * m2 * coeff * ((9 - pd) * (9 - pd) * (-12 + 2 * pd) / 8);
+            const double coeff = qm[w] * (0.25 * inv) + se[w] * (r6 * r6 - r6);
+            const bool near = pd > 0.11 && pd < 7.0, far = pd > 7.0 && pd < 9.0;
+            const double sw = (9 - pd) * (9 - pd) * (-12 + 2 * pd) * 0.125;
+            const double c10 = 10 * coeff;
+            acc += near ? c10 : (far ? c10 * sw : 0.);
         }
         const double total = block_sum(acc, RED);
-        if (tid == 0) L.F[r] = total / n;
+        if (tid == 0) L.F[r] = (2 * total) / n;
     }
     __syncthreads();
 }
@@ -709,12 +741,25 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     if (kind == 15 || kind == 24) {
         for (int e = tid; e < NE; e += MBX_NT) T[e] = m_cos(kTwoPi * Z[e]);
     } else if (kind == 16) {                                        // Weierstrass series, bbob.py:623
+        // sum_k 0.5^k cos(3^k b), b = 2 pi (z + 0.5): the twelve cosines are one (cos b, sin b) pair and eleven complex cubes
+        //   (c + i s)^3:  c' = c (c^2 - 3 s^2),  s' = s (3 c^2 - s^2)
+        // -- 7 instructions per term instead of a range reduction + 21st-order polynomial each (~35).  The cube triples the angle error and the
+        // radius error of the pair per step (the one-square forms cos 3a = cos a (1 - 4 sin^2 a) amplify a radius error 9x per step and end at
+        // 2e-10): 3^11 x 1e-16 = 2e-11 at the last term, whose weight is 0.5^11 -- 3e-14 absolute in the sum against an extended-precision
+        // evaluation.  The reference rounds the ARGUMENT 3^k b of each cosine (up to 5.5e6 rad at k = 11, half an ulp = 5e-10 rad): its own sum is
+        // 5.6e-13 off the same exact value, which is the distance between the two routes; the KATs pin the function at 1e-10 relative.
         for (int e = tid; e < NE; e += MBX_NT) {
             const double base = kTwoPi * (Z[e] + 0.5);
-            double s = 0., ak = 1., bk = 1.;
-#pragma unroll 1
-            for (int k = 0; k < 12; ++k) { s += ak * m_cos(base * bk); ak *= 0.5; bk *= 3.; }
-            T[e] = s;
+            double c = m_cos(base), s = m_sin(base), sum = c, ak = 1.;
+#pragma unroll
+            for (int k = 1; k < 12; ++k) {
+                const double c2 = c * c, s2 = s * s;
+                c = c * __builtin_fma(-3., s2, c2);
+                s = s * __builtin_fma(3., c2, -s2);
+                ak *= 0.5;                                          // compile-time constant after unrolling
+                sum = __builtin_fma(ak, c, sum);                    // 0.5^k c is exact: the same value as sum + ak * c
+            }
+            T[e] = sum;
         }
     } else if (kind == 17 || kind == 18) {                          // Schaffers, bbob.py:642-643
         for (int e = tid; e < NE; e += MBX_NT) {

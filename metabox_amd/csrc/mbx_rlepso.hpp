@@ -763,8 +763,9 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
     const FastDiv fg(per_group), fh(HD);
     int* ORDER = L.IMPR;          // free until the first commit of a generation
     int* NLESS = L.MASK;
-    int* RANK = L.RANK;           // doubles as the nle accumulator
+    int* RANK = L.RANK;
     float* ACT = (float*)L.R1;    // sampled action; R1 is not written before the ranking barrier
+    int* TIE = (int*)(L.RED + 14);  // equal-cost flag of the ranking (block_argmin uses RED[0..1] only)
 
     // pbest / gbest bookkeeping of update() and __reinit() (rl_commit with c_cost and the pbest positions in registers)
     auto commit = [&](bool stagnation, int tid) {
@@ -809,7 +810,8 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
             ACT[tid] = a;
             if (out.traj_actions) out.traj_actions[((int64_t)g * B + b) * A + tid] = a;
         }
-        if (tid < NP) { RANK[tid] = 0; NLESS[tid] = 0; ORDER[tid] = tid; }
+        if (tid < NP) { NLESS[tid] = 0; ORDER[tid] = tid; }
+        if (tid == 0) *TIE = 0;
         __syncthreads();
         if (tid < G) {                                            // __get_coe (:112-132), float32 like k_rlepso_step
             const float* a = ACT + tid * G;
@@ -824,25 +826,26 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
             c[2] = (double)(scale * a[3]); c[3] = (double)(scale * a[4]);
             c[4] = (double)(scale * a[5]); c[5] = (double)(scale * a[6]);
         }
-        // ---- rank the particles by (pbest cost, index), see k_rlepso_step
+        // ---- rank the particles by (pbest cost, index).  k_rlepso_step counts, per pair, both `<` and `<=` so that equal costs can be ordered
+        // by index; here only the strictly better particles are counted (ONE compare per pair: half the ranking's instructions) and the rank is
+        // that count.  Two particles with exactly the same pbest cost then claim the same slot of ORDER: the one that lost the slot sees it
+        // (ORDER[rank] != i), raises the workgroup's TIE flag, and the workgroup -- uniformly -- redoes the per-particle step with the index
+        // tie-break and restages the rows.  Same ranks as k_rlepso_step in every case; the slow path only runs for instances that really hold
+        // equal costs (collapsed swarms on F5 / F7 plateaus).
         {
             constexpr int parts = THREADS / NP > 0 ? THREADS / NP : 1;
             for (int w = tid; w < parts * NP; w += THREADS) {
                 const int part = w / NP, i = w - part * NP;
                 const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
                 const double fi = L.PBC[i];
-                int nle = 0, nless = 0;
+                int nless = 0;
 #ifndef MBX_ABLATE_RANK
-#pragma unroll 4
-                for (int j = j0; j < j1; ++j) {
-                    const double fj = L.PBC[j];
-                    nless += fj < fi;
-                    nle += fj <= fi;
-                }
+#pragma unroll 5
+                for (int j = j0; j < j1; ++j) nless += L.PBC[j] < fi;
 #else
-                if (part == 0) { nle = i + 1; nless = i; }
+                if (part == 0) nless = i;
 #endif
-                atomicAdd(&RANK[i], nle); atomicAdd(&NLESS[i], nless);
+                atomicAdd(&NLESS[i], nless);
             }
         }
         __syncthreads();
@@ -851,21 +854,35 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
             L.CMUT[i] = gi < G ? L.COEF[gi * 6] * L.PNI[i] : 0.;
             const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART);
             L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w);
-            const double fi = L.PBC[i];
-            int rank = NLESS[i];
-            if (RANK[i] - rank > 1)
-                for (int j = 0; j < i; ++j) rank += L.PBC[j] == fi;
+            const int rank = NLESS[i];
             RANK[i] = rank;
-            ORDER[rank] = i; L.NC[rank] = fi;
+            ORDER[rank] = i; L.NC[rank] = L.PBC[i];
         }
         __syncthreads();
+        if (tid < NP && ORDER[RANK[tid]] != tid) *TIE = 1;
         // ---- pbest positions -> LDS in rank order, from the owners' registers
+        auto stage_pbest = [&](int tid) {
 #pragma unroll
-        for (int j = 0; j < IT; ++j) {
-            const int it = tid + j * THREADS;
-            if (it < NI) { const int i = fh.div(it), d0 = 2 * (it - i * HD); *(double2*)(L.PB + RANK[i] * D + d0) = double2{pbp[j][0], pbp[j][1]}; }
-        }
+            for (int j = 0; j < IT; ++j) {
+                const int it = tid + j * THREADS;
+                if (it < NI) { const int i = fh.div(it), d0 = 2 * (it - i * HD); *(double2*)(L.PB + RANK[i] * D + d0) = double2{pbp[j][0], pbp[j][1]}; }
+            }
+        };
+        stage_pbest(tid);
         __syncthreads();
+        if (*TIE) {                                               // workgroup-uniform: equal pbest costs exist, order them by index
+            int rank = 0;
+            if (tid < NP) {
+                const double fi = L.PBC[tid];
+                rank = NLESS[tid];
+                for (int j = 0; j < tid; ++j) rank += L.PBC[j] == fi;
+            }
+            __syncthreads();                                      // every thread has read TIE and the fast path's tables
+            if (tid < NP) { RANK[tid] = rank; ORDER[rank] = tid; L.NC[rank] = L.PBC[tid]; }
+            __syncthreads();
+            stage_pbest(tid);
+            __syncthreads();
+        }
         // ---- FDR exemplars -> KB (see k_rlepso_step)
 #ifdef MBX_ABLATE_FDR
         for (int e = tid; e < NP * D; e += THREADS) L.KB[e] = 0;

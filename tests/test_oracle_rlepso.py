@@ -56,7 +56,9 @@ def test_oracle_replays_reference_episode(case):
     assert np.array_equal(rows[:m, 3].astype(bool), TR[f'{case}/done'][:m])
     if m == len(rows):
         assert np.array_equal(st['pni'], TR[f'{case}/final_pni'])
-        assert np.abs(st['pos'].reshape(100, 10) - TR[f'{case}/final_pos']).max() <= 1e-12
+        # positions after 199 generations: the matvec is an fma chain here and BLAS (its own blocking) in the reference, 1e-16 apart per
+        # evaluation; a PSO amplifies that (bbob/15/2, two maps per evaluation: 2.7e-11 with every branch still identical to the reference's)
+        assert np.abs(st['pos'].reshape(100, 10) - TR[f'{case}/final_pos']).max() <= 1e-9
         assert close(st['pbest'], TR[f'{case}/final_pbest'], rtol=1e-9)
 
 
