@@ -217,6 +217,19 @@ typedef struct mbx_lstm_policy {
 int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state, float* d_h, float* d_c, float* d_actions,
                    float* d_mu_sigma, void* stream);
 
+/* DE-DDQN's greedy action for the whole batch in ONE launch (src/agent/de_ddqn_agent.py:59-68, 108-117: `action = argmax Q(state)`;
+ * Q = the ReLU MLP of :26-36 / src/agent/networks.py:4-26, in_dim -> width x depth -> n_act) on the float32 matrix cores
+ * (v_mfma_f32_16x16x4_f32: one float32 fma chain per unit, k ascending, starting at the bias).  Only the reference's architecture is
+ * built: in_dim 99, width 100, depth 4, n_act 4 (MBX_E_UNSUPPORTED otherwise; callers keep their PyTorch route for other shapes).
+ * d_weights (float32): for every layer of the torch module in order, the weight TRANSPOSED, Wt [in][out] row-major, then the bias [out].
+ * d_state [n_instances, in_dim] float64 (what mbx_reset / mbx_step wrote) -> d_actions [n_instances] int32, ready for mbx_step (first
+ * maximum, like torch.argmax); d_q, if not NULL, receives the Q values [n_instances, n_act] float32. */
+typedef struct mbx_qnet {
+    const float* d_weights;
+    int32_t in_dim, width, depth, n_act;
+} mbx_qnet;
+int mbx_ddqn_qnet(mbx_batch* b, const mbx_qnet* net, const double* d_state, int32_t* d_actions, float* d_q, void* stream);
+
 /* The agent's act() and the environment's step() in ONE launch (the loop body of RLEPSO_Agent.rollout_episode,
  * src/agent/rlepso_agent.py:294-303: `action = actor(state); state, reward, done = env.step(action)`).
  * RLEPSO's state is the scalar fes/maxFEs (rlepso_optimizer.py:170-171) and fes is an integer, so the actor's (mu, sigma)

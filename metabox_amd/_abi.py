@@ -43,6 +43,11 @@ class LstmPolicy(C.Structure):
     _fields_ = [('d_weights', C.c_void_p), ('in_dim', C.c_int32), ('hidden', C.c_int32), ('out_dim', C.c_int32)]
 
 
+class QNet(C.Structure):
+    """mbx_qnet"""
+    _fields_ = [('d_weights', C.c_void_p), ('in_dim', C.c_int32), ('width', C.c_int32), ('depth', C.c_int32), ('n_act', C.c_int32)]
+
+
 class GleetActor(C.Structure):
     """mbx_gleet_actor"""
     _fields_ = [('d_weights', C.c_void_p), ('n_floats', C.c_int32), ('min_sigma', C.c_float), ('max_sigma', C.c_float)]
@@ -125,6 +130,7 @@ def load_lib():
         'mbx_results': (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
         'mbx_gauss_policy': (C.c_int, [vp, C.POINTER(GaussMlp), vp, vp, vp, vp]),
         'mbx_lde_policy': (C.c_int, [vp, C.POINTER(LstmPolicy), vp, vp, vp, vp, vp, vp]),
+        'mbx_ddqn_qnet': (C.c_int, [vp, C.POINTER(QNet), vp, vp, vp, vp]),
         'mbx_rlepso_policy_table_rows': (C.c_int, [vp]),
         'mbx_rlepso_policy_table': (C.c_int, [vp, C.POINTER(GaussMlp), vp, vp]),
         'mbx_rlepso_act_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
@@ -153,7 +159,7 @@ def load_lib():
 
 EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval',
                     'mbx_state_dim', 'mbx_action_dim', 'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy',
-                    'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results', 'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_rlepso_policy_table_rows',
+                    'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results', 'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_ddqn_qnet', 'mbx_rlepso_policy_table_rows',
                     'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlepso_rollout_resident', 'mbx_rlepso_rollout', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_debug_math', 'mbx_debug_rlepso_draws', 'mbx_batch_launch_info', 'mbx_instance_state_doubles',
                     'mbx_debug_read_state', 'mbx_batch_rebind', 'mbx_read_public', 'mbx_last_error', 'mbx_version')
 

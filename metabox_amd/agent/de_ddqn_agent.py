@@ -87,6 +87,20 @@ class DE_DDQN_Agent(Basic_Agent):
             return int(np.random.randint(low=0, high=self.__config.n_act))
         return int(torch.argmax(q))
 
+    def packed_weights(self):
+        """float32 CUDA tensor in the layout ``mbx_qnet`` documents (include/mbx.h): per Linear layer the weight transposed, Wt [in][out], then
+        the bias.  Rebuilt on every call (the network is 40 k parameters); callers that roll out with fixed weights keep the tensor."""
+        parts = []
+        for m in self.__pred_func.net:
+            if isinstance(m, torch.nn.Linear):
+                parts += [m.weight.detach().t().contiguous().reshape(-1), m.bias.detach().reshape(-1)]
+        return torch.cat(parts).to(torch.float32).contiguous()
+
+    def qnet_shape(self):
+        """(in_dim, width, depth, n_act) of the Q-network."""
+        lin = [m for m in self.__pred_func.net if isinstance(m, torch.nn.Linear)]
+        return lin[0].in_features, lin[0].out_features, len(lin) - 1, lin[-1].out_features
+
     @torch.no_grad()
     def greedy_batch(self, states):
         """Greedy operator choice for a batch of states [B, 99] -> int32 [B] (argmax Q, de_ddqn_agent.py:59-68,108-117)."""
@@ -100,17 +114,23 @@ class DE_DDQN_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': total}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, graph=False):
-        """Lock-step rollout: greedy action of the Q-network for the whole batch, then the fused DE-DDQN step kernel.  ``graph=True``
-        captures the Q-network forward (5 small GEMMs + element-wise ops) once into a hipGraph that reads the batch's persistent
-        state tensor and replays it every step; measured on config 4's share it is not faster than the eager ops (181 vs 175 us per
-        step: the step is bound by GPU time, not by launches), so eager stays the default."""
+    def rollout_batch(self, env, max_steps=None, graph=False, policy='hip'):
+        """Lock-step rollout: greedy action of the Q-network for the whole batch, then the fused DE-DDQN step kernel.
+        policy = 'hip' (default): the Q-network + argmax as ONE launch on the float32 matrix cores (``mbx_ddqn_qnet``, reads the batch's own
+        state tensor); 'torch': the PyTorch module (5 small GEMMs + element-wise launches; also what any non-reference architecture uses).
+        ``graph=True`` captures the PyTorch forward once into a hipGraph and replays it every step (round 2: not faster than eager)."""
         if max_steps is None:
             bc = env.batch.cfg
             max_steps = bc.max_fes - bc.np                # one evaluation per step
         state = env.reset()
 
         greedy_of = self.greedy_batch
+        if policy == 'hip' and not graph and self.qnet_shape() == (99, 100, 4, 4) and state.is_cuda:
+            packed = self.packed_weights()
+            for _ in range(max_steps):
+                env.step(env.batch.ddqn_qnet(packed))
+            res = env.results()
+            return {k: res[k] for k in ('cost', 'fes', 'return', 'steps', 'cost_len')}
 
         replay, static_action = None, None
         if graph:

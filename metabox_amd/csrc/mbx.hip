@@ -18,6 +18,7 @@
 #include "mbx_rs.hpp"
 #include "mbx_policy.hpp"
 #include "mbx_lstm_policy.hpp"
+#include "mbx_qnet.hpp"
 #include "mbx_rlpso.hpp"
 #include "mbx_gleet.hpp"
 #include "mbx_qlpso.hpp"
@@ -738,6 +739,21 @@ extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const do
     const LstmPolicy g{net->d_weights, net->in_dim, net->hidden, net->out_dim};
     hipLaunchKernelGGL(k_lstm_policy, dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
                        d_state, d_h, d_c, d_actions, d_mu_sigma);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_ddqn_qnet(mbx_batch* b, const mbx_qnet* net, const double* d_state, int32_t* d_actions, float* d_q, void* stream)
+{
+    if (!b || !net || !net->d_weights || !d_state || !d_actions) return fail(MBX_E_ARG, "mbx_ddqn_qnet: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_DEDDQN) return fail(MBX_E_UNSUPPORTED, "mbx_ddqn_qnet: the batch is not a DE-DDQN batch");
+    if (net->in_dim != b->state_dim) return fail(MBX_E_ARG, "mbx_ddqn_qnet: the network reads %d features, the batch writes %d", net->in_dim, b->state_dim);
+    if (net->in_dim != 99 || net->width != 100 || net->depth != 4 || net->n_act != 4)
+        return fail(MBX_E_UNSUPPORTED, "mbx_ddqn_qnet: only the reference architecture 99 -> 100 x 4 -> 4 is built (got %d -> %d x %d -> %d)",
+                    net->in_dim, net->width, net->depth, net->n_act);
+    const QNet g{net->d_weights, net->in_dim, net->width, net->depth, net->n_act};
+    hipLaunchKernelGGL((k_qnet_argmax<99, 100, 4>), dim3((b->B + kQTile - 1) / kQTile), dim3(kThreads), 0, (hipStream_t)stream, g, d_state, d_actions,
+                       d_q, b->B);
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }

@@ -189,6 +189,21 @@ class Batch:
                                               _ptr(self.done), _stream()))
         return (self.state, self.reward, self.done, acts) if want_actions else (self.state, self.reward, self.done)
 
+    def ddqn_qnet(self, weights, width=100, depth=4, n_act=4, want_q=False):
+        """DE-DDQN's greedy action over the batch's own state tensor in one launch (``mbx_ddqn_qnet``: the Q-network on the float32
+        matrix cores).  weights: packed float32 CUDA tensor (``DE_DDQN_Agent.packed_weights``: per layer Wt [in][out], b [out]).
+        Returns the int32 [B] action tensor (overwritten by the next call)[, Q values [B, n_act]]."""
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        need = self.state_dim * width + width + (depth - 1) * (width * width + width) + width * n_act + n_act      # qnet_floats (mbx_qnet.hpp)
+        if weights.numel() != need:
+            raise ValueError(f'packed Q-network has {weights.numel()} floats, {self.state_dim} -> {width} x {depth} -> {n_act} needs {need}')
+        if getattr(self, '_iactions', None) is None:
+            self._iactions = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        q = torch.empty(self.B, n_act, dtype=torch.float32, device=self.device) if want_q else None
+        net = _abi.QNet(weights.data_ptr(), self.state_dim, int(width), int(depth), int(n_act))
+        _abi.check(self.lib.mbx_ddqn_qnet(self._h, C.byref(net), _ptr(self.state), _ptr(self._iactions), _ptr(q), _stream()))
+        return (self._iactions, q) if want_q else self._iactions
+
     def lde_policy(self, weights, hidden, h, c, want_mu_sigma=False, sample=True):
         """LDE's PolicyNet in one launch (``mbx_lde_policy``): reads the batch's own state tensor, updates h / c [B, hidden] (float32,
         contiguous) in place, returns the actions [B, 2 NP] (float32; None when ``sample`` is False)[, mu_sigma [B, 2, 2 NP]]."""

@@ -100,6 +100,43 @@ def test_ddqn_qnet_reproduces_reference_io_on_gpu():
 
 
 @pytest.mark.gpu
+def test_ddqn_qnet_kernel_reproduces_reference_io():
+    """mbx_ddqn_qnet (Q-network + argmax in one launch on the float32 matrix cores, what rollout_batch uses) on the reference module's recorded
+    (state -> Q) pairs and against the PyTorch module on a ragged batch (B not a multiple of the 16-instance tile).  Tolerance 1e-5 like the
+    module test: float32, every unit is one fma chain in k order instead of torch's GEMM tiling."""
+    from metabox_amd._abi import ALGO_DEDDQN, MbxError
+    from metabox_amd.suite import Batch, Suite
+    from helpers import problems
+    agent, pol = _check_ddqn_forward('cuda')
+    ps = problems('bbob', 10)
+    suite = Suite([ps[k] for k in sorted(ps)])
+    packed = agent.packed_weights()
+    assert agent.qnet_shape() == (99, 100, 4, 4)
+    want = pol['io/q']
+    for B, src in ((len(want), 'golden'), (37, 'torch'), (2240, 'torch')):
+        batch = Batch(suite, ALGO_DEDDQN, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, 100, 20000, 400, 50)
+        batch.reset()
+        if src == 'golden':
+            batch.state.copy_(torch.from_numpy(pol['io/x']).cuda().to(batch.state.dtype))
+            ref_q = want
+        else:
+            with torch.no_grad():
+                ref_q = agent.q_net(batch.state.to(torch.float32)).cpu().numpy()
+        acts, q = batch.ddqn_qnet(packed, want_q=True)
+        q, acts = q.cpu().numpy(), acts.cpu().numpy()
+        assert np.abs(q - ref_q).max() <= 1e-5 * max(1.0, np.abs(ref_q).max()), (src, B, np.abs(q - ref_q).max())
+        assert np.array_equal(acts, q.argmax(1))                                   # the kernel's own argmax: first maximum
+        srt = np.sort(ref_q, axis=1)
+        decided = srt[:, -1] - srt[:, -2] > 2e-5 * max(1.0, np.abs(ref_q).max())
+        assert decided.sum() >= int(0.99 * B) and np.array_equal(acts[decided], ref_q.argmax(1)[decided])
+        again = batch.ddqn_qnet(packed).cpu().numpy()
+        assert np.array_equal(again, acts)
+        with pytest.raises(ValueError):
+            batch.ddqn_qnet(packed[:-1])
+        batch.close()
+
+
+@pytest.mark.gpu
 def test_rlepso_critic_reproduces_reference_io_on_gpu():
     _check_rlepso_critic('cuda')
 

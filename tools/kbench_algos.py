@@ -60,7 +60,20 @@ if 'ddqn' in which:
         for _ in range(n):
             g.replay(); env.step(ga)
     run_graph(5); dg = timed(run_graph, 200)
-    print(json.dumps({'path': 'DE-DDQN protein, Q-net replayed as a hipGraph (rollout_batch default)', 'ms_per_step': dg / 200 * 1e3, 'env_steps_per_s': B * 200 / dg}))
+    print(json.dumps({'path': 'DE-DDQN protein, Q-net replayed as a hipGraph', 'ms_per_step': dg / 200 * 1e3, 'env_steps_per_s': B * 200 / dg}))
+    packed = agent.packed_weights()
+    def run_hip(n):
+        for _ in range(n):
+            env.step(env.batch.ddqn_qnet(packed))
+    def run_q(n):
+        for _ in range(n): env.batch.ddqn_qnet(packed)
+    def run_s(n):
+        a = env.batch.ddqn_qnet(packed)
+        for _ in range(n): env.step(a)
+    run_hip(5); dh = timed(run_hip, 200)
+    print(json.dumps({'path': 'DE-DDQN protein, Q-net + argmax as one MFMA launch (mbx_ddqn_qnet; rollout_batch default)', 'ms_per_step': dh / 200 * 1e3, 'env_steps_per_s': B * 200 / dh}))
+    dq = timed(run_q, 200); ds = timed(run_s, 200)
+    print(json.dumps({'path': 'DE-DDQN protein: the two launches alone', 'qnet_us': dq / 200 * 1e6, 'k_dq_step_us': ds / 200 * 1e6}))
     run(5); dt = timed(run, 200)
     print(json.dumps({'path': 'DE-DDQN protein d=12 NP=100, 2240 instances (35 problems x 64 runs), Q-net via PyTorch', 'ms_per_step': dt / 200 * 1e3, 'env_steps_per_s': B * 200 / dt}))
     env.close()
