@@ -302,6 +302,32 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
                 }
             o.o[9] = push(ry.data(), NA * D);
         }
+        if (protein) {
+            // The energy kernel visits the atom pairs i < j only (eval_rows_protein), in the order of the folded rectangle
+            // ceil(n / 2) x (n - 1): pair t = a (n - 1) + b is (a, a + 1 + b) for b < n - 1 - a, else (n - 1 - a, ...).  Its inputs are laid
+            // out in that order: `pyr` <- [n_pairs][4] = sqrt(e) | q | r | 0 (one 32-byte record per pair: lane t reads record t, fully
+            // coalesced), `plogw` <- the pair's atoms as int32 i | j << 16 (two per double).  Requires what the reference constructs
+            // (protein_docking.py:175-181): symmetric tables.
+            const int n = d.n_peaks, W = n - 1, n_pairs = ((n + 1) / 2) * W;
+            const double *se = d.pw, *qm = d.pw + NA * NA, *rm = d.pw + 2 * NA * NA;
+            for (int a = 0; a < n; ++a)
+                for (int c = a + 1; c < n; ++c)
+                    if (se[a * n + c] != se[c * n + a] || qm[a * n + c] != qm[c * n + a] || rm[a * n + c] != rm[c * n + a])
+                        return fail(MBX_E_ARG, "problem %d: the protein tables sqrt(e) | q | r must be symmetric (atoms %d, %d)", i, a, c);
+            std::vector<double> rec((size_t)n_pairs * 4, 0.);
+            std::vector<double> ij((size_t)(n_pairs + 1) / 2, 0.);
+            int32_t* ijw = reinterpret_cast<int32_t*>(ij.data());
+            for (int t = 0; t < n_pairs; ++t) {
+                const int a = t / W, b = t - a * W, La = W - a;
+                const bool lower = b >= La;
+                const int pi = lower ? W - a : a, pj = pi + 1 + (lower ? b - La : b);
+                ijw[t] = pi | (pj << 16);
+                if (lower && pi == a) { ijw[t] = -1; continue; }       // odd n: the middle atom's row appears once
+                rec[(size_t)t * 4] = se[pi * n + pj]; rec[(size_t)t * 4 + 1] = qm[pi * n + pj]; rec[(size_t)t * 4 + 2] = rm[pi * n + pj];
+            }
+            o.o[9] = push(rec.data(), rec.size());
+            o.o[10] = push(ij.data(), ij.size());
+        }
     }
     std::unique_ptr<mbx_suite, int (*)(mbx_suite*)> guard(new mbx_suite(), mbx_suite_destroy);   // freed on every error return
     mbx_suite* s = guard.get();
@@ -681,10 +707,10 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
             hipLaunchKernelGGL(k_lde_step<kThreads>, dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->fixed_geometry == 4)
-            hipLaunchKernelGGL((k_dq_step<100, 12>), dim3(b->B), dim3(kThreads), (size_t)dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double), (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL((k_dq_step<100, 12>), dim3(b->B), dim3(kDqStepThreads), (size_t)dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double), (hipStream_t)stream, make_params(b),
                                (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
         else
-            hipLaunchKernelGGL(k_dq_step<>, dim3(b->B), dim3(kThreads), (size_t)dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double), (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL(k_dq_step<>, dim3(b->B), dim3(kDqStepThreads), (size_t)dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double), (hipStream_t)stream, make_params(b),
                                (const int32_t*)d_actions, d_state_out, d_reward_out, d_done_out);
     }
     HIP_TRY(hipGetLastError());
@@ -953,6 +979,9 @@ extern "C" int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4])
 {
     if (!b || !out) return fail(MBX_E_ARG, "mbx_batch_launch_info: bad arguments");
     out[0] = b->threads; out[1] = (int32_t)b->lds_bytes; out[2] = b->fixed_geometry; out[3] = (int32_t)b->state_stride;
+    if (b->cfg.algo == MBX_ALGO_DEDDQN) {                      // the step kernel (one wave per instance, one-row evaluator scratch), not k_dq_reset
+        out[0] = kDqStepThreads; out[1] = (int32_t)(dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double));
+    }
     return MBX_OK;
 }
 

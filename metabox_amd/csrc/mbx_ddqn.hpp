@@ -53,13 +53,13 @@ __device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP,
                                             double* gR, double* state_out)
 {
     const int tid = threadIdx.x;
-    for (int k = tid; k < MBX_DQ_NFEAT; k += kThreads) L.FEAT[k] = 0.;
+    for (int k = tid; k < MBX_DQ_NFEAT; k += MBX_NT) L.FEAT[k] = 0.;
     // mean / std of the cost vector (np.mean, np.std :79-80)
     double part = 0.;
-    for (int i = tid; i < NP; i += kThreads) part += L.COST[i];
+    for (int i = tid; i < NP; i += MBX_NT) part += L.COST[i];
     const double mean = block_sum(part, L.RED) / NP;
     part = 0.;
-    for (int i = tid; i < NP; i += kThreads) { const double t = fabs(L.COST[i] - mean); part += t * t; }
+    for (int i = tid; i < NP; i += MBX_NT) { const double t = fabs(L.COST[i] - mean); part += t * t; }
     const double var = block_sum(part, L.RED) / NP;
     int* R = reinterpret_cast<int*>(L.MISC);
     if (tid == 0) {
@@ -96,8 +96,10 @@ __device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP,
         else if (tid == 5) L.FEAT[11] = dist;
         else L.FEAT[18] = dist;
     }
-    if (tid >= 64 && tid < 80) {                                    // operator-credit statistics (:94-126)
-        const int q = tid - 64, op = q >> 2;
+    // (the three groups below sit in different waves when the workgroup has four, and share the one wave of a 64-thread workgroup)
+    const int t1 = MBX_NT >= 256 ? 64 : 16, t2 = MBX_NT >= 256 ? 128 : 32;
+    if (tid >= t1 && tid < t1 + 16) {                               // operator-credit statistics (:94-126)
+        const int q = tid - t1, op = q >> 2;
         const int G = gen < MBX_DQ_GENMAX ? gen : MBX_DQ_GENMAX;
         const double *nt = L.ntot() + op * MBX_DQ_GENMAX, *ns = L.nsucc() + q * MBX_DQ_GENMAX, *os = L.omsum() + q * MBX_DQ_GENMAX,
                      *ox = L.ommax() + q * MBX_DQ_GENMAX;
@@ -118,14 +120,14 @@ __device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP,
             if (dn != 0 && ns[s0] > 0 && ns[s1] > 0) L.FEAT[51 + q] = (ox[s0] - ox[s1]) / (ox[s1] * fabs(dn));
         }
     }
-    if (tid >= 128 && tid < 144) {                                  // OM_W window sums (:127-129)
-        const int q = tid - 128, op = q >> 2, m = q & 3;
+    if (tid >= t2 && tid < t2 + 16) {                               // OM_W window sums (:127-129)
+        const int q = tid - t2, op = q >> 2, m = q & 3;
         double s = 0.;
         for (int w = 0; w < omw_len; ++w) if ((int)L.omw()[w * 6] == op) s += L.omw()[w * 6 + 1 + m];
         L.FEAT[83 + q] = s;
     }
     __syncthreads();
-    for (int k = tid; k < MBX_DQ_NFEAT; k += kThreads) state_out[k] = L.FEAT[k];
+    for (int k = tid; k < MBX_DQ_NFEAT; k += MBX_NT) state_out[k] = L.FEAT[k];
 }
 
 // ------------------------------------------------------------------------------------------------ reset
@@ -188,11 +190,20 @@ __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* _
 
 // ------------------------------------------------------------------------------------------------ step
 #ifndef MBX_DQ_WAVES
-#define MBX_DQ_WAVES
+#define MBX_DQ_WAVES __attribute__((amdgpu_waves_per_eu(3)))      // nine one-wave workgroups per CU: at most three waves on a SIMD, 168 VGPRs each
 #endif
+// ONE wave per instance.  A step is a chain of ~20 short phases, most of them a handful of lanes wide (one trial vector of D coordinates, 16
+// credit statistics, single-lane bookkeeping); with four waves per instance every phase boundary was a workgroup barrier and 2240 instances
+// needed 2.2 rounds of resident workgroups (99 VGPRs: four per CU).  A 64-thread workgroup has no barrier to wait at (s_barrier of a single
+// wave), 17.9 KB of LDS let nine of them share a CU, so all 2240 instances of config 4's share are resident at once; the only wide phase, the
+// protein energy, is 78 instead of 20 pair iterations per lane.  (The helpers take the workgroup size from the launch.)
+#ifndef MBX_DQ_STEP_THREADS
+#define MBX_DQ_STEP_THREADS 64
+#endif
+constexpr int kDqStepThreads = MBX_DQ_STEP_THREADS;
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int NPC = 0, int DC = 0>
-__global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams bp, const int32_t* __restrict__ actions, double* __restrict__ state_out,
+__global__ __launch_bounds__(kDqStepThreads) MBX_DQ_WAVES void k_dq_step(BatchParams bp, const int32_t* __restrict__ actions, double* __restrict__ state_out,
                                                       double* __restrict__ reward_out, uint8_t* __restrict__ done_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
         return;
     }
     ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);   // scalar loads on demand, no SGPR-resident copy
+    MBX_PHASE_BEGIN
     const DqLds L = dq_carve(smem, 1, NP, D);
     const double* tape = bp.tape ? bp.tape + (int64_t)b * bp.tape_stride : nullptr;
     const int action = actions[b];
@@ -228,8 +240,8 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
     for (int j = 0; j < 5; ++j) r[j] = (int)S[MBX_DQ_ST_R(NP, D) + j];
 
     // ---- stage records, cost vector, problem constants
-    for (int k = tid; k < kDqRec; k += kThreads) L.REC[k] = S[MBX_DQ_ST_NTOT(NP, D) + k];
-    for (int i = tid; i < NP; i += kThreads) L.COST[i] = S[MBX_DQ_ST_COST(NP, D) + i];
+    for (int k = tid; k < kDqRec; k += MBX_NT) L.REC[k] = S[MBX_DQ_ST_NTOT(NP, D) + k];
+    for (int i = tid; i < NP; i += MBX_NT) L.COST[i] = S[MBX_DQ_ST_COST(NP, D) + i];
     stage_problem<eval_dc(DC)>(P, L.eval());
     double* PRE = L.MISC + 8;            // prebest position used by the features (after a possible re-bind)
     double* GBP = PRE + align2(D) ;      // gbest position used by mutation / features
@@ -251,6 +263,7 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
         PRE[tid] = prev;
     }
     __syncthreads();
+    MBX_PHASE(0);                                                 // staging
 
     // ---- mutation (operators/mutate.py), clipping, Cr = 1 => trial = donor (crossover.py:6-18)
     if (tid < D) {
@@ -265,16 +278,22 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
         L.X[d] = fmin(fmax(v, lb), ub);
     }
     __syncthreads();
+    MBX_PHASE(1);                                                 // mutation
     eval_rows<eval_dc(DC)>(P, L.eval(), 1);
+    MBX_PHASE(2);                                                 // evaluation
     // ---- median of the current costs (:171) by rank counting
-    for (int i = tid; i < NP; i += kThreads) {
+    // c_i is the k-th smallest (0-based) iff #{c_j < c_i} <= k < #{c_j <= c_i}: equal costs are interchangeable for the VALUE at rank k, so no
+    // index tie-break is needed (two compares per pair instead of three and their logic)
+    for (int i = tid; i < NP; i += MBX_NT) {
         const double ci = L.COST[i];
-        int rank = 0;
-        for (int j = 0; j < NP; ++j) { const double cj = L.COST[j]; rank += (cj < ci) || (cj == ci && j < i); }
-        if (rank == NP / 2) L.RED[8] = ci;
-        if (rank == NP / 2 - 1) L.RED[9] = ci;
+        int nless = 0, nle = 0;
+#pragma unroll 4
+        for (int j = 0; j < NP; ++j) { const double cj = L.COST[j]; nless += cj < ci; nle += cj <= ci; }
+        if (nless <= NP / 2 && NP / 2 < nle) L.RED[8] = ci;
+        if (nless <= NP / 2 - 1 && NP / 2 - 1 < nle) L.RED[9] = ci;
     }
     __syncthreads();
+    MBX_PHASE(3);                                                 // median
 
     // ---- OM_W window (:178-187): when full, evict the first entry of the same operator, else the worst trial (first maximum), and
     // close the gap.  Depends on the action only, so it is done here by the whole block instead of inside the one-lane section
@@ -292,14 +311,17 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
         }
         __syncthreads();
         const int del = (int)L.MISC[5], last = (omw_len - 1) * 6;
-        const int k0 = del * 6 + tid, k1 = k0 + kThreads;
-        const double v0 = k0 < last ? W[k0 + 6] : 0., v1 = k1 < last ? W[k1 + 6] : 0.;
+        constexpr int NV = (MBX_DQ_W * 6 + kDqStepThreads - 1) / kDqStepThreads;        // window words per thread
+        double v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { const int k = del * 6 + tid + j * MBX_NT; v[j] = k < last ? W[k + 6] : 0.; }
         __syncthreads();
-        if (k0 < last) W[k0] = v0;
-        if (k1 < last) W[k1] = v1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { const int k = del * 6 + tid + j * MBX_NT; if (k < last) W[k] = v[j]; }
         omw_len -= 1;
         __syncthreads();
     }
+    MBX_PHASE(4);                                                 // window eviction
     // ---- sequential bookkeeping (:164-203) by one lane
     if (tid == 0) {
         double tc = L.NC[0];
@@ -334,6 +356,7 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
         L.MISC[6] = stag; L.MISC[7] = omw_len;
     }
     __syncthreads();
+    MBX_PHASE(5);                                                 // bookkeeping
     const double tc = L.RED[10], reward = L.RED[11];
     const int sel = (int)L.RED[12], newbest = (int)L.RED[13];
     gbest = L.RED[14]; gworst = L.RED[15]; stag = L.MISC[6]; omw_len = (int)L.MISC[7]; fes += 1;
@@ -348,11 +371,13 @@ __global__ __launch_bounds__(kThreads) MBX_DQ_WAVES void k_dq_step(BatchParams b
     const int pointer = (p + 1) % NP;
     __syncthreads();
 
+    MBX_PHASE(6);                                                 // selection
     // ---- next state (:209) — rows are read from HBM except the one this step rewrote (still in LDS)
     auto row = [&](int k) -> const double* { return (sel && k == p) ? L.X : gX + k * D; };
     dq_features(P, L, NP, D, bp, rng, tape, row, GBP, PRE, gbest, gworst, cpre, pointer, gen, stag, fes, omw_len,
                 S + MBX_DQ_ST_R(NP, D), state_out + (int64_t)b * MBX_DQ_NFEAT);
-    for (int k = tid; k < kDqRec; k += kThreads) S[MBX_DQ_ST_NTOT(NP, D) + k] = L.REC[k];
+    MBX_PHASE(7);                                                 // features
+    for (int k = tid; k < kDqRec; k += MBX_NT) S[MBX_DQ_ST_NTOT(NP, D) + k] = L.REC[k];
     if (tid == 0) {
         int log_index = (int)sc[MBX_SC_LOG_INDEX], cost_len = (int)sc[MBX_SC_COST_LEN];
         double* cost = sc + MBX_NSCALAR;

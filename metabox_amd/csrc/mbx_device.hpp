@@ -48,8 +48,8 @@ struct DevProblem {
     int32_t func_id, kind, dim, n_peaks, noise_kind, pad;
     double bias, lb, ub, pen_coef, s[4], noise_a, noise_b, optimum;
     const double *dshift, *m1, *m2, *v0, *v1, *v2, *py, *pc, *pw;
-    const double* pyr;   // Gallagher: R y_k, precomputed at upload (mbx_suite_create)
-    const double* plogw; // Gallagher: log(w_k), precomputed at upload
+    const double* pyr;   // Gallagher: R y_k, precomputed at upload (mbx_suite_create); protein: pair records [n_pairs][4] = sqrt(e) | q | r | 0
+    const double* plogw; // Gallagher: log(w_k), precomputed at upload; protein: the pairs' atoms, int32 i | j << 16 (-1: no pair)
 };
 
 // The same record read through the constant address space: every field access is a scalar load (s_load_dword*) of memory the compiler knows
@@ -433,6 +433,7 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (MBX_NW == 1) return v;                                       // a single wave: every lane already holds the sum, nothing to exchange
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
@@ -455,18 +456,28 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // sqrt and the two divisions by the distance (the reference's `r / pair_dis` and `q / (4 pair_dis)`) come from ONE v_rsq_f64 estimate:
 // two coupled Goldschmidt steps give sqrt(s) and 1 / (2 sqrt(s)), one residual correction each brings both to <= 1 ulp -- 13 instructions
 // instead of a library sqrt and two IEEE divisions (~70).  The energy is pinned at 1e-9 relative against the reference's own outputs.
-template <int DC = 0, class PT = DevProblem>
+// pairs in flight per lane in eval_rows_protein: 4 for the D = 12 instantiation (k_dq_step<100, 12>, one wave per instance), the plain loop elsewhere
+// (the generation kernels that can meet a protein problem run under a 96-register cap)
+#ifndef MBX_PROTEIN_PF
+#define MBX_PROTEIN_PF 4
+#endif
+constexpr int protein_prefetch(int dc) { return dc == 12 ? MBX_PROTEIN_PF : 1; }
+
+// PF: atom pairs per lane and loop iteration.  PF = 1 is the plain loop.  With PF > 1 the body fetches PF pairs and walks their PF independent
+// dependency chains side by side, one arithmetic step at a time over all of them: k_dq_step runs ONE wave per instance with ~2 waves per
+// SIMD, and a pair term is a chain of ~40 dependent float64 operations (rsq, Goldschmidt steps, r^12) that a single wave issues at the
+// chain's latency -- 11-13 cycles per instruction (instrumented build: 1070 cycles per pair, the energy 93 k of the step's 152 k cycles).
+// Same pairs per lane in the same order: every PF gives the same sums.
+template <int DC = 0, class PT = DevProblem, int PF = 1>
 __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
 {
     const int D = DC ? DC : P.dim, n = P.n_peaks, m3 = 3 * n, tid = threadIdx.x;
     double* COOR = L.Z;
     double* P2 = L.Z + ((m3 + 1) & ~1);
     double* RED = P2 + ((n + 1) & ~1);
-    const double* __restrict__ se = P.pw;
-    const double* __restrict__ qm = P.pw + (size_t)n * n;
-    const double* __restrict__ rm = P.pw + 2 * (size_t)n * n;
-    const int W = n - 1, n_pairs = ((n + 1) >> 1) * W;
-    const FastDiv fw(W);
+    const double2* __restrict__ rec = (const double2*)P.pyr;       // [n_pairs][2]: (sqrt(e), q), (r, 0) in pair order (mbx_suite_create)
+    const int32_t* __restrict__ pij = (const int32_t*)P.plogw;
+    const int n_pairs = ((n + 1) >> 1) * (n - 1);
     for (int r = 0; r < n_rows; ++r) {
         const double* x = L.X + r * D;
         for (int m = tid; m < m3; m += MBX_NT) {
@@ -479,34 +490,55 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
             P2[i] = COOR[3 * i] * COOR[3 * i] + COOR[3 * i + 1] * COOR[3 * i + 1] + COOR[3 * i + 2] * COOR[3 * i + 2];
         __syncthreads();
         double acc = 0.;
-        for (int t = tid; t < n_pairs; t += MBX_NT) {
-            const int a = fw.div(t), b = t - a * W, La = W - a;
-            const bool lower = b >= La;                            // second part of the folded row: the pairs of atom n - 1 - a
-            const int i = lower ? W - a : a, j = i + 1 + (lower ? b - La : b);
-            if (lower && i == a) continue;                         // odd n: the middle atom's pairs are all in the first part
-            const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
-            const double s = P2[i] - 2 * p3 + P2[j] + 0.01;        // >= 0.01 up to rounding: always a positive normal number
-            double g, h;
-            {
-                const double y = __builtin_amdgcn_rsq(s);
-                g = s * y; h = 0.5 * y;
-                double e = __builtin_fma(-h, g, 0.5);
-                g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
-                e = __builtin_fma(-h, g, 0.5);
-                g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
-                g = __builtin_fma(__builtin_fma(-g, g, s), h, g);  // sqrt(s) + (s - g^2) / (2 sqrt(s))
+        for (int t0 = tid; t0 < n_pairs; t0 += PF * MBX_NT) {
+            double se[PF], q[PF], rr[PF], s[PF], g[PF], h[PF], e[PF], inv[PF], tv[PF];
+            bool ok[PF];
+            // ---- fetch: one 4-byte index word and one 32-byte record per pair (lane t reads word / record t), eight LDS words
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u * MBX_NT;
+                const int tc = t < n_pairs ? t : n_pairs - 1;      // clamped: the loads are unconditional
+                const int w = pij[tc];
+                ok[u] = t < n_pairs && w >= 0;
+                const int i = w < 0 ? 0 : (w & 0xffff), j = w < 0 ? 1 : (w >> 16);
+                const double2 a = rec[2 * tc], b = rec[2 * tc + 1];
+                se[u] = a.x; q[u] = a.y; rr[u] = b.x;
+                const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
+                s[u] = P2[i] - 2 * p3 + P2[j] + 0.01;              // >= 0.01 up to rounding: always a positive normal number
             }
-            const double pd = g;
-            double inv = h + h;
-            inv = __builtin_fma(inv, __builtin_fma(-pd, inv, 1.0), inv);                       // 1 / pd
-            const int w = i * n + j;
-            const double rr = rm[w] * inv;
-            const double r2 = rr * rr, r6 = r2 * r2 * r2;
-            const double coeff = qm[w] * (0.25 * inv) + se[w] * (r6 * r6 - r6);
-            const bool near = pd > 0.11 && pd < 7.0, far = pd > 7.0 && pd < 9.0;
-            const double sw = (9 - pd) * (9 - pd) * (-12 + 2 * pd) * 0.125;
-            const double c10 = 10 * coeff;
-            acc += near ? c10 : (far ? c10 * sw : 0.);
+            // ---- pd = sqrt(s) and 1 / pd from one v_rsq_f64 estimate: two coupled Goldschmidt steps, one residual correction each
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { const double y = __builtin_amdgcn_rsq(s[u]); g[u] = s[u] * y; h[u] = 0.5 * y; }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) e[u] = __builtin_fma(-h[u], g[u], 0.5);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { g[u] = __builtin_fma(g[u], e[u], g[u]); h[u] = __builtin_fma(h[u], e[u], h[u]); }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) e[u] = __builtin_fma(-h[u], g[u], 0.5);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { g[u] = __builtin_fma(g[u], e[u], g[u]); h[u] = __builtin_fma(h[u], e[u], h[u]); }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) g[u] = __builtin_fma(__builtin_fma(-g[u], g[u], s[u]), h[u], g[u]);    // pd: sqrt(s) + (s - g^2) / (2 sqrt(s))
+#pragma unroll
+            for (int u = 0; u < PF; ++u) inv[u] = h[u] + h[u];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) inv[u] = __builtin_fma(inv[u], __builtin_fma(-g[u], inv[u], 1.0), inv[u]);   // 1 / pd
+            // ---- Coulomb + Lennard-Jones with the distance windows (protein_docking.py:40-46)
+#pragma unroll
+            for (int u = 0; u < PF; ++u) rr[u] = rr[u] * inv[u];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { const double r2 = rr[u] * rr[u]; rr[u] = r2 * r2 * r2; }                 // (r / pd)^6
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const double pd = g[u], r6 = rr[u];
+                const double coeff = q[u] * (0.25 * inv[u]) + se[u] * (r6 * r6 - r6);
+                const bool near = pd > 0.11 && pd < 7.0, far = pd > 7.0 && pd < 9.0;
+                const double sw = (9 - pd) * (9 - pd) * (-12 + 2 * pd) * 0.125;
+                const double c10 = 10 * coeff;
+                tv[u] = near ? c10 : (far ? c10 * sw : 0.);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) if (ok[u]) acc += tv[u];
         }
         const double total = block_sum(acc, RED);
         if (tid == 0) L.F[r] = (2 * total) / n;
@@ -541,7 +573,7 @@ template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0>
 __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* post = nullptr)
 {
     if (P.kind == MBX_KIND_PROTEIN) {
-        eval_rows_protein<DC, PT>(P, L, n);
+        eval_rows_protein<DC, PT, protein_prefetch(DC)>(P, L, n);
         if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
         return;
     }
