@@ -229,6 +229,36 @@ __device__ __forceinline__ double osc1(double x)
     return pos ? r : -r;
 }
 
+// The same transform as ONE out-of-line call per coordinate with its four transcendentals inline inside (same routines, same arithmetic as the
+// four m_* calls of osc1: each call costs argument moves, a jump pair and a full s_waitcnt at the callee's entry), and the Schaffers term
+// (bbob.py:642-643) likewise.  A kernel's register count is the maximum over everything it can call, and these two need more than the leaf
+// routines (round 2: with them k_lde_step<512, 50, 30> lost its third resident workgroup), so only the evaluator instantiation of the headline
+// geometry (eval_rows<10>: k_rlepso_step / k_rlepso_run<256, 100, 10, 5>, 96 VGPRs either way) refers to them: 122.5 -> 119.5 us per generation
+// (A/B on one box).  Measured and dropped: the Weierstrass series and T_asy(T_osz(.)) as composites of their own (119.9 -> 120.1 us).
+#if defined(MBX_NOINLINE_MATH) && !defined(MBX_LIBM_MATH)
+__device__ __noinline__ double osc1_composite(double x)
+{
+    if (x == 0.) return x;
+    const bool pos = x > 0.;
+    const double y = div_by_tenth(fm::log_fast(fabs(x)));
+    const double c1 = pos ? 1.0 : 0.55, c2 = pos ? 0.79 : 0.31;
+    const double r = fm::exp_fast(0.1 * (y + 0.49 * (fm::sincos_fast<false>(c1 * y) + fm::sincos_fast<false>(c2 * y))));
+    return pos ? r : -r;
+}
+__device__ __noinline__ double schaffers_composite(double s)
+{
+    const double w = fm::sincos_fast<false>(50 * fm::pow_fast(s, 0.2));
+    return sqrt(s) * (w * w + 1);                                 // pow(w, 2) is the correctly rounded square in numpy, libm and pow_fast alike
+}
+#else
+__device__ __forceinline__ double osc1_composite(double x) { return osc1(x); }
+__device__ __forceinline__ double schaffers_composite(double s) { return sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1); }
+#endif
+#ifndef MBX_COMPOSITE_DC
+#define MBX_COMPOSITE_DC 10
+#endif
+template <bool CMP> __device__ __forceinline__ double osc_t(double x) { if constexpr (CMP) return osc1_composite(x); else return osc1(x); }
+
 __device__ __forceinline__ double asy1(double x, double beta_lin)  // asy_transform, bbob.py:70-82
 {
     return x > 0. ? m_pow(x, 1. + beta_lin * sqrt(x)) : x;
@@ -461,6 +491,12 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 #ifndef MBX_PROTEIN_PF
 #define MBX_PROTEIN_PF 4
 #endif
+// Gallagher peak search with a block of peaks as accumulators (eval_rows): the instantiations that have the registers for it -- under the 80-VGPR
+// cap of k_lde_step<512, 50, 30> it spilled so badly that the whole kernel ran 6x slower (615 -> 3680 us per generation), and k_lde_step<512, 100, 30>
+// (128 VGPRs, two workgroups per CU) lost 17 % (1123 -> 1314 us), and config 5's resident kernel (velocities / pbest positions in registers next to it)
+// 33 % (1.87 -> 2.50 ms): only config 5's one-generation kernel k_rlepso_step<1024, 128, 40, 5> takes it (Gallagher-101 evaluation 203 k -> 83 k cycles)
+constexpr bool gallagher_blocked(int md, int kc) { return md == 40 && kc == 0; }
+
 constexpr int protein_prefetch(int dc) { return dc == 12 ? MBX_PROTEIN_PF : 1; }
 
 // PF: atom pairs per lane and loop iteration.  PF = 1 is the plain loop.  With PF > 1 the body fetches PF pairs and walks their PF independent
@@ -577,6 +613,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
         if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
         return;
     }
+    constexpr bool CMP = DC == MBX_COMPOSITE_DC;                   // composite out-of-line transforms (osc1_composite): the headline geometry only
     const int D = DC ? DC : P.dim, NE = n * D, kind = P.kind, tid = opaque_tid();
     const double ub = P.ub, bias = P.bias;
     const double* X = L.X;
@@ -613,9 +650,8 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
         // Gallagher (bbob.py:796-800): max_k w_k exp(-1/(2D) sum_d C_kd z_kd^2), z_k = R (x - y_k) = R x - R y_k.
         // exp is monotone, so the winning peak of a row is found on key_k = log(w_k) - s_k/(2D) (log w_k pre-computed at
         // upload) and the reference's expression is evaluated for that peak only: one exp per row instead of n_peaks.
-        // The pre-rotated peaks, C and log w are streamed through LDS in chunks (T); inside a chunk wave w takes the peaks
-        // k = w (mod number of waves) — uniform per wave, i.e. broadcast LDS reads — and lane l the rows l, l+64, ..; the running
-        // maximum of a (row, wave) pair lives in registers across chunks.  Peaks that tie to within rounding are both
+        // Wave w takes the peaks k = w (mod number of waves) -- uniform per wave, so the pre-rotated peaks, C and log w come through scalar
+        // loads -- and lane l the rows l, l + 64, ..; the running maximum of a (row, wave) pair lives in registers.  Peaks that tie to within rounding are both
         // "the maximum" to 1 ulp; the lower peak index is kept.  The search key accumulates with one fused multiply-add per
         // coordinate (3 instead of 4 instructions in the (row, peak, coordinate) loop); the value of the winning peak is
         // evaluated in the row phase with the reference's expression.
@@ -644,6 +680,79 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
                         for (int d = 0; d < DC; ++d) { const double zd = rx[d] - py[kk * DC + d]; acc = __builtin_fma(pcc[kk * DC + d], zd * zd, acc); }
                         const double key = plw[kk] + cexp * acc;
                         if (key > bkey[q]) { bkey[q] = key; bk[q] = kk; }
+                    }
+                }
+            }
+        } else if constexpr (gallagher_blocked(MD, KC)) {
+            // config 5 (D = 40, NP = 128, one 1024-thread workgroup per CU).  The row does not fit in registers, and re-reading it
+            // from LDS for every peak made this loop LDS-bound: one 512-byte ds_read per (row group, peak, coordinate) next to three VALU
+            // instructions -- the 101-peak functions took 203 k cycles per evaluation at NP = 128, D = 40 on 16 waves against an issue bound of
+            // 24 k (instrumented build, round 3), with the peak tables streamed through LDS chunks on top.  Here a wave keeps a block of up to
+            // PB of its peaks as accumulators and walks the row in chunks of GC coordinates held in registers: one LDS read of the row per
+            // PB peaks, y_k / C_k / log w_k -- wave-uniform -- through scalar loads as in the small-dimension route.  Each key is still the
+            // fma chain over d ascending, each (row, wave) still visits its peaks k = wave, wave + waves, .. in ascending order with the
+            // strict `>`: bit-identical to the routes this replaces.
+            typedef const double __attribute__((address_space(4)))* kptr;
+            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
+            const int wv = __builtin_amdgcn_readfirstlane(wave), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+            constexpr int PB = 8, GC = 10;
+            const int mine = wv < npk ? (npk - wv + nw - 1) / nw : 0;       // peaks of this wave: wv + j nw, j < mine
+            // two row groups (lanes l and l + 64) share every scalar load of y_k / C_k: half the scalar traffic and two independent chains
+#pragma unroll
+            for (int q0 = 0; q0 < 4; q0 += 2) {
+                if (64 * q0 >= n) break;                                     // wave-uniform
+                const int i0 = lane + 64 * q0, i1 = i0 + 64;
+                const double* rx0 = Z + (i0 < n ? i0 : n - 1) * D;          // lanes past the last row repeat it (results unused)
+                const double* rx1 = Z + (i1 < n ? i1 : n - 1) * D;
+                for (int j0 = 0; j0 < mine; j0 += PB) {
+                    double acc0[PB], acc1[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) { acc0[j] = 0.; acc1[j] = 0.; }
+                    for (int c0 = 0; c0 < D; c0 += GC) {
+                        double y0[GC], y1[GC];
+                        const int kn = D - c0 < GC ? D - c0 : GC;
+                        if (kn == GC) {                                      // a whole chunk (every chunk at D = 10, 20, 30, 40)
+#pragma unroll
+                            for (int k = 0; k < GC; ++k) { y0[k] = rx0[c0 + k]; y1[k] = rx1[c0 + k]; }
+#pragma unroll
+                            for (int j = 0; j < PB; ++j) {
+                                if (j0 + j < mine) {                         // wave-uniform
+                                    const int kk = wv + (j0 + j) * nw;
+                                    const kptr ry = py + (int64_t)kk * D + c0;
+                                    const kptr ck = pcc + (int64_t)kk * D + c0;
+#pragma unroll
+                                    for (int k = 0; k < GC; ++k) {
+                                        const double z0 = y0[k] - ry[k], z1 = y1[k] - ry[k];
+                                        acc0[j] = __builtin_fma(ck[k], z0 * z0, acc0[j]);
+                                        acc1[j] = __builtin_fma(ck[k], z1 * z1, acc1[j]);
+                                    }
+                                }
+                            }
+                        } else {
+                            for (int k = 0; k < kn; ++k) { y0[k] = rx0[c0 + k]; y1[k] = rx1[c0 + k]; }
+#pragma unroll
+                            for (int j = 0; j < PB; ++j) {
+                                if (j0 + j < mine) {
+                                    const int kk = wv + (j0 + j) * nw;
+                                    const kptr ry = py + (int64_t)kk * D + c0;
+                                    const kptr ck = pcc + (int64_t)kk * D + c0;
+                                    for (int k = 0; k < kn; ++k) {
+                                        const double z0 = y0[k] - ry[k], z1 = y1[k] - ry[k];
+                                        acc0[j] = __builtin_fma(ck[k], z0 * z0, acc0[j]);
+                                        acc1[j] = __builtin_fma(ck[k], z1 * z1, acc1[j]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        if (j0 + j < mine) {
+                            const int kk = wv + (j0 + j) * nw;
+                            const double k0 = plw[kk] + cexp * acc0[j], k1 = plw[kk] + cexp * acc1[j];
+                            if (k0 > bkey[q0]) { bkey[q0] = k0; bk[q0] = kk; }
+                            if (k1 > bkey[q0 + 1]) { bkey[q0 + 1] = k1; bk[q0 + 1] = kk; }
+                        }
                     }
                 }
             }
@@ -707,10 +816,10 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
         for (int e = tid; e < NE; e += MBX_NT) {
             const int d = fd.mod(e);
             switch (kind) {
-            case 2: case 10: { const double o = osc1(Z[e]); T[e] = v0[d] * (o * o); break; }
-            case 3: { const double z = v0[d] * asy1(osc1(Z[e]), v1[d]); Z[e] = z; T[e] = m_cos(kTwoPi * z); break; }
+            case 2: case 10: { const double o = osc_t<CMP>(Z[e]); T[e] = v0[d] * (o * o); break; }
+            case 3: { const double z = v0[d] * asy1(osc_t<CMP>(Z[e]), v1[d]); Z[e] = z; T[e] = m_cos(kTwoPi * z); break; }
             case 4: {
-                double o = osc1(Z[e]);
+                double o = osc_t<CMP>(Z[e]);
                 if ((d & 1) == 0 && o > 0.) o *= 10.;
                 const double z = o * v0[d];
                 Z[e] = z; T[e] = m_cos(kTwoPi * z);
@@ -731,11 +840,11 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
             }
             case 8: Z[e] = P.s[0] * Z[e] + 1; break;
             case 9: case 19: Z[e] = Z[e] + 0.5; break;
-            case 11: { const double o = osc1(Z[e]); T[e] = o * o; break; }
+            case 11: { const double o = osc_t<CMP>(Z[e]); T[e] = o * o; break; }
             case 12: case 17: case 18: T[e] = asy1(Z[e], v1[d]); break;
             case 14: T[e] = m_pow(fabs(Z[e]), v0[d]); break;
-            case 15: T[e] = asy1(osc1(Z[e]), v1[d]); break;
-            case 16: T[e] = osc1(Z[e]); break;
+            case 15: T[e] = asy1(osc_t<CMP>(Z[e]), v1[d]); break;
+            case 16: T[e] = osc_t<CMP>(Z[e]); break;
             case 20: T[e] = v2[d] * X[e]; break;
             case 23: {                                              // Katsuura inner series, bbob.py:858-863
                 const double z = Z[e];
@@ -798,7 +907,8 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
             const int d = fd.mod(e);
             if (d < D - 1) {
                 const double s = sqrt(Z[e] * Z[e] + Z[e + 1] * Z[e + 1]);
-                T[e] = sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1);
+                if constexpr (CMP) T[e] = schaffers_composite(s);
+                else T[e] = sqrt(s) * (m_pow(m_sin(50 * m_pow(s, 0.2)), 2) + 1);
             }
         }
     } else if (kind == 19) {                                        // Griewank-Rosenbrock, bbob.py:702-703
@@ -851,7 +961,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
             break;
         }
         case 5: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = s + bias; break; }
-        case 6: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = m_pow(osc1(s), 0.9) + bias; break; }
+        case 6: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = m_pow(osc_t<CMP>(s), 0.9) + bias; break; }
         case 7: {
             double s = 0.;
             for (int d = 0; d < D; ++d) s += v0[d] * (z[d] * z[d]);
@@ -904,7 +1014,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
             double acc = 0.;
             for (int d = 0; d < D; ++d) { const double zd = z[d] - ry[d]; acc += ck[d] * (zd * zd); }
             const double best = P.pw[ks] * m_exp((-0.5 / D) * acc);
-            const double o = osc1(10 - best);
+            const double o = osc_t<CMP>(10 - best);
             f = o * o + bias + bh;
             break;
         }
