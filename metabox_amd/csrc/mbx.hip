@@ -778,7 +778,7 @@ extern "C" int mbx_ddqn_qnet(mbx_batch* b, const mbx_qnet* net, const double* d_
         return fail(MBX_E_UNSUPPORTED, "mbx_ddqn_qnet: only the reference architecture 99 -> 100 x 4 -> 4 is built (got %d -> %d x %d -> %d)",
                     net->in_dim, net->width, net->depth, net->n_act);
     const QNet g{net->d_weights, net->in_dim, net->width, net->depth, net->n_act};
-    hipLaunchKernelGGL((k_qnet_argmax<99, 100, 4>), dim3((b->B + kQTile - 1) / kQTile), dim3(kThreads), 0, (hipStream_t)stream, g, d_state, d_actions,
+    hipLaunchKernelGGL((k_qnet_argmax<99, 100, 4>), dim3((b->B + kQTile - 1) / kQTile), dim3(kQThreads), 0, (hipStream_t)stream, g, d_state, d_actions,
                        d_q, b->B);
     HIP_TRY(hipGetLastError());
     return MBX_OK;

@@ -458,6 +458,47 @@ __device__ __forceinline__ void matvec_rows_scalar_kc(const double* __restrict__
     }
 }
 
+// The same product on the float64 matrix cores: v_mfma_f64_16x16x4_f64, rows = population rows (A: lane l holds In[16 rt + (l & 15)][4 s + (l >> 4)] - sub),
+// columns = outputs (B: lane l holds M[16 ct + (l & 15)][4 s + (l >> 4)], straight from the problem's row-major map in global memory / L2), the
+// accumulator tile starts at +0 and is chained over the ceil(MD / 4) k-steps.  The instruction IS the fma chain in ascending k, bit for bit
+// (tools/ubench/mfma_f64_probe.hip), and the zero padding of k >= MD adds fma(0, 0, acc) = acc: results are identical to matvec_rows_scalar.
+// On MI355X the float64 matrix peak equals the float64 vector peak (78.6 TFLOP/s: 64 cycles per instruction = the 16 v_fma_f64 it replaces), so
+// this is not a faster multiplier but a SECOND pipe: the ~40 VALU instructions per 16 x 16 tile (fragment loads, shift, stores) replace ~300, and
+// the matrix pipe works while the other resident workgroups' waves keep the vector pipe busy.  Tile (rt, ct) -> wave (rt CT + ct) mod waves.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int MD, bool SUB>
+__device__ __forceinline__ void matvec_rows_mfma(const double* __restrict__ Mg, const double* In, const double* sub, int n, double* Out)
+{
+    constexpr int KS = (MD + 3) / 4, CT = (MD + 15) / 16;
+    const int tid0 = opaque_tid(), lane = tid0 & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+    const int units = ((n + 15) >> 4) * CT;
+    double sh[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { const int k = 4 * s + q; sh[s] = (SUB && k < MD) ? sub[k] : 0.; }
+    for (int u = wave; u < units; u += nw) {
+        const int rt = u / CT, ct = u - rt * CT;
+        const int row = 16 * rt + c, d = 16 * ct + c;
+        double a[KS], b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + q;
+            b[s] = (d < MD && k < MD) ? Mg[d * MD + k] : 0.;
+            a[s] = (row < n && k < MD) ? In[row * MD + k] - sh[s] : 0.;
+        }
+        f64x4 acc = {0., 0., 0., 0.};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+        if (d < MD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = 16 * rt + q + 4 * r;              // C / D layout of the float64 shape: row (l >> 4) + 4 r, column l & 15
+                if (orow < n) Out[orow * MD + d] = acc[r];
+            }
+        }
+    }
+}
+
 // sum of v over the block (all threads call; result to every thread).  red: >= 16 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
@@ -496,6 +537,13 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // (128 VGPRs, two workgroups per CU) lost 17 % (1123 -> 1314 us), and config 5's resident kernel (velocities / pbest positions in registers next to it)
 // 33 % (1.87 -> 2.50 ms): only config 5's one-generation kernel k_rlepso_step<1024, 128, 40, 5> takes it (Gallagher-101 evaluation 203 k -> 83 k cycles)
 constexpr bool gallagher_blocked(int md, int kc) { return md == 40 && kc == 0; }
+
+// which compile-time geometries take the matrix-core matvec (matvec_rows_mfma): MBX_MFMA_MATVEC = 0 none, 1 the D = 30 kernels (LDE, RLEPSO --dim 30),
+// 2 also D = 40 (config 5)
+#ifndef MBX_MFMA_MATVEC
+#define MBX_MFMA_MATVEC 1
+#endif
+constexpr bool mfma_matvec(int md, int kc) { (void)kc; return (MBX_MFMA_MATVEC >= 1 && md == 30) || (MBX_MFMA_MATVEC >= 2 && md == 40); }
 
 constexpr int protein_prefetch(int dc) { return dc == 12 ? MBX_PROTEIN_PF : 1; }
 
@@ -632,7 +680,10 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     // Barriers only where a phase exists for this function (the kind is workgroup-uniform, so every thread takes the same path).
     const bool first_map = !(kind == 5 || kind == 20 || kind == 24);
     if (first_map) {
-        if constexpr (MD > 0 && KC > 0) {
+        if constexpr (mfma_matvec(MD, KC)) {
+            if (kind == 21 || kind == 22) matvec_rows_mfma<MD, false>(P.m1, X, nullptr, n, Z);
+            else matvec_rows_mfma<MD, true>(P.m1, X, dsh, n, Z);
+        } else if constexpr (MD > 0 && KC > 0) {
             if (kind == 21 || kind == 22) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, X, nullptr, n, Z);
             else matvec_rows_scalar_kc<MD, true, KC, (MD == 40 ? 5 : 4)>(P.m1, X, dsh, n, Z);
         } else if constexpr (MD > 0) {
@@ -868,13 +919,13 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     if (kind == 7) {
         for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
-        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 12 || kind == 24) {
-        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
+        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
-        if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     }
 

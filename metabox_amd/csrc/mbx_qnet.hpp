@@ -4,8 +4,8 @@
 // (src/agent/de_ddqn_agent.py:26-36, networks.py:4-26).  As PyTorch ops this is five hipBLASLt GEMMs at 4.8 % MFMA utilisation plus ~10
 // element-wise launches (cast, bias, ReLU, argmax): 56 us of a 174 us step for 2240 instances (round 2).  M = 2240 rows and K = N = 100 cannot
 // fill a library tile, and a VALU kernel (round 1) was slower than the library; what the shape does fit is the 16 x 16 x 4 float32 MFMA:
-//   * a workgroup (4 waves) owns a tile of 16 instances; their activations sit in LDS as ACT[row][k] (float32, row stride padded to 132 words);
-//   * a layer K -> N is ceil(N / 16) column tiles x ceil(K / 4) chained v_mfma_f32_16x16x4_f32; wave w takes the column tiles w, w + 4, ..;
+//   * a workgroup (8 waves) owns a tile of 16 instances; their activations sit in LDS as ACT[row][k] (float32, row stride padded to 132 words);
+//   * a layer K -> N is ceil(N / 16) column tiles x ceil(K / 4) chained v_mfma_f32_16x16x4_f32; wave w takes the column tiles w, w + 8, .. (one per wave at width 100);
 //     A fragment (lane l: row l & 15, k = 4 s + (l >> 4)) is one LDS word, B fragment (k = 4 s + (l >> 4), column l & 15) one word of the
 //     TRANSPOSED weight matrix Wt[k][n] -- 16 consecutive words per k, four 64-byte segments per load -- straight from L2 (the 162 KB of
 //     weights are shared by all workgroups); the accumulator starts at the bias, so a layer's output is ONE float32 fma chain per unit,
@@ -33,8 +33,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kQTile = 16;       // instances per workgroup (one MFMA row tile)
 constexpr int kQStride = 132;    // words per activation row in LDS (>= 128, + 4 so that the 16 rows of an A fragment fall into different banks)
+#ifndef MBX_QNET_THREADS
+#define MBX_QNET_THREADS 512
+#endif
+constexpr int kQThreads = MBX_QNET_THREADS;   // 8 waves: one 16-column tile of a 100-wide layer per wave (7 tiles), i.e. ONE chain of 25 MFMAs per wave and layer
+constexpr int kQWaves = kQThreads / 64;
 
-// B fragments of one layer for this wave: column tiles wave, wave + 4 (at most TPW), K / 4 steps each
+// B fragments of one layer for this wave: column tiles wave, wave + kQWaves (at most TPW), K / 4 steps each
 template <int K, int N, int TPW>
 __device__ __forceinline__ void qnet_load_b(const float* __restrict__ Wt, int wave, int lane, float (&bf)[TPW][(K + 3) / 4])
 {
@@ -42,7 +47,7 @@ __device__ __forceinline__ void qnet_load_b(const float* __restrict__ Wt, int wa
     const int c = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-        const int n = 16 * (wave + 4 * j) + c;
+        const int n = 16 * (wave + kQWaves * j) + c;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k = 4 * s + q;
@@ -63,7 +68,7 @@ __device__ __forceinline__ void qnet_layer(const float* IN, float* OUT, const fl
     for (int s = 0; s < KS; ++s) a[s] = IN[c * kQStride + 4 * s + q];          // columns K .. 4 KS - 1 of IN are zero
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wave + kQWaves * j;
         if (16 * t >= N) continue;                                            // wave-uniform
         const int n = 16 * t + c;
         const float b0 = n < N ? bias[n] : 0.f;
@@ -81,13 +86,13 @@ __device__ __forceinline__ void qnet_layer(const float* IN, float* OUT, const fl
 }
 
 template <int IN, int W, int A>
-__global__ __launch_bounds__(kThreads) void k_qnet_argmax(QNet net, const double* __restrict__ state, int32_t* __restrict__ actions,
+__global__ __launch_bounds__(kQThreads) void k_qnet_argmax(QNet net, const double* __restrict__ state, int32_t* __restrict__ actions,
                                                           float* __restrict__ q_out, int B)
 {
     static_assert(IN <= 128 && W <= 128 && A <= 16, "k_qnet_argmax: one LDS row of 128 words per instance");
     __shared__ __attribute__((aligned(16))) float act0[kQTile * kQStride];
     __shared__ __attribute__((aligned(16))) float act1[kQTile * kQStride];
-    constexpr int TPW = ((W + 15) / 16 + 3) / 4;                               // column tiles per wave in the hidden layers
+    constexpr int TPW = ((W + 15) / 16 + kQWaves - 1) / kQWaves;                // column tiles per wave in the hidden layers
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * kQTile;
     const int nb = B - b0 < kQTile ? B - b0 : kQTile;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void k_qnet_argmax(QNet net, const double
     // the first layer's weights are on their way while the states are staged
     float bfa[TPW][(IN + 3) / 4];
     qnet_load_b<IN, W, TPW>(W1, wave, lane, bfa);
-    for (int t = tid; t < kQTile * kQStride; t += kThreads) {
+    for (int t = tid; t < kQTile * kQStride; t += kQThreads) {
         const int i = t / kQStride, k = t - i * kQStride;
         act0[t] = (i < nb && k < IN) ? (float)state[(int64_t)(b0 + i) * IN + k] : 0.f;
         act1[t] = 0.f;                                                        // padding columns of both buffers stay zero: only n < N is ever written
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_qnet_argmax(QNet net, const double
     __syncthreads();
     qnet_layer<W, W, TPW, true>(act0, act1, B3, wave, lane, bfc);
     float bfl[1][(W + 3) / 4];
-    qnet_load_b<W, A, 1>(W5, wave, lane, bfl);                                 // (waves 1 .. 3 load zeros: their column tile is empty)
+    qnet_load_b<W, A, 1>(W5, wave, lane, bfl);                                 // (waves 1 .. 7 load zeros: their column tile is empty)
     __syncthreads();
     qnet_layer<W, W, TPW, true>(act1, act0, B4, wave, lane, bfb);
     __syncthreads();
