@@ -246,12 +246,17 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     const FastDiv fd(D);
     // The parents' storage doubles as evaluator scratch; a thread's own four parent coordinates stay in registers across the
     // evaluation, so the rows that lose the selection need no second trip to HBM (larger populations re-read them).
-    const bool kept = NE <= 4 * MBX_NT;
-    double keep[4] = {0., 0., 0., 0.};
+    // (KG = 2 groups per thread would cover pop = 100 at D = 30 on 512 threads; measured: the eight more live doubles across the evaluation cost
+    // that instantiation more than the second read, 1.167 -> 1.239 ms per generation, so larger populations keep re-reading)
+    constexpr int KG = 1;
+    const bool kept = NE <= 4 * KG * MBX_NT;
+    double keep[KG][4];
+#pragma unroll
+    for (int gk = 0; gk < KG; ++gk) { keep[gk][0] = keep[gk][1] = keep[gk][2] = keep[gk][3] = 0.; }
     // A thread owns groups of four consecutive elements: ONE Philox call (site LDE_ELEM, index e >> 2) carries their four crossover uniforms,
     // 32 bits each (u <= CR against a float32 rate: 2^-32 resolution; include/mbx_layout.h section 3) -- a call per element spent a quarter of
     // the kernel's integer work on draws of which half the words were thrown away.
-    for (int t = tid; 4 * t < NE; t += MBX_NT) {
+    auto mutate_group = [&](int t, double (&kp)[4]) {
         U4 w{0, 0, 0, 0};
         if (!tape) w = rng.draw((uint32_t)t, MBX_SITE_LDE_ELEM);
 #pragma unroll
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
             else u = u32d(q == 0 ? w.x : q == 1 ? w.y : q == 2 ? w.z : w.w);
             if (d == L.JR[i]) u = 0.;
             const double xi = L.P[e], sf = L.SF[i], om = (double)(1.f - (float)sf);      // 1 - sf in float32, like the policy's tensor
-            if (kept) keep[q] = xi;
+            if (kept) kp[q] = xi;
             const int pidx = L.PIDX[i];
             double m;
             if (pidx == i) m = xi;
@@ -276,6 +281,11 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
             else if (c > ub) c = (xi + ub) / 2.;
             L.X[e] = c;
         }
+    };
+    if constexpr (KG == 1) { for (int t = tid; 4 * t < NE; t += MBX_NT) mutate_group(t, keep[0]); }
+    else {                                                           // two groups per thread, spelled out so that keep[][] stays in registers
+        if (4 * tid < NE) mutate_group(tid, keep[0]);
+        if (4 * (tid + MBX_NT) < NE) mutate_group(tid + MBX_NT, keep[KG - 1]);
     }
     __syncthreads();
     MBX_PHASE(2);                                                 // mutation + crossover
@@ -292,14 +302,19 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     }
     __syncthreads();
     // survivors take the trial vector; the other rows come back from the registers above (P's storage served as evaluator scratch meanwhile)
-    for (int t = tid; 4 * t < NE; t += MBX_NT) {                   // same element ownership as the mutation loop
+    auto select_group = [&](int t, const double (&kp)[4]) {         // same element ownership as the mutation
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = 4 * t + q;
             if (e >= NE) continue;
-            const double parent = !kept ? gPop[e] : keep[q];
+            const double parent = !kept ? gPop[e] : kp[q];
             L.P[e] = L.R0[fd.div(e)] ? L.X[e] : parent;
         }
+    };
+    if constexpr (KG == 1) { for (int t = tid; 4 * t < NE; t += MBX_NT) select_group(t, keep[0]); }
+    else {
+        if (4 * tid < NE) select_group(tid, keep[0]);
+        if (4 * (tid + MBX_NT) < NE) select_group(tid + MBX_NT, keep[KG - 1]);
     }
     double bsf_next; int bi;
     block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
