@@ -85,6 +85,25 @@ def test_ddqn_qnet_reproduces_reference_io_on_host():
     _check_ddqn_forward('cpu')
 
 
+def test_ddqn_packed_weights_follow_the_mbx_qnet_layout():
+    """DE_DDQN_Agent.packed_weights is what mbx_ddqn_qnet reads (include/mbx.h: per layer Wt [in][out] then b [out]): a plain numpy forward over
+    the packed buffer reproduces the reference module's recorded Q values."""
+    agent, pol = _check_ddqn_forward('cpu')
+    in_dim, width, depth, n_act = agent.qnet_shape()
+    assert (in_dim, width, depth, n_act) == (99, 100, 4, 4)
+    w = agent.packed_weights().numpy()
+    assert w.dtype == np.float32 and w.size == in_dim * width + width + (depth - 1) * (width * width + width) + width * n_act + n_act
+    x, off = pol['io/x'].astype(np.float32), 0
+    dims = [in_dim] + [width] * depth + [n_act]
+    for li, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        wt = w[off:off + a * b].reshape(a, b); off += a * b
+        bias = w[off:off + b]; off += b
+        x = x @ wt + bias
+        if li < len(dims) - 2:
+            x = np.maximum(x, 0)
+    assert off == w.size and np.abs(x - pol['io/q']).max() <= 1e-5
+
+
 def test_rlepso_critic_reproduces_reference_io_on_host():
     _check_rlepso_critic('cpu')
 
