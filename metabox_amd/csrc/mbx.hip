@@ -1013,7 +1013,7 @@ extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out
 }
 
 extern "C" const char* mbx_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mbx_version(void) { return "metabox_amd libmbx 0.3 (gfx950; Philox stream layout 2: include/mbx_layout.h section 3)"; }
+extern "C" const char* mbx_version(void) { return "metabox_amd libmbx 0.4 (gfx950; Philox stream layout 2: include/mbx_layout.h section 3; linear maps as fma chains)"; }
 
 #ifdef MBX_PHASE_TIMING
 // Instrumented builds only (not declared in include/mbx.h): cumulative per-phase cycles of k_rlepso_step (thread 0 of every
