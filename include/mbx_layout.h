@@ -169,6 +169,8 @@
 #define MBX_DQ_X_G0       6   /* row that X_gbest / X_prebest alias while they are numpy views (:55,58) */
 #define MBX_DQ_X_GBVIEW   7
 #define MBX_DQ_X_PREVIEW  8
+#define MBX_DQ_X_MEDLO    9   /* cache: the cost order statistics NP/2 - 1 and NP/2 the last update() found (NaN after reset); */
+#define MBX_DQ_X_MEDHI    10  /* the next update() re-validates them with one counting pass before it trusts them          */
 #define MBX_SITE_DQ_R      13u
 #define MBX_SITE_DQ_JRAND  14u
 /* mbx_gauss_policy: index j = action component, u53(w0,w1), u53(w2,w3) -> Box-Muller, first normal used */

@@ -305,8 +305,8 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
         if (protein) {
             // The energy kernel visits the atom pairs i < j only (eval_rows_protein), in the order of the folded rectangle
             // ceil(n / 2) x (n - 1): pair t = a (n - 1) + b is (a, a + 1 + b) for b < n - 1 - a, else (n - 1 - a, ...).  Its inputs are laid
-            // out in that order: `pyr` <- [n_pairs][4] = sqrt(e) | q | r | 0 (one 32-byte record per pair: lane t reads record t, fully
-            // coalesced), `plogw` <- the pair's atoms as int32 i | j << 16 (two per double).  Requires what the reference constructs
+            // out per pair: `pyr` <- [n_pairs][4] = sqrt(e) | q | r | 0 (one 32-byte record per pair: lane t reads record t, fully
+            // coalesced), `plogw` <- the pair's atoms as int32 i | j << 16 (two per double), -1 for an empty slot.  Requires what the reference constructs
             // (protein_docking.py:175-181): symmetric tables.
             const int n = d.n_peaks, W = n - 1, n_pairs = ((n + 1) / 2) * W;
             const double *se = d.pw, *qm = d.pw + NA * NA, *rm = d.pw + 2 * NA * NA;
@@ -314,15 +314,30 @@ extern "C" int mbx_suite_create(const mbx_problem_desc* descs, int n_problems, c
                 for (int c = a + 1; c < n; ++c)
                     if (se[a * n + c] != se[c * n + a] || qm[a * n + c] != qm[c * n + a] || rm[a * n + c] != rm[c * n + a])
                         return fail(MBX_E_ARG, "problem %d: the protein tables sqrt(e) | q | r must be symmetric (atoms %d, %d)", i, a, c);
+            // Pairs in ascending order of their distance in coor_init.  A move along the normal modes displaces an atom pair by a fraction of an
+            // Angstrom (|x| <= 1.5 over 1 / sqrt(eigval)), so the ~60 % of the pairs that start beyond the 9 A cut-off stay beyond it: they sit at the
+            // end of the list, whole waves see nothing but zero terms there and skip the arithmetic (eval_rows_protein checks the actual distance).
+            std::vector<int> pi_(n_pairs), pj_(n_pairs), order;
+            std::vector<double> d0(n_pairs, INFINITY);
+            for (int t = 0; t < n_pairs; ++t) {
+                const int a = t / W, b = t - a * W, La = W - a;
+                const bool lower = b >= La;
+                pi_[t] = lower ? W - a : a; pj_[t] = pi_[t] + 1 + (lower ? b - La : b);
+                if (lower && pi_[t] == a) { pi_[t] = -1; continue; }   // odd n: the middle atom's row appears once; the empty slots go last
+                double q2 = 0.;
+                for (int c = 0; c < 3; ++c) { const double dd = d.pc[3 * pi_[t] + c] - d.pc[3 * pj_[t] + c]; q2 += dd * dd; }
+                d0[t] = q2;
+            }
+            order.resize(n_pairs);
+            for (int t = 0; t < n_pairs; ++t) order[t] = t;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d0[x] < d0[y]; });
             std::vector<double> rec((size_t)n_pairs * 4, 0.);
             std::vector<double> ij((size_t)(n_pairs + 1) / 2, 0.);
             int32_t* ijw = reinterpret_cast<int32_t*>(ij.data());
             for (int t = 0; t < n_pairs; ++t) {
-                const int a = t / W, b = t - a * W, La = W - a;
-                const bool lower = b >= La;
-                const int pi = lower ? W - a : a, pj = pi + 1 + (lower ? b - La : b);
+                const int pi = pi_[order[t]], pj = pj_[order[t]];
+                if (pi < 0) { ijw[t] = -1; continue; }
                 ijw[t] = pi | (pj << 16);
-                if (lower && pi == a) { ijw[t] = -1; continue; }       // odd n: the middle atom's row appears once
                 rec[(size_t)t * 4] = se[pi * n + pj]; rec[(size_t)t * 4 + 1] = qm[pi * n + pj]; rec[(size_t)t * 4 + 2] = rm[pi * n + pj];
             }
             o.o[9] = push(rec.data(), rec.size());

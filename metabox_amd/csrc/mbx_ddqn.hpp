@@ -182,6 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* _
     if (tid == 0) {
         ex[MBX_DQ_X_GWORST] = gworst; ex[MBX_DQ_X_CPRE] = gb; ex[MBX_DQ_X_POINTER] = 0; ex[MBX_DQ_X_GEN] = 0; ex[MBX_DQ_X_STAG] = 0;
         ex[MBX_DQ_X_OMWLEN] = 0; ex[MBX_DQ_X_G0] = g0; ex[MBX_DQ_X_GBVIEW] = 1; ex[MBX_DQ_X_PREVIEW] = 1;
+        ex[MBX_DQ_X_MEDLO] = NAN; ex[MBX_DQ_X_MEDHI] = NAN;
         sc[MBX_SC_GBEST] = gb; sc[MBX_SC_FES] = NP; sc[MBX_SC_LOG_INDEX] = 1; sc[MBX_SC_COST_LEN] = 1; sc[MBX_SC_DONE] = 0;
         sc[MBX_SC_RETURN] = 0; sc[MBX_SC_GEN] = 0; sc[MBX_SC_EPISODE] = episode;
         sc[MBX_NSCALAR] = gb;
@@ -283,14 +284,34 @@ __global__ __launch_bounds__(kDqStepThreads) MBX_DQ_WAVES void k_dq_step(BatchPa
     MBX_PHASE(2);                                                 // evaluation
     // ---- median of the current costs (:171) by rank counting
     // c_i is the k-th smallest (0-based) iff #{c_j < c_i} <= k < #{c_j <= c_i}: equal costs are interchangeable for the VALUE at rank k, so no
-    // index tie-break is needed (two compares per pair instead of three and their logic)
-    for (int i = tid; i < NP; i += MBX_NT) {
-        const double ci = L.COST[i];
-        int nless = 0, nle = 0;
+    // index tie-break is needed (two compares per pair instead of three and their logic).
+    // A step replaces at most one cost, so the two order statistics the previous step found are usually still the ones: they are cached in the
+    // state (MBX_DQ_X_MEDLO / MEDHI) and re-validated by ONE counting pass over the cost vector (each thread a few elements, the four counts
+    // packed into one reduction); only when the replaced cost crossed them does the workgroup rank the whole vector (NP^2 compares, a tenth
+    // of the step's instructions when it ran every time).
+    {
+        const int K = NP / 2;
+        const double mlo = ex[MBX_DQ_X_MEDLO], mhi = ex[MBX_DQ_X_MEDHI];
+        double packed = 0.;                                          // four counts <= NP <= 256 in 12-bit fields of one exactly represented integer
+        for (int i = tid; i < NP; i += MBX_NT) {
+            const double c = L.COST[i];
+            packed += (double)((c < mhi) + ((c <= mhi) << 12)) + 16777216. * (double)((c < mlo) + ((c <= mlo) << 12));
+        }
+        const unsigned long long all = (unsigned long long)block_sum(packed, L.RED);
+        const int nl_hi = (int)(all & 4095), ne_hi = (int)((all >> 12) & 4095), nl_lo = (int)((all >> 24) & 4095), ne_lo = (int)((all >> 36) & 4095);
+        const bool valid = nl_hi <= K && K < ne_hi && ((NP & 1) || (nl_lo <= K - 1 && K - 1 < ne_lo));
+        if (valid) {
+            if (tid == 0) { L.RED[8] = mhi; L.RED[9] = mlo; }
+        } else {
+            for (int i = tid; i < NP; i += MBX_NT) {
+                const double ci = L.COST[i];
+                int nless = 0, nle = 0;
 #pragma unroll 4
-        for (int j = 0; j < NP; ++j) { const double cj = L.COST[j]; nless += cj < ci; nle += cj <= ci; }
-        if (nless <= NP / 2 && NP / 2 < nle) L.RED[8] = ci;
-        if (nless <= NP / 2 - 1 && NP / 2 - 1 < nle) L.RED[9] = ci;
+                for (int j = 0; j < NP; ++j) { const double cj = L.COST[j]; nless += cj < ci; nle += cj <= ci; }
+                if (nless <= K && K < nle) L.RED[8] = ci;
+                if (nless <= K - 1 && K - 1 < nle) L.RED[9] = ci;
+            }
+        }
     }
     __syncthreads();
     MBX_PHASE(3);                                                 // median
@@ -337,6 +358,7 @@ __global__ __launch_bounds__(kDqStepThreads) MBX_DQ_WAVES void k_dq_step(BatchPa
         const int s0 = dq_slot(0, gen);
         L.ntot()[action * MBX_DQ_GENMAX + s0] += 1;
         const double median = (NP & 1) ? L.RED[8] : (L.RED[9] + L.RED[8]) / 2;
+        ex[MBX_DQ_X_MEDHI] = L.RED[8]; ex[MBX_DQ_X_MEDLO] = (NP & 1) ? L.RED[8] : L.RED[9];
         const double om[4] = {cpv - tc, cpre - tc, gbest - tc, median - tc};
         for (int m = 0; m < 4; ++m)
             if (om[m] > 0) {

@@ -577,18 +577,29 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
         for (int t0 = tid; t0 < n_pairs; t0 += PF * MBX_NT) {
             double se[PF], q[PF], rr[PF], s[PF], g[PF], h[PF], e[PF], inv[PF], tv[PF];
             bool ok[PF];
-            // ---- fetch: one 4-byte index word and one 32-byte record per pair (lane t reads word / record t), eight LDS words
+            // ---- squared distance: one 4-byte index word per pair (lane t reads word t), eight LDS words
+            int tcl[PF];
+            bool close = false;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int t = t0 + u * MBX_NT;
                 const int tc = t < n_pairs ? t : n_pairs - 1;      // clamped: the loads are unconditional
                 const int w = pij[tc];
+                tcl[u] = tc;
                 ok[u] = t < n_pairs && w >= 0;
                 const int i = w < 0 ? 0 : (w & 0xffff), j = w < 0 ? 1 : (w >> 16);
-                const double2 a = rec[2 * tc], b = rec[2 * tc + 1];
-                se[u] = a.x; q[u] = a.y; rr[u] = b.x;
                 const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
                 s[u] = P2[i] - 2 * p3 + P2[j] + 0.01;              // >= 0.01 up to rounding: always a positive normal number
+                close = close || (ok[u] && s[u] < 81.01);
+            }
+            // The pairs come in ascending order of their distance in coor_init (mbx_suite_create) and a move displaces a pair by a fraction of an
+            // Angstrom, so the tail of the list -- ~60 % of the pairs -- is beyond the 9 A cut-off in every candidate.  sqrt(81.01) = 9.0006: at
+            // s >= 81.01 both distance windows are closed and the term is exactly 0, so a wave that sees no closer pair adds nothing and moves on.
+            if (!__any(close)) continue;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {                         // one 32-byte record per pair (lane t reads record t)
+                const double2 a = rec[2 * tcl[u]], b = rec[2 * tcl[u] + 1];
+                se[u] = a.x; q[u] = a.y; rr[u] = b.x;
             }
             // ---- pd = sqrt(s) and 1 / pd from one v_rsq_f64 estimate: two coupled Goldschmidt steps, one residual correction each
 #pragma unroll

@@ -123,7 +123,7 @@ def test_hip_ddqn_philox_parity_with_oracle():
         for key in ('ntot', 'nsucc'):
             assert np.array_equal(got[key], want[key]), (ids[k], key)
         assert close(got['extra'][:2], want['extra'][:2])                       # c_gworst, c_prebest (floating point)
-        assert np.array_equal(got['extra'][2:], want['extra'][2:]), ids[k]      # pointer, gen, stagcount, |OM_W|, aliases
+        assert np.array_equal(got['extra'][2:9], want['extra'][2:9]), ids[k]    # pointer, gen, stagcount, |OM_W|, aliases (slots 9 / 10: the kernel's median cache)
     b.close()
 
 
@@ -225,7 +225,7 @@ def test_hip_ddqn_philox_parity_with_oracle_on_protein():
         assert np.abs(got['X'] - want['X']).max() <= 1e-12 and np.all(np.abs(got['cost'] - want['cost']) <= 1e-5 * np.abs(want['cost']) + 1e-9)
         for key in ('ntot', 'nsucc'):
             assert np.array_equal(got[key], want[key]), (k, key)
-        assert np.array_equal(got['extra'][2:], want['extra'][2:]), k
+        assert np.array_equal(got['extra'][2:9], want['extra'][2:9]), k
     b.close()
 
 
