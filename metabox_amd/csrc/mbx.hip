@@ -774,12 +774,14 @@ extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const do
     if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->hidden < 1 || net->hidden > 64 || net->out_dim > 512)
         return fail(MBX_E_ARG, "mbx_lde_policy: network %d -> %d -> %d does not fit the batch (state %d, action %d; hidden <= 64)",
                     net->in_dim, net->hidden, net->out_dim, b->state_dim, b->action_dim);
-    const size_t lds = lstm_policy_lds_bytes(net->in_dim, net->hidden);
-    if (lds > (size_t)max_lds_bytes()) return fail(MBX_E_UNSUPPORTED, "mbx_lde_policy: %zu B of LDS needed", lds);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_policy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const LstmPolicy g{net->d_weights, net->in_dim, net->hidden, net->out_dim};
-    hipLaunchKernelGGL(k_lstm_policy, dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
-                       d_state, d_h, d_c, d_actions, d_mu_sigma);
+    {
+        const size_t lds = lstm_policy_lds_bytes(net->in_dim, net->hidden);
+        if (lds > (size_t)max_lds_bytes()) return fail(MBX_E_UNSUPPORTED, "mbx_lde_policy: %zu B of LDS needed", lds);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_policy<kLstmTile>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_lstm_policy<kLstmTile>, dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
+                           d_state, d_h, d_c, d_actions, d_mu_sigma);
+    }
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }
