@@ -778,9 +778,17 @@ extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const do
     {
         const size_t lds = lstm_policy_lds_bytes(net->in_dim, net->hidden);
         if (lds > (size_t)max_lds_bytes()) return fail(MBX_E_UNSUPPORTED, "mbx_lde_policy: %zu B of LDS needed", lds);
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_policy<kLstmTile>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_lstm_policy<kLstmTile>, dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream, make_params(b), g,
-                           d_state, d_h, d_c, d_actions, d_mu_sigma);
+#define MBX_LSTM_LAUNCH(...)                                                                                                                          \
+        do {                                                                                                                                          \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_policy<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+            hipLaunchKernelGGL((k_lstm_policy<__VA_ARGS__>), dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream,      \
+                               make_params(b), g, d_state, d_h, d_c, d_actions, d_mu_sigma);                                                          \
+        } while (0)
+        // the reference's PolicyNet (lde_agent.py:8-29: LSTM NP + 10 -> 50, heads 50 -> 2 NP) at config 3's two populations: compile-time dimensions
+        if (net->in_dim == 60 && net->hidden == 50 && net->out_dim == 100) MBX_LSTM_LAUNCH(kLstmTile, 60, 50, 100);
+        else if (net->in_dim == 110 && net->hidden == 50 && net->out_dim == 200) MBX_LSTM_LAUNCH(kLstmTile, 110, 50, 200);
+        else MBX_LSTM_LAUNCH(kLstmTile);
+#undef MBX_LSTM_LAUNCH
     }
     HIP_TRY(hipGetLastError());
     return MBX_OK;

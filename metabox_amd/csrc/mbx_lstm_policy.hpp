@@ -36,14 +36,16 @@ __host__ __device__ inline size_t lstm_policy_lds_bytes(int IN, int H, int TI = 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int TI>
+// INC / HC / AC: the network's dimensions at compile time (0 = taken from `net`): with the k-step counts known, ALL B fragments of an output tile are
+// loaded before its MFMA chain starts (one L2 round trip per tile instead of one per k-step, as in mbx_qnet.hpp); config 3's two networks get instantiations.
+template <int TI, int INC = 0, int HC = 0, int AC = 0>
 __global__ __launch_bounds__(kThreads) void k_lstm_policy(BatchParams bp, LstmPolicy net, const double* __restrict__ state, float* __restrict__ hbuf,
                                                           float* __restrict__ cbuf, float* __restrict__ actions, float* __restrict__ mu_sigma)
 {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     constexpr int RT = TI / 16;                                   // 16-instance row tiles per workgroup
     const int tid = threadIdx.x;
-    const int IN = net.in_dim, H = net.hidden, A = net.out_dim, G4 = 4 * H, K1 = IN + H;
+    const int IN = INC ? INC : net.in_dim, H = HC ? HC : net.hidden, A = AC ? AC : net.out_dim, G4 = 4 * H, K1 = IN + H;
     float* XS = lsm;                      // [K1][TI]   inputs: state (IN rows) then h (H rows)
     float* GT = XS + K1 * TI;             // [4H][TI]   gate pre-activations
     float* HN = GT + G4 * TI;             // [H][TI]    new hidden state
@@ -76,15 +78,34 @@ __global__ __launch_bounds__(kThreads) void k_lstm_policy(BatchParams bp, LstmPo
             lstm_f32x4 acc[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = lstm_f32x4{bias, bias, bias, bias};
-#pragma unroll 2
-            for (int s = 0; s < ks; ++s) {
-                const int k = 4 * s + qq;
-                float w = 0.f;
-                if (k < K1 && u < G4) w = k < IN ? WihT[(int64_t)k * G4 + u] : WhhT[(int64_t)(k - IN) * G4 + u];
+            if constexpr (INC > 0 && HC > 0) {
+                constexpr int KS = (INC + HC + 3) / 4;
+                float wv[KS];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const float a = k < K1 ? XS[k * TI + 16 * rt + cc] : 0.f;
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, acc[rt], 0, 0, 0);
+                for (int s = 0; s < KS; ++s) {
+                    const int k = 4 * s + qq;
+                    wv[s] = (k < INC + HC && u < G4) ? (k < INC ? WihT[k * (4 * HC) + u] : WhhT[(k - INC) * (4 * HC) + u]) : 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int k = 4 * s + qq;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float a = k < INC + HC ? XS[k * TI + 16 * rt + cc] : 0.f;
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[s], acc[rt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int s = 0; s < ks; ++s) {
+                    const int k = 4 * s + qq;
+                    float w = 0.f;
+                    if (k < K1 && u < G4) w = k < IN ? WihT[(int64_t)k * G4 + u] : WhhT[(int64_t)(k - IN) * G4 + u];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float a = k < K1 ? XS[k * TI + 16 * rt + cc] : 0.f;
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w, acc[rt], 0, 0, 0);
+                    }
                 }
             }
             if (u < G4) {
@@ -120,16 +141,37 @@ __global__ __launch_bounds__(kThreads) void k_lstm_policy(BatchParams bp, LstmPo
             lstm_f32x4 am[RT], as[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) { am[rt] = lstm_f32x4{b1, b1, b1, b1}; as[rt] = lstm_f32x4{b2, b2, b2, b2}; }
-#pragma unroll 2
-            for (int s = 0; s < ks; ++s) {
-                const int k = 4 * s + qq;
-                float wm = 0.f, ws = 0.f;
-                if (k < H && j < A) { wm = WmuT[(int64_t)k * A + j]; ws = WsgT[(int64_t)k * A + j]; }
+            if constexpr (HC > 0 && AC > 0) {
+                constexpr int KS = (HC + 3) / 4;
+                float wmv[KS], wsv[KS];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const float a = k < H ? HN[k * TI + 16 * rt + cc] : 0.f;
-                    am[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wm, am[rt], 0, 0, 0);
-                    as[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ws, as[rt], 0, 0, 0);
+                for (int s = 0; s < KS; ++s) {
+                    const int k = 4 * s + qq;
+                    const bool in = k < HC && j < AC;
+                    wmv[s] = in ? WmuT[k * AC + j] : 0.f; wsv[s] = in ? WsgT[k * AC + j] : 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int k = 4 * s + qq;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float a = k < HC ? HN[k * TI + 16 * rt + cc] : 0.f;
+                        am[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wmv[s], am[rt], 0, 0, 0);
+                        as[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wsv[s], as[rt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int s = 0; s < ks; ++s) {
+                    const int k = 4 * s + qq;
+                    float wm = 0.f, ws = 0.f;
+                    if (k < H && j < A) { wm = WmuT[(int64_t)k * A + j]; ws = WsgT[(int64_t)k * A + j]; }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float a = k < H ? HN[k * TI + 16 * rt + cc] : 0.f;
+                        am[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wm, am[rt], 0, 0, 0);
+                        as[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ws, as[rt], 0, 0, 0);
+                    }
                 }
             }
             if (j < A) {

@@ -161,6 +161,42 @@ def test_rlepso_critic_reproduces_reference_io_on_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('NP', [100, 30])
+def test_lde_policy_kernel_equals_the_pytorch_module_at_other_populations(NP):
+    """mbx_lde_policy at config 3's pop = 100 (the 110 -> 50 -> 200 instantiation with compile-time dimensions) and at a population that takes the
+    run-time-dimension kernel (NP = 30: 40 -> 50 -> 60): a seeded fresh PolicyNet of that shape (no shipped policy has these shapes), ragged batch."""
+    from metabox_amd._abi import ALGO_LDE
+    from metabox_amd.agent import LDE_Agent
+    from metabox_amd.suite import Batch, Suite
+    from helpers import problems
+    cfg = _cfg('bbob', 10, 'cuda')
+    cfg.NP_override = NP
+    torch.manual_seed(5)
+    net = LDE_Agent(cfg).to('cuda').net
+    ps = problems('bbob', 10)
+    suite = Suite([ps[k] for k in sorted(ps)])
+    B = 53
+    batch = Batch(suite, ALGO_LDE, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, NP, 20000, 400, 50)
+    batch.reset()
+    assert batch.state_dim == NP + 10 and batch.action_dim == 2 * NP
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.rand(1, B, NP + 10, device='cuda', generator=g)
+    h0, c0 = torch.randn(1, B, 50, device='cuda', generator=g) * 0.5, torch.randn(1, B, 50, device='cuda', generator=g)
+    with torch.no_grad():
+        want = [t[0].cpu().numpy() for t in net.forward(x, h0, c0)]
+    batch.state.copy_(x[0].to(torch.float64))
+    h, c = h0.clone().contiguous(), c0.clone().contiguous()
+    acts, ms = batch.lde_policy(net.packed_weights(), 50, h, c, want_mu_sigma=True)
+    torch.cuda.synchronize()
+    got = [ms[:, 0].cpu().numpy(), ms[:, 1].cpu().numpy(), h[0].cpu().numpy(), c[0].cpu().numpy()]
+    for name, g_, w_ in zip(('mu', 'sigma', 'h_out', 'c_out'), got, want):
+        assert np.abs(g_ - w_).max() <= 5e-6, (NP, name, np.abs(g_ - w_).max())
+    a = acts.cpu().numpy()
+    assert a.shape == (B, 2 * NP) and a.min() >= 0 and a.max() <= 1
+    batch.close()
+
+
+@pytest.mark.gpu
 def test_lde_policy_kernel_reproduces_reference_io():
     """mbx_lde_policy (the whole PolicyNet in one launch, what rollout_batch uses) on the recorded (x, h, c) -> (mu, sigma, h', c') pairs
     of the reference's module, and against the PyTorch modules on a ragged batch (B not a multiple of the 16-instance tile).

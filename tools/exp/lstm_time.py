@@ -22,5 +22,9 @@ for NP in (50, 100):
     e0.record()
     for _ in range(200): b.lde_policy(w, H, h, c)
     e1.record(); torch.cuda.synchronize()
-    print(json.dumps({'lib': os.path.basename(os.environ.get('MBX_LIB', 'libmbx.so')), 'pop': NP, 'k_lstm_policy_us': round(e0.elapsed_time(e1) / 200 * 1e3, 1)}))
+    t_all = e0.elapsed_time(e1) / 200 * 1e3
+    e0.record()
+    for _ in range(200): b.lde_policy(w, H, h, c, sample=False)
+    e1.record(); torch.cuda.synchronize()
+    print(json.dumps({'lib': os.path.basename(os.environ.get('MBX_LIB', 'libmbx.so')), 'pop': NP, 'k_lstm_policy_us': round(t_all, 1), 'without_sampling_us': round(e0.elapsed_time(e1) / 200 * 1e3, 1)}))
     b.close()
