@@ -898,6 +898,9 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
             }
         }
 #endif
+        // (Measured and dropped, round 3: dealing config 5's half-empty last pass -- 512 items of the highest ranks on 1024 threads -- as single
+        // coordinates, one per thread, so that every wave scans: 1.80 -> 1.94 ms per generation; the one-coordinate scan repeats the cost difference
+        // and the LDS reads per candidate, which costs more than the idle waves did.)
         __syncthreads();
         // ---- velocity / position update (:179-195): new position -> X, new velocity -> register
         {
