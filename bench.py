@@ -306,10 +306,10 @@ def other_configs(budget_s=60.0):
 
             def run5(n, b=b, table=table):
                 b.rlepso_rollout(table, n)                 # n generations in ONE resident launch (k_rlepso_run<1024, 128, 40, 5>)
-            run5(2)
-            dt = _bracket(run5, 8)
+            run5(4)
+            dt = sorted(_bracket(run5, 20) for _ in range(3))[1]      # launches of 20 generations like the headline window (an episode is 624); median of 3
             S5 = (3 * NP5 * D5 + 3 * NP5 + D5 + 1) * 8 + 16
-            entry('config 5: RLEPSO mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances (one GPU of eight), mbx_rlepso_rollout (8 generations per launch)', B, dt,
+            entry('config 5: RLEPSO mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances (one GPU of eight), mbx_rlepso_rollout (20 generations per launch, median of 3 launches)', B, dt,
                   2 * S5 + 4 * 35 + (D5 * D5 + D5 + 2) * 8 + 13, {'launch_info': b.launch_info()})
             b.close()
     return out

@@ -142,7 +142,7 @@ class LDE_Agent(Basic_Agent):
         return state, h, c
 
     def policy_route(self, policy='hip'):
-        return {'hip': 'mbx_lde_policy: LSTM cell + both heads + sampling in ONE hand-written launch per generation (float32 VALU, weights in L2)',
+        return {'hip': 'mbx_lde_policy: LSTM cell + both heads + sampling in ONE hand-written launch per generation (gate and head products on the float32 matrix cores, weights in L2)',
                 'torch': 'PyTorch-ROCm: one LSTM cell + two linear heads over [B, NP + 10] per generation (rocBLAS / hipBLASLt GEMMs)'}[policy]
 
     @torch.no_grad()

@@ -31,7 +31,7 @@ typedef float lstm_f32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int64_t lstm_policy_floats(int IN, int H, int A) { return (int64_t)(IN + H) * 4 * H + 4 * H + 2 * (int64_t)H * A + 2 * A; }
 __host__ __device__ inline size_t lstm_policy_lds_bytes(int IN, int H, int TI = kLstmTile) { return sizeof(float) * (size_t)((IN + H) * TI + 4 * H * TI + H * TI); }
 // (TI: instances per workgroup, a multiple of 16.  Measured on one box, 16 384 instances, pop 50 / 100: float32 VALU kernel 63.8 / 81.0 us, this kernel at
-// TI = 16 50.9 / 79.5 us, at TI = 64 -- four row tiles per B fragment, a quarter of the weight traffic, one workgroup per CU -- 78.6 / 125.1 us: the launch is
+// TI = 16 50.9 / 79.5 us (33.5 / 50.8 us with the compile-time dimensions below), at TI = 64 -- four row tiles per B fragment, a quarter of the weight traffic, one workgroup per CU -- 78.6 / 125.1 us: the launch is
 // bound by the latency chains of its workgroups, not by weight traffic or matrix work, so the small tile with six workgroups per CU stays.)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
