@@ -537,6 +537,10 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // (128 VGPRs, two workgroups per CU) lost 17 % (1123 -> 1314 us), and config 5's resident kernel (velocities / pbest positions in registers next to it)
 // 33 % (1.87 -> 2.50 ms): only config 5's one-generation kernel k_rlepso_step<1024, 128, 40, 5> takes it (Gallagher-101 evaluation 203 k -> 83 k cycles)
 constexpr bool gallagher_blocked(int md, int kc) { return md == 40 && kc == 0; }
+#ifndef MBX_GALLAGHER_LEAN
+#define MBX_GALLAGHER_LEAN 1
+#endif
+constexpr bool gallagher_lean(int md, int kc) { (void)kc; return MBX_GALLAGHER_LEAN && md == 30; }
 
 // which compile-time geometries take the matrix-core matvec (matvec_rows_mfma): MBX_MFMA_MATVEC = 0 none, 1 the D = 30 kernels (LDE, RLEPSO --dim 30),
 // 2 also D = 40 (config 5)
@@ -742,6 +746,52 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
                         for (int d = 0; d < DC; ++d) { const double zd = rx[d] - py[kk * DC + d]; acc = __builtin_fma(pcc[kk * DC + d], zd * zd, acc); }
                         const double key = plw[kk] + cexp * acc;
                         if (key > bkey[q]) { bkey[q] = key; bk[q] = kk; }
+                    }
+                }
+            }
+        } else if constexpr (gallagher_lean(MD, KC)) {
+            // D = 30 (LDE, RLEPSO --dim 30): the same idea as the blocked route below with a footprint that fits these kernels' register caps -- four peaks
+            // as accumulators, the row in chunks of six coordinates, one row group at a time: one LDS read of the row per FOUR peaks instead of per peak.
+            // LDE pop 50: the three Gallagher functions 919 -> 825 us per generation of 16 384 instances, all 30 noisy functions 539 -> 529 us; config 3
+            // 0.566 -> 0.556 ms (pop 50), 1.141 -> 1.130 ms (pop 100) (A/B on one box).
+            typedef const double __attribute__((address_space(4)))* kptr;
+            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
+            const int wv = __builtin_amdgcn_readfirstlane(wave), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+            constexpr int PB = 4, GC = 6;
+            static_assert(MD % GC == 0, "whole chunks only");
+            const int mine = wv < npk ? (npk - wv + nw - 1) / nw : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (64 * q >= n) break;                                      // wave-uniform
+                const int i = lane + 64 * q;
+                const double* rx = Z + (i < n ? i : n - 1) * MD;
+                for (int j0 = 0; j0 < mine; j0 += PB) {
+                    double acc[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) acc[j] = 0.;
+#pragma unroll 1
+                    for (int c0 = 0; c0 < MD; c0 += GC) {
+                        double y[GC];
+#pragma unroll
+                        for (int k = 0; k < GC; ++k) y[k] = rx[c0 + k];
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) {
+                            if (j0 + j < mine) {                             // wave-uniform
+                                const int kk = wv + (j0 + j) * nw;
+                                const kptr ry = py + (int64_t)kk * MD + c0;
+                                const kptr ck = pcc + (int64_t)kk * MD + c0;
+#pragma unroll
+                                for (int k = 0; k < GC; ++k) { const double zd = y[k] - ry[k]; acc[j] = __builtin_fma(ck[k], zd * zd, acc[j]); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        if (j0 + j < mine) {
+                            const int kk = wv + (j0 + j) * nw;
+                            const double key = plw[kk] + cexp * acc[j];
+                            if (key > bkey[q]) { bkey[q] = key; bk[q] = kk; }
+                        }
                     }
                 }
             }
