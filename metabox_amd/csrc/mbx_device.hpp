@@ -538,9 +538,9 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // 33 % (1.87 -> 2.50 ms): only config 5's one-generation kernel k_rlepso_step<1024, 128, 40, 5> takes it (Gallagher-101 evaluation 203 k -> 83 k cycles)
 constexpr bool gallagher_blocked(int md, int kc) { return md == 40 && kc == 0; }
 #ifndef MBX_GALLAGHER_LEAN
-#define MBX_GALLAGHER_LEAN 1
+#define MBX_GALLAGHER_LEAN 2
 #endif
-constexpr bool gallagher_lean(int md, int kc) { (void)kc; return MBX_GALLAGHER_LEAN && md == 30; }
+constexpr bool gallagher_lean(int md, int kc) { return MBX_GALLAGHER_LEAN && (md == 30 || (MBX_GALLAGHER_LEAN >= 2 && md == 40 && kc > 0)); }
 
 // which compile-time geometries take the matrix-core matvec (matvec_rows_mfma): MBX_MFMA_MATVEC = 0 none, 1 the D = 30 kernels (LDE, RLEPSO --dim 30),
 // 2 also D = 40 (config 5)
@@ -750,14 +750,15 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
                 }
             }
         } else if constexpr (gallagher_lean(MD, KC)) {
-            // D = 30 (LDE, RLEPSO --dim 30): the same idea as the blocked route below with a footprint that fits these kernels' register caps -- four peaks
-            // as accumulators, the row in chunks of six coordinates, one row group at a time: one LDS read of the row per FOUR peaks instead of per peak.
+            // D = 30 (LDE, RLEPSO --dim 30) and config 5's resident kernel (D = 40): the same idea as the blocked route below with a footprint that fits these
+            // kernels' register caps -- four peaks as accumulators, the row in chunks of six (five at D = 40) coordinates, one row group at a time: one LDS read of the row per FOUR peaks instead of per peak.
             // LDE pop 50: the three Gallagher functions 919 -> 825 us per generation of 16 384 instances, all 30 noisy functions 539 -> 529 us; config 3
-            // 0.566 -> 0.556 ms (pop 50), 1.141 -> 1.130 ms (pop 100) (A/B on one box).
+            // 0.566 -> 0.556 ms (pop 50), 1.141 -> 1.130 ms (pop 100); config 5's resident kernel on a batch of F21 / F128 only 3.86 -> 2.64 ms per generation
+            // (A/B on one box).
             typedef const double __attribute__((address_space(4)))* kptr;
             const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
             const int wv = __builtin_amdgcn_readfirstlane(wave), nw = __builtin_amdgcn_readfirstlane(MBX_NW);
-            constexpr int PB = 4, GC = 6;
+            constexpr int PB = 4, GC = MD == 40 ? 5 : 6;
             static_assert(MD % GC == 0, "whole chunks only");
             const int mine = wv < npk ? (npk - wv + nw - 1) / nw : 0;
 #pragma unroll
