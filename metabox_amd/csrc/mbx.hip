@@ -444,9 +444,10 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
         const int k = s->h_problems[pi].kind;
         switch (k) {
         case MBX_KIND_PROTEIN: return 3000;
-        case 16: case 21: return 390; case 15: return 322; case 17: case 18: return 319; case 3: return 310;
-        case 4: return 285; case 2: case 10: case 11: return 277; case 23: return 268; case 22: return 263;
-        case 12: return 248; case 14: return 241; case 5: return 188; default: return 225;
+        // (round 3, profiles/r03b_phase_cycles_per_function.jsonl: one-generation kernel, us per generation of 4096 instances of that function)
+        case 21: return 189; case 3: case 16: return 163; case 15: return 160; case 17: case 18: return 159; case 23: return 157;
+        case 2: return 150; case 4: return 146; case 22: return 140; case 10: case 11: return 137; case 12: return 136; case 7: return 135;
+        case 1: return 133; case 14: case 20: return 130; case 19: case 6: case 24: return 128; case 5: return 114; default: return 121;
         }
     };
     std::vector<int32_t> order(n_instances);
