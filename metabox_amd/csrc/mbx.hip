@@ -442,6 +442,15 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     const int n_instances = b->B;
     auto weight = [&](int pi) -> int {
         const int k = s->h_problems[pi].kind;
+        if (s->dim >= 16 && k != MBX_KIND_PROTEIN) {
+            // large dimensions (tools/exp/kind_costs.py: RLEPSO D = 40, NP = 128, us per generation of 4096 instances of that function, round 3): the
+            // matvecs and the peak search weigh more than at D = 10, Gallagher-21 moves up to second place
+            switch (k) {
+            case 21: return 1314; case 22: return 1049; case 16: return 1024; case 15: return 1008; case 17: case 18: return 988; case 3: return 928;
+            case 23: return 902; case 4: return 880; case 7: return 843; case 12: return 829; case 2: case 10: case 11: return 803; case 24: return 776;
+            case 14: return 754; case 19: return 735; case 20: return 715; case 6: return 707; case 5: return 625; default: return 694;
+            }
+        }
         switch (k) {
         case MBX_KIND_PROTEIN: return 3000;
         // (round 3, profiles/r03b_phase_cycles_per_function.jsonl: one-generation kernel, us per generation of 4096 instances of that function)
