@@ -415,6 +415,9 @@ __device__ __forceinline__ void matvec_rows_scalar(const double* __restrict__ Mg
 // The same scheme for kernels with a tight register budget (k_lde_step<512, 50, 30>: 80 VGPRs): the row is taken in chunks of KC values and up to
 // UMAX outputs of the wave are accumulated side by side, so 2 KC + 2 UMAX registers replace the 2 MD of matvec_rows_scalar.  Every output still runs
 // its fma chain in ascending k: bit-identical.
+#ifndef MBX_UMAX40
+#define MBX_UMAX40 5      // outputs accumulated side by side at D = 40 (A/B on one box with KC = 8: 4 / 5 / 8 -> see DESIGN.md)
+#endif
 template <int MD, bool SUB, int KC, int UMAX>
 __device__ __forceinline__ void matvec_rows_scalar_kc(const double* __restrict__ Mg, const double* In, const double* sub, int n, double* Out)
 {
@@ -699,8 +702,8 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
             if (kind == 21 || kind == 22) matvec_rows_mfma<MD, false>(P.m1, X, nullptr, n, Z);
             else matvec_rows_mfma<MD, true>(P.m1, X, dsh, n, Z);
         } else if constexpr (MD > 0 && KC > 0) {
-            if (kind == 21 || kind == 22) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, X, nullptr, n, Z);
-            else matvec_rows_scalar_kc<MD, true, KC, (MD == 40 ? 5 : 4)>(P.m1, X, dsh, n, Z);
+            if (kind == 21 || kind == 22) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? MBX_UMAX40 : 4)>(P.m1, X, nullptr, n, Z);
+            else matvec_rows_scalar_kc<MD, true, KC, (MD == 40 ? MBX_UMAX40 : 4)>(P.m1, X, dsh, n, Z);
         } else if constexpr (MD > 0) {
             if (kind == 21 || kind == 22) matvec_rows_scalar<MD, false>(P.m1, X, nullptr, n, Z);
             else matvec_rows_scalar<MD, true>(P.m1, X, dsh, n, Z);
@@ -981,13 +984,13 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
     if (kind == 7) {
         for (int i = tid; i < n; i += MBX_NT) F[i] = fabs(Z[i * D]);
         __syncthreads();
-        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? MBX_UMAX40 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 12 || kind == 24) {
-        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
+        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? MBX_UMAX40 : 4)>(P.m1, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m1, T, nullptr, n, Z); else matvec_rows(M1T, T, n, D, Z);
         __syncthreads();
     } else if (kind == 15 || kind == 16 || kind == 17 || kind == 18) {
-        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? 5 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
+        if constexpr (mfma_matvec(MD, KC)) matvec_rows_mfma<MD, false>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0 && KC > 0) matvec_rows_scalar_kc<MD, false, KC, (MD == 40 ? MBX_UMAX40 : 4)>(P.m2, T, nullptr, n, Z); else if constexpr (MD > 0) matvec_rows_scalar<MD, false>(P.m2, T, nullptr, n, Z); else matvec_rows(M2T, T, n, D, Z);
         __syncthreads();
     }
 

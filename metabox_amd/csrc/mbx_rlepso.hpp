@@ -69,9 +69,10 @@ __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
 
 // chunk of the register-resident row in the resident kernel's matvec (matvec_rows_scalar_kc; 0: whole row): at D = 40 the 80 row registers collide
 // with the resident velocities / pbest positions
-// (config 5, A/B on one box: whole row 2.00 ms, chunks of 20 / 10 / 8: 1.886 / 1.830 / 1.854 ms per generation of 8192 instances)
+// (config 5, A/B on one box: whole row 2.00 ms, chunks of 20 / 10 / 8: 1.886 / 1.830 / 1.854 ms per generation of 8192 instances in round 2; with the
+// fma-chain matvec, round 3: whole row 2.53, chunks of 20 / 10 / 8 / 5 / 4: 1.667 / 1.672 / 1.628 / 1.887 / 1.700 ms -- register allocation, not arithmetic, decides)
 #ifndef MBX_RUN_KC40
-#define MBX_RUN_KC40 10
+#define MBX_RUN_KC40 8
 #endif
 #ifndef MBX_RUN_KC30
 #define MBX_RUN_KC30 0
