@@ -321,7 +321,7 @@ def test_fused_act_step_equals_policy_then_step():
     env_a.close(); env_b.close()
 
 
-def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None, resident=True):
+def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None, resident=True, early_stop=True):
     """One resident launch per chunk (mbx_rlepso_rollout) against one mbx_rlepso_act_step launch per generation on a twin batch:
     whole state blocks, trajectories and result tables must agree bit for bit."""
     from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
@@ -338,8 +338,8 @@ def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None, resident=T
     s = Suite(ps)
     maxfes = maxfes or 2000 * dim
     pidx, seeds = np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) * 104729 + 11
-    a = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50)
-    b = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50)
+    a = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50, early_stop=early_stop)
+    b = Batch(s, ALGO_RLEPSO, pidx, seeds, np_, maxfes, maxfes // 50, 50, early_stop=early_stop)
     table = a.policy_table(*net)
     assert a.rollout_is_resident() == resident                      # the route mbx_rlepso_rollout takes is not silent (mbx_rlepso_rollout_resident)
     with pytest.raises(ValueError):
@@ -363,7 +363,8 @@ def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None, resident=T
     ra, rb_ = a.results(), b.results()
     for key in ra:
         assert torch.equal(ra[key], rb_[key]), key
-    out = {'steps': ra['steps'].cpu().numpy(), 'fes': ra['fes'].cpu().numpy()}
+    out = {'steps': ra['steps'].cpu().numpy(), 'fes': ra['fes'].cpu().numpy(),
+           'pbest': np.stack([oracle.split_rlepso_state(a.read_state(k), np_, dim, 50)['pbest'] for k in range(B)])}
     a.close(); b.close()
     return out
 
@@ -375,6 +376,16 @@ def test_resident_rollout_equals_one_launch_per_generation():
     assert (r['steps'] < 199).any() and (r['fes'] >= 20000).any() and (r['fes'] % 100 != 0).any()      # re-initialisations bill odd FEs
     r = _rollout_case('bbob-noisy', 10, (101, 105, 115, 122, 128, 130), 100, 60, (25, 180))
     assert (r['fes'] >= 20000).any()
+
+
+def test_resident_ranking_orders_equal_costs_like_the_one_generation_kernel():
+    """k_rlepso_run ranks the particles with ONE compare per pair and falls back to the index tie-break only when two pbest costs are exactly
+    equal (a contested slot of ORDER); k_rlepso_step always counts `<` and `<=`.  Linear slope without the stop rule collapses onto the optimum
+    corner (cost exactly 0 for many particles) and the step ellipsoid has plateaus: long runs of both must stay bit-identical between the two
+    kernels, and the final states must really hold equal costs (otherwise the fallback was never taken)."""
+    r = _rollout_case('bbob', 10, (5, 7), 100, 32, (70, 50, 30), early_stop=False)
+    ties = [(len(row) - len(np.unique(row))) for row in r['pbest']]
+    assert max(ties) >= 5, ties
 
 
 @pytest.mark.parametrize('suite_name', ['bbob', 'bbob-noisy'])
