@@ -96,6 +96,46 @@ def test_hip_energy_matches_reference_and_oracle():
 
 
 @pytest.mark.gpu
+def test_suite_rejects_asymmetric_protein_tables_and_odd_atom_counts_work():
+    """The energy kernel evaluates the pairs i < j only (the reference's tables are symmetric by construction, protein_docking.py:175-181):
+    mbx_suite_create must refuse tables that are not, and the folded pair list must also cover an odd number of atoms (the middle atom's row
+    appears once) -- checked against the oracle, which sums all n^2 pairs."""
+    from metabox_amd._abi import MbxError
+    from metabox_amd.suite import Suite
+    byid = protein()[0]
+    p = byid[sorted(byid)[0]]
+
+    class Tampered:
+        def __init__(self, base, fn):
+            self.base, self.fn = base, fn
+            self.dim, self.lb, self.ub, self.optimum = base.dim, base.lb, base.ub, None
+
+        def desc(self):
+            return self.fn(dict(self.base.desc()))
+
+    def asym(d):
+        pw = d['pw'].copy(); n = d['n_peaks']
+        pw[2 * n * n + 3 * n + 7] += 1e-3                               # r[3][7] != r[7][3]
+        d['pw'] = pw
+        return d
+    with pytest.raises(MbxError):
+        Suite([Tampered(p, asym)])
+
+    def odd(d):                                                         # drop the last atom: n = 99
+        n = d['n_peaks']; m = n - 1
+        t = d['pw'].reshape(3, n, n)[:, :m, :m]
+        d['pw'] = np.ascontiguousarray(t).ravel(); d['n_peaks'] = m
+        d['py'] = np.ascontiguousarray(d['py'].reshape(-1, n, 3)[:, :m].reshape(d['py'].shape[0], 3 * m))
+        d['pc'] = np.ascontiguousarray(d['pc'].reshape(n, 3)[:m]).ravel()
+        return d
+    q = Tampered(p, odd)
+    s = Suite([q])
+    X = np.random.RandomState(4).uniform(-1.5, 1.5, size=(9, 12))
+    g = oracle.evaluate(q.desc(), X)
+    assert np.all(np.abs(s.eval(0, X) - g) <= 1e-9 * np.abs(g))
+
+
+@pytest.mark.gpu
 def test_hip_rlepso_and_lde_on_protein_replay_reference():
     import torch
     from metabox_amd.suite import Batch, Suite
