@@ -152,6 +152,42 @@ def pmc_traffic_per_launch(live_per_launch, resident=False):
         return None, None
 
 
+def pmc_traffic_in_run(instances, timeout_s=150):
+    """HBM bytes per env-step of k_rlepso_run measured DURING this bench run, the way MI355X_MICROARCH.md prescribes: two separate rocprofv3
+    passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; no trace domains) of a child `bench.py --steps 20 --warmup 2 --repeats 1` (generations 3-22 of an
+    episode: every instance live, one 20-generation launch), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of that launch (FETCH_SIZE under-reports
+    these loads x2 on gfx950, WRITE_SIZE is 1:1: calibration in profiles/README.md), divided by its instances x 20 env-steps.
+    Returns (bytes per env-step, note) or (None, reason)."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    tmp = tempfile.mkdtemp(prefix='mbx_pmc_')
+    got = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, MBX_BENCH_CHILD='1', TMPDIR='/tmp')
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable, os.path.abspath(__file__), '--steps', '20',
+                   '--warmup', '2', '--repeats', '1', '--instances', str(instances), '--no-cpu-baseline', '--no-other-configs']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for path in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if 'k_rlepso_run' in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                            vals.append(float(row['Counter_Value']))
+            if r.returncode != 0 or not vals:
+                return None, f'rocprofv3 --pmc {counter} pass failed (rc {r.returncode})'
+            got[counter] = max(vals)                      # the 20-generation launch (the other dispatch is the 2-generation warm-up)
+        return (2 * got['FETCH_SIZE'] + got['WRITE_SIZE']) * 1024 / (instances * 20), \
+            f"2 x FETCH_SIZE ({got['FETCH_SIZE']:.0f} KB) + WRITE_SIZE ({got['WRITE_SIZE']:.0f} KB) of one 20-generation launch with {instances} live instances"
+    except Exception as e:                                # a profiler hiccup must never take the bench line down
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def valu_roofline(live_per_gen, avg_gen_s, resident=False):
     """VALU side of the roofline ('report both achieved GB/s and VALU utilisation'), per GENERATION of the batch:
     wave-instructions by class from the committed PMC profile x the issue cost of each class measured with tools/ubench/valu_rates.hip,
@@ -326,6 +362,7 @@ def main():
                          '(~2 s of timed windows), the line reports the median repeat')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the configs 3 / 4 / 5 legs (other_configs)')
+    ap.add_argument('--no-pmc', action='store_true', help='do not collect roofline.traffic in this run (two rocprofv3 --pmc child passes, ~40 s); use the newest committed profile')
     ap.add_argument('--functions', default='all24',
                     help="all24 (default: every bbob function round-robin), train18 (the bbob-easy train split), or a comma list of "
                          "function ids (SURVEY §8(d) C2 asks for the split and per-function figures next to the headline)")
@@ -569,6 +606,11 @@ def main():
         bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         traffic, traffic_src = pmc_traffic_per_launch(live_per_launch, resident)
+        traffic_in_run, traffic_note = False, None
+        if resident and world == 1 and not args.no_pmc and not os.environ.get('MBX_BENCH_CHILD'):
+            per_step, traffic_note = pmc_traffic_in_run(B)
+            if per_step is not None:
+                traffic, traffic_in_run = per_step * live_per_launch, True
         first_gen = W % EPISODE_GENS + 1
         out = {
             'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
@@ -599,9 +641,11 @@ def main():
                        'timed_window': f'{K} consecutive lock-step generations starting at generation {first_gen} of an episode of {EPISODE_GENS} '
                                        f'(episodes restart with mbx_reset inside the window when it is longer)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_in_run': False,
-                         'traffic_source': (f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
-                                            f"run's live instances (not collected during this run)") if traffic_src else None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_measured_in_run': traffic_in_run,
+                         'traffic_source': (f'collected during this run: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of a child bench.py --steps 20 --warmup 2 '
+                                            f'(every instance live): {traffic_note}; scaled to the env-steps of an average launch of this run') if traffic_in_run else
+                                           ((f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
+                                             f"run's live instances (not collected during this run" + (f': {traffic_note}' if traffic_note else '') + ')') if traffic_src else None),
                          'kernel': 'k_rlepso_run<256, 100, 10, 5>' if resident else 'k_rlepso_step<256, 100, 10, 5>',
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
