@@ -133,8 +133,7 @@ __device__ __forceinline__ void philox_noise(const Rng& rng, uint32_t row, uint3
     U4 w = rng.draw(row, siteA);
     const double ua = u53(w.x, w.y), ub = u53(w.z, w.w);
     if (noise_kind == MBX_NOISE_GAUSS) {
-        double n1;
-        box_muller(ua, ub, a, n1);
+        a = sqrt(-2.0 * m_log(1.0 - ua)) * m_cos(kTwoPi * ub);       // the cosine half of box_muller: the sine half is not used (an out-of-line call the compiler cannot drop)
     } else if (noise_kind == MBX_NOISE_UNIFORM) {
         a = ua; b = ub;
     } else {
