@@ -52,7 +52,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d['repeats'] >= 30 and 0 <= d['spread'] < 1.0 and d['timed_region_s'] >= d['repeats'] * d['repeat_ms_per_step']['min'] * 1e-3 * d['steps'] * 0.999
     assert d['repeat_ms_per_step']['min'] <= d['ms_per_step'] <= d['repeat_ms_per_step']['max']
     # the HBM traffic is collected during the run (two rocprofv3 --pmc child passes) when rocprofv3 is there, else taken from the committed profile
-    assert isinstance(r['traffic_measured_in_run'], bool) and ('collected during this run' in r['traffic_source']) == r['traffic_measured_in_run']
+    assert isinstance(r['traffic_measured_in_run'], bool) and ('collected during this run' in (r['traffic_source'] or '')) == r['traffic_measured_in_run']
     assert r['traffic'] is None or 0 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 1.0
     # event brackets are net of the empty-pair cost: the launch cannot take longer than the steps it contains
     assert r['avg_kernel_us'] <= d['ms_per_step'] * 1e3 * r['generations_per_launch'] * 1.02
