@@ -120,7 +120,7 @@
 #define MBX_LDE_BINS 5
 #define MBX_LDE_ST_POP(NP, D)      ((int64_t)0)
 #define MBX_LDE_ST_FIT(NP, D)      ((int64_t)(NP) * (D))
-#define MBX_LDE_ST_HSUM(NP, D)     ((int64_t)(NP) * (D) + (NP))
+#define MBX_LDE_ST_HSUM(NP, D)     ((int64_t)(NP) * (D) + (NP))      /* 8 doubles: [0..5) running sum of past_histo, [5] the last histogram, packed 10 bits per bin */
 #define MBX_LDE_ST_SCALARS(NP, D)  ((int64_t)(NP) * (D) + (NP) + 8)
 #define MBX_LDE_STATE_DOUBLES(NP, D, NLOG) (MBX_LDE_ST_SCALARS(NP, D) + MBX_NSCALAR + (int64_t)(NLOG) + 1)
 #define MBX_SC_HCOUNT 10

@@ -88,6 +88,15 @@ __device__ __forceinline__ void lde_norm_hist(const double* F, int NP, double* N
     __syncthreads();
 }
 
+// the five bin counts (each <= NP <= 256) as one exactly represented integer, 10 bits per bin
+__device__ __forceinline__ double lde_pack_hist(const int* H)
+{
+    unsigned long long v = 0;
+    for (int k = MBX_LDE_BINS - 1; k >= 0; --k) v = (v << 10) | (unsigned long long)(H[k] & 1023);
+    return (double)v;
+}
+__device__ __forceinline__ int lde_unpack_hist(double packed, int k) { return (int)(((unsigned long long)packed >> (10 * k)) & 1023); }
+
 // __order_by_f (stable) + __get_feature (lde_optimizer.py:74-79,145-157): rows of L.P with fitness L.FIT are written
 // to HBM in ascending-fitness order and the [NP+10] state vector is emitted.  hs/hcount = past_histo sum / length.
 __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, double* gPop, double* gFit, const double* hs,
@@ -165,6 +174,7 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
     block_argmin(L.NC, NP, L.RED, gb, gi);
     lde_sort_emit(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, 1., state_out + (int64_t)b * (NP + 10));
     if (tid == 0) {
+        S[MBX_LDE_ST_HSUM(NP, D) + MBX_LDE_BINS] = lde_pack_hist(L.HIST);            // the histogram of the state just emitted: the next update()'s past_histo entry
         sc[MBX_SC_GBEST] = gb; sc[MBX_SC_FES] = NP; sc[MBX_SC_LOG_INDEX] = 1; sc[MBX_SC_COST_LEN] = 1;
         sc[MBX_SC_DONE] = 0; sc[MBX_SC_RETURN] = 0; sc[MBX_SC_GEN] = 0; sc[MBX_SC_EPISODE] = episode; sc[MBX_SC_HCOUNT] = 1;
         sc[MBX_NSCALAR] = gb;
@@ -237,9 +247,10 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     }
     __syncthreads();
     MBX_PHASE(0);                                                 // staging + per-individual draws
-    // histogram of the pre-update (sorted) fitness: appended to past_histo at :186
-    lde_norm_hist(L.FIT, NP, nullptr, L.HIST);
-    int my_hist = tid < MBX_LDE_BINS ? L.HIST[tid] : 0;
+    // histogram of the pre-update (sorted) fitness, appended to past_histo at :186.  It is the histogram the previous update() / reset computed for the state
+    // it emitted (same sorted fitness vector), kept packed in the spare slot of the state's HSUM block: no second min-max + histogram pass over the population
+    // (two barrier intervals and NP divisions per generation).
+    int my_hist = tid < MBX_LDE_BINS ? lde_unpack_hist(L.HS[MBX_LDE_BINS], tid) : 0;
 
     MBX_PHASE(1);                                                 // histogram of the parents
     // ---- mutation + crossover + boundary repair (:88-130, 44-50, 31-38)
@@ -322,6 +333,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
     __syncthreads();
     MBX_PHASE(4);                                                 // selection, survivors, argmin
     lde_sort_emit(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, hcount + 1, state_out + (int64_t)b * (NP + 10));
+    if (tid == 0) S[MBX_LDE_ST_HSUM(NP, D) + MBX_LDE_BINS] = lde_pack_hist(L.HIST);
 
     MBX_PHASE(5);                                                 // sort + write-back + features
     if (tid == 0) {
