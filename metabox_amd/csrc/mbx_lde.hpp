@@ -99,14 +99,18 @@ __device__ __forceinline__ int lde_unpack_hist(double packed, int k) { return (i
 
 // __order_by_f (stable) + __get_feature (lde_optimizer.py:74-79,145-157): rows of L.P with fitness L.FIT are written
 // to HBM in ascending-fitness order and the [NP+10] state vector is emitted.  hs/hcount = past_histo sum / length.
+// PIDX_ZEROED: the caller cleared L.PIDX before its last barrier (k_lde_step does so in the selection loop: one barrier interval less)
+template <bool PIDX_ZEROED = false>
 __device__ __forceinline__ void lde_sort_emit(const LdeLds& L, int NP, int D, double* gPop, double* gFit, const double* hs,
                                               double hcount, double* state_out)
 {
     const int tid = threadIdx.x;
     // stable rank of every individual; the NP x NP comparisons are spread over the whole workgroup (thread (i, part) counts over a
     // slice of j, partial counts meet in LDS) instead of NP threads walking NP entries each
-    for (int i = tid; i < NP; i += MBX_NT) L.PIDX[i] = 0;
-    __syncthreads();
+    if constexpr (!PIDX_ZEROED) {
+        for (int i = tid; i < NP; i += MBX_NT) L.PIDX[i] = 0;
+        __syncthreads();
+    }
     {
         const int parts = MBX_NT / NP > 0 ? MBX_NT / NP : 1;
         for (int w = tid; w < parts * NP; w += MBX_NT) {
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
         const int surv = L.NC[i] <= L.FIT[i];
         L.R0[i] = surv;
         if (surv) L.FIT[i] = L.NC[i];
+        L.PIDX[i] = 0;                                             // the sort's rank accumulator (the p-best indices are dead since the mutation)
     }
     __syncthreads();
     // survivors take the trial vector; the other rows come back from the registers above (P's storage served as evaluator scratch meanwhile)
@@ -327,13 +332,12 @@ __global__ __launch_bounds__(THREADS) MBX_LDE_WAVES void k_lde_step(BatchParams 
         if (4 * tid < NE) select_group(tid, keep[0]);
         if (4 * (tid + MBX_NT) < NE) select_group(tid + MBX_NT, keep[KG - 1]);
     }
-    double bsf_next; int bi;
-    block_argmin(L.FIT, NP, L.RED, bsf_next, bi);
     if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid]; }
     __syncthreads();
-    MBX_PHASE(4);                                                 // selection, survivors, argmin
-    lde_sort_emit(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, hcount + 1, state_out + (int64_t)b * (NP + 10));
+    MBX_PHASE(4);                                                 // selection, survivors
+    lde_sort_emit<true>(L, NP, D, S + MBX_LDE_ST_POP(NP, D), S + MBX_LDE_ST_FIT(NP, D), L.HS, hcount + 1, state_out + (int64_t)b * (NP + 10));
     if (tid == 0) S[MBX_LDE_ST_HSUM(NP, D) + MBX_LDE_BINS] = lde_pack_hist(L.HIST);
+    const double bsf_next = L.SORTED[0];                           // the new best-so-far is the head of the sorted fitness vector: no argmin pass of its own
 
     MBX_PHASE(5);                                                 // sort + write-back + features
     if (tid == 0) {
