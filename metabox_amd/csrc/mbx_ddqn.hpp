@@ -190,16 +190,17 @@ __global__ __launch_bounds__(kThreads) void k_dq_reset(BatchParams bp, double* _
 }
 
 // ------------------------------------------------------------------------------------------------ step
+// TWO waves per instance.  A step is a chain of ~20 short phases, most of them a handful of lanes wide (one trial vector of D coordinates, 16 credit
+// statistics, single-lane bookkeeping); with four waves per instance every phase boundary was a four-wave barrier and 2240 instances needed 2.2 rounds
+// of resident workgroups (99 VGPRs: four per CU).  Small workgroups (17.9 KB of LDS: nine per CU) keep all 2240 instances of config 4's share resident
+// at once; the only wide phase, the protein energy, is split over the workgroup's lanes.  Measured (k_dq_step<100, 12>, 2240 instances, one box; threads /
+// waves per SIMD the compiler may assume): 64 / 3 60.7 us, **128 / 5 53.3-54.3 us**, 128 / 4 65.9, 128 / 6 57.6, 192 / 6 74.8, 256 / 6 65.2.
+// (The helpers take the workgroup size from the launch.)
 #ifndef MBX_DQ_WAVES
-#define MBX_DQ_WAVES __attribute__((amdgpu_waves_per_eu(3)))      // nine one-wave workgroups per CU: at most three waves on a SIMD, 168 VGPRs each
+#define MBX_DQ_WAVES __attribute__((amdgpu_waves_per_eu(5)))      // nine two-wave workgroups per CU: 4.5 waves per SIMD, 96 VGPRs each
 #endif
-// ONE wave per instance.  A step is a chain of ~20 short phases, most of them a handful of lanes wide (one trial vector of D coordinates, 16
-// credit statistics, single-lane bookkeeping); with four waves per instance every phase boundary was a workgroup barrier and 2240 instances
-// needed 2.2 rounds of resident workgroups (99 VGPRs: four per CU).  A 64-thread workgroup has no barrier to wait at (s_barrier of a single
-// wave), 17.9 KB of LDS let nine of them share a CU, so all 2240 instances of config 4's share are resident at once; the only wide phase, the
-// protein energy, is 78 instead of 20 pair iterations per lane.  (The helpers take the workgroup size from the launch.)
 #ifndef MBX_DQ_STEP_THREADS
-#define MBX_DQ_STEP_THREADS 64
+#define MBX_DQ_STEP_THREADS 128
 #endif
 constexpr int kDqStepThreads = MBX_DQ_STEP_THREADS;
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step

@@ -510,8 +510,14 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
-    double s = (red[0] + red[1]) + (red[2] + red[3]);               // 4 waves: the association the oracle-pinned protein energy uses
-    for (int g = 4; g < MBX_NW; g += 4) s = s + ((red[g] + red[g + 1]) + (red[g + 2] + red[g + 3]));
+    double s;
+    if (MBX_NW < 4) {                                                // two or three waves (k_dq_step's 128-thread workgroups)
+        s = red[0];
+        for (int g = 1; g < MBX_NW; ++g) s = s + red[g];
+    } else {
+        s = (red[0] + red[1]) + (red[2] + red[3]);                   // 4 waves: the association the oracle-pinned protein energy uses
+        for (int g = 4; g < MBX_NW; g += 4) s = s + ((red[g] + red[g + 1]) + (red[g + 2] + red[g + 3]));
+    }
     __syncthreads();
     return s;
 }
@@ -529,7 +535,7 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 // sqrt and the two divisions by the distance (the reference's `r / pair_dis` and `q / (4 pair_dis)`) come from ONE v_rsq_f64 estimate:
 // two coupled Goldschmidt steps give sqrt(s) and 1 / (2 sqrt(s)), one residual correction each brings both to <= 1 ulp -- 13 instructions
 // instead of a library sqrt and two IEEE divisions (~70).  The energy is pinned at 1e-9 relative against the reference's own outputs.
-// pairs in flight per lane in eval_rows_protein: 4 for the D = 12 instantiation (k_dq_step<100, 12>, one wave per instance), the plain loop elsewhere
+// pairs in flight per lane in eval_rows_protein: 4 for the D = 12 instantiation (k_dq_step<100, 12>, two waves per instance), the plain loop elsewhere
 // (the generation kernels that can meet a protein problem run under a 96-register cap)
 #ifndef MBX_PROTEIN_PF
 #define MBX_PROTEIN_PF 4
@@ -554,7 +560,7 @@ constexpr bool mfma_matvec(int md, int kc) { (void)kc; return (MBX_MFMA_MATVEC >
 constexpr int protein_prefetch(int dc) { return dc == 12 ? MBX_PROTEIN_PF : 1; }
 
 // PF: atom pairs per lane and loop iteration.  PF = 1 is the plain loop.  With PF > 1 the body fetches PF pairs and walks their PF independent
-// dependency chains side by side, one arithmetic step at a time over all of them: k_dq_step runs ONE wave per instance with ~2 waves per
+// dependency chains side by side, one arithmetic step at a time over all of them: k_dq_step runs one or two waves per instance with 2-4 waves per
 // SIMD, and a pair term is a chain of ~40 dependent float64 operations (rsq, Goldschmidt steps, r^12) that a single wave issues at the
 // chain's latency -- 11-13 cycles per instruction (instrumented build: 1070 cycles per pair, the energy 93 k of the step's 152 k cycles).
 // Same pairs per lane in the same order: every PF gives the same sums.
