@@ -79,7 +79,12 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
         const uint64_t p0 = (uint64_t)MBX_PHILOX_M0 * c0, p1 = (uint64_t)MBX_PHILOX_M1 * c2;   // one v_mad_u64_u32 each
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#ifdef MBX_PHILOX_XOR2
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+#else
+        // gfx950's three-input bit operation (truth table 0x96 = a ^ b ^ c): one instruction per word instead of two v_xor_b32
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+#endif
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += MBX_PHILOX_W0; k1 += MBX_PHILOX_W1;
     }
