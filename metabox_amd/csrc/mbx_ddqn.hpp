@@ -62,16 +62,16 @@ __device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP,
     for (int i = tid; i < NP; i += MBX_NT) { const double t = fabs(L.COST[i] - mean); part += t * t; }
     const double var = block_sum(part, L.RED) / NP;
     int* R = reinterpret_cast<int*>(L.MISC);
-    if (tid == 0) {
-        if (tape) for (int j = 0; j < 5; ++j) R[j] = (int)tape[MBX_DQ_TAPE_R(NP, D) + j];
+    if (tid < 2) {                                                   // the two Philox calls side by side (lane 0: r0..r3, lane 1: r4)
+        if (tape) { for (int j = 4 * tid; j < (tid ? 5 : 4); ++j) R[j] = (int)tape[MBX_DQ_TAPE_R(NP, D) + j]; }
         else {
-            U4 w = rng.draw(0u, MBX_SITE_DQ_R);
-            R[0] = (int)__umulhi(w.x, (uint32_t)NP); R[1] = (int)__umulhi(w.y, (uint32_t)NP);
-            R[2] = (int)__umulhi(w.z, (uint32_t)NP); R[3] = (int)__umulhi(w.w, (uint32_t)NP);
-            w = rng.draw(1u, MBX_SITE_DQ_R);
-            R[4] = (int)__umulhi(w.x, (uint32_t)NP);
+            const U4 w = rng.draw((uint32_t)tid, MBX_SITE_DQ_R);
+            if (tid == 0) {
+                R[0] = (int)__umulhi(w.x, (uint32_t)NP); R[1] = (int)__umulhi(w.y, (uint32_t)NP);
+                R[2] = (int)__umulhi(w.z, (uint32_t)NP); R[3] = (int)__umulhi(w.w, (uint32_t)NP);
+            } else R[4] = (int)__umulhi(w.x, (uint32_t)NP);
         }
-        for (int j = 0; j < 5; ++j) gR[j] = (double)R[j];
+        for (int j = 4 * tid; j < (tid ? 5 : 4); ++j) gR[j] = (double)R[j];
     }
     __syncthreads();
     double md = 0.;
@@ -96,8 +96,18 @@ __device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP,
         else if (tid == 5) L.FEAT[11] = dist;
         else L.FEAT[18] = dist;
     }
-    // (the three groups below sit in different waves when the workgroup has four, and share the one wave of a 64-thread workgroup)
-    const int t1 = MBX_NT >= 256 ? 64 : 16, t2 = MBX_NT >= 256 ? 128 : 32;
+    // (the three groups below sit in different waves when the workgroup has four; with two waves the distances have the first wave to themselves and the
+    // second takes the window sums -- on all 64 lanes, a quarter of the window each -- and then the credit statistics; one wave runs all three in turn)
+    const int t1 = MBX_NT >= 256 ? 64 : (MBX_NT >= 128 ? 64 : 16), t2 = MBX_NT >= 256 ? 128 : (MBX_NT >= 128 ? 64 : 32);
+    const bool spread_window = MBX_NT == 128;
+    if (spread_window && tid >= 64) {                               // OM_W window sums (:127-129), 16 (operator, metric) pairs x 4 interleaved window slices
+        const int l = tid - 64, q = l & 15, op = q >> 2, m = q & 3;
+        double s = 0.;
+        for (int w = l >> 4; w < omw_len; w += 4) if ((int)L.omw()[w * 6] == op) s += L.omw()[w * 6 + 1 + m];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (l < 16) L.FEAT[83 + q] = s;
+    }
     if (tid >= t1 && tid < t1 + 16) {                               // operator-credit statistics (:94-126)
         const int q = tid - t1, op = q >> 2;
         const int G = gen < MBX_DQ_GENMAX ? gen : MBX_DQ_GENMAX;
@@ -120,7 +130,7 @@ __device__ __forceinline__ void dq_features(const PT& P, const DqLds& L, int NP,
             if (dn != 0 && ns[s0] > 0 && ns[s1] > 0) L.FEAT[51 + q] = (ox[s0] - ox[s1]) / (ox[s1] * fabs(dn));
         }
     }
-    if (tid >= t2 && tid < t2 + 16) {                               // OM_W window sums (:127-129)
+    if (!spread_window && tid >= t2 && tid < t2 + 16) {             // OM_W window sums (:127-129)
         const int q = tid - t2, op = q >> 2, m = q & 3;
         double s = 0.;
         for (int w = 0; w < omw_len; ++w) if ((int)L.omw()[w * 6] == op) s += L.omw()[w * 6 + 1 + m];
