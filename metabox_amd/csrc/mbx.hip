@@ -14,6 +14,10 @@
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"
 #include "mbx_lde.hpp"
+#ifndef MBX_LDE50_STEP_THREADS
+#define MBX_LDE50_STEP_THREADS 256     // workgroup size of k_lde_step<., 50, 30>: 38.8 KB of LDS let FOUR 256-thread workgroups share a CU (round 3, all 30 noisy
+                                       // functions, 16 384 instances, one box: 128 / 256 / 384 / 512 / 1024 threads -> 658 / 466 / 662 / 483 / 849 us per generation)
+#endif
 #include "mbx_ddqn.hpp"
 #include "mbx_rs.hpp"
 #include "mbx_policy.hpp"
@@ -544,7 +548,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<MBX_LDE50_STEP_THREADS, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -720,7 +724,7 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
     else {
         if (!d_state_out) return fail(MBX_E_ARG, "mbx_step: this algorithm needs d_state_out");
         if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 3)
-            hipLaunchKernelGGL((k_lde_step<512, 50, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL((k_lde_step<MBX_LDE50_STEP_THREADS, 50, 30>), dim3(b->B), dim3(MBX_LDE50_STEP_THREADS), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 6)
             hipLaunchKernelGGL((k_lde_step<512, 100, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
@@ -1014,7 +1018,8 @@ extern "C" int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4])
 {
     if (!b || !out) return fail(MBX_E_ARG, "mbx_batch_launch_info: bad arguments");
     out[0] = b->threads; out[1] = (int32_t)b->lds_bytes; out[2] = b->fixed_geometry; out[3] = (int32_t)b->state_stride;
-    if (b->cfg.algo == MBX_ALGO_DEDDQN) {                      // the step kernel (one wave per instance, one-row evaluator scratch), not k_dq_reset
+    if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 3) out[0] = MBX_LDE50_STEP_THREADS;       // k_lde_step's own workgroup size (k_lde_reset keeps b->threads)
+    if (b->cfg.algo == MBX_ALGO_DEDDQN) {                      // the step kernel (small workgroups, one-row evaluator scratch), not k_dq_reset
         out[0] = kDqStepThreads; out[1] = (int32_t)(dq_lds_doubles(1, b->cfg.np, b->cfg.dim) * sizeof(double));
     }
     return MBX_OK;

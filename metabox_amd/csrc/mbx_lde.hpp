@@ -191,7 +191,7 @@ __global__ __launch_bounds__(THREADS) void k_lde_reset(BatchParams bp, double* _
 // (all 30 noisy functions, 16 384 instances: 792 us at two resident workgroups -> 627 us at three).
 // (pop = 100 / D = 30: two resident workgroups = four waves per SIMD, 128 VGPRs: room for the register-resident rows of matvec_rows_scalar)
 #ifndef MBX_LDE_WAVES
-#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(NPC == 100 ? 4 : 6)))
+#define MBX_LDE_WAVES __attribute__((amdgpu_waves_per_eu(4)))     // pop 100: two 512-thread workgroups per CU; pop 50: four 256-thread workgroups (round 3; three of 512 at 6 waves before)
 #endif
 // NPC / DC: population and dimension fixed at compile time (0 = taken from the batch), see k_rlepso_step
 template <int THREADS, int NPC = 0, int DC = 0>

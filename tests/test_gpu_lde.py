@@ -136,7 +136,7 @@ def test_lde_large_batch_properties(NP):
     def run(sel):
         b = Batch(s, ALGO_LDE, pidx[sel], seeds[sel], NP, 60000, 1200, 50)
         info = b.launch_info()
-        assert info['threads'] == 512 and info['fixed_geometry'] == (3 if NP == 50 else 6), info
+        assert info['threads'] == (256 if NP == 50 else 512) and info['fixed_geometry'] == (3 if NP == 50 else 6), info
         # the maps stay in global memory (scalar-operand matvec): 38 848 B at NP = 50 (53 248 with them), 76 416 B at NP = 100 (90 816): two workgroups per CU
         assert info['lds_bytes'] == {50: 38848, 100: 76416}[NP] and 2 * info['lds_bytes'] <= 160 * 1024, info
         assert b.state_dim == NP + 10 and b.action_dim == 2 * NP
