@@ -14,6 +14,9 @@
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"
 #include "mbx_lde.hpp"
+#ifndef MBX_LDE100_STEP_THREADS
+#define MBX_LDE100_STEP_THREADS 512
+#endif
 #ifndef MBX_LDE50_STEP_THREADS
 #define MBX_LDE50_STEP_THREADS 256     // workgroup size of k_lde_step<., 50, 30>: 38.8 KB of LDS let FOUR 256-thread workgroups share a CU (round 3, all 30 noisy
                                        // functions, 16 384 instances, one box: 128 / 256 / 384 / 512 / 1024 threads -> 658 / 466 / 662 / 483 / 849 us per generation)
@@ -549,7 +552,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<MBX_LDE50_STEP_THREADS, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<MBX_LDE100_STEP_THREADS, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512, 50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_DEDDQN) {
@@ -727,7 +730,7 @@ extern "C" int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out
             hipLaunchKernelGGL((k_lde_step<MBX_LDE50_STEP_THREADS, 50, 30>), dim3(b->B), dim3(MBX_LDE50_STEP_THREADS), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->cfg.algo == MBX_ALGO_LDE && b->fixed_geometry == 6)
-            hipLaunchKernelGGL((k_lde_step<512, 100, 30>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
+            hipLaunchKernelGGL((k_lde_step<MBX_LDE100_STEP_THREADS, 100, 30>), dim3(b->B), dim3(MBX_LDE100_STEP_THREADS), b->lds_bytes, (hipStream_t)stream, make_params(b),
                                (const float*)d_actions, d_state_out, d_reward_out, d_done_out);
         else if (b->cfg.algo == MBX_ALGO_LDE && b->threads == 512)
             hipLaunchKernelGGL(k_lde_step<512>, dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream, make_params(b),
