@@ -14,6 +14,9 @@
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"
 #include "mbx_lde.hpp"
+#ifndef MBX_RUN10_THREADS
+#define MBX_RUN10_THREADS kThreads      // workgroup size of the headline resident kernel k_rlepso_run<., 100, 10, 5> (A/B knob; 128 threads at 3 waves per SIMD, no spills: 158.9 against 117.1 us per generation)
+#endif
 #ifndef MBX_LDE100_STEP_THREADS
 #define MBX_LDE100_STEP_THREADS 512
 #endif
@@ -537,7 +540,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -881,7 +884,7 @@ extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens
     if (mbx_rlepso_rollout_resident(b) == 1) {
         const RunOut out{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
         if (b->fixed_geometry == 1)
-            hipLaunchKernelGGL((k_rlepso_run<kThreads, 100, 10, 5>), dim3(b->B), dim3(kThreads), b->lds_bytes, (hipStream_t)stream,
+            hipLaunchKernelGGL((k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>), dim3(b->B), dim3(MBX_RUN10_THREADS), b->lds_bytes, (hipStream_t)stream,
                                make_params(b), d_table, rows, n_gens, out);
         else if (b->fixed_geometry == 7)
             hipLaunchKernelGGL((k_rlepso_run<512, 100, 30, 5>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream,
