@@ -242,7 +242,9 @@ __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, dou
 //    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
 //    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
 // Exact float64 scan for W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk; returns the exemplar's rank per coordinate.
-template <int W>
+// UN: candidates per unrolled group (MBX_FDR_UNROLL = 4 everywhere but config 5's resident kernel: 1024 threads, D = 40: 2 / 4 / 8 -> 1.619 / 1.641 / 1.703 ms per
+// generation; the headline kernel: 2 / 3 / 4 / 6 / 8 -> 119.9 / 117.1 / 116.5 / 117.5 / 121.6 us)
+template <int W, int UN = MBX_FDR_UNROLL>
 __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W])
 {
 #pragma unroll
@@ -257,16 +259,16 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
     // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
     // issued before its first comparison
     int k = 1;
-    for (; k + MBX_FDR_UNROLL <= nless; k += MBX_FDR_UNROLL) {
-        double a[MBX_FDR_UNROLL], x[MBX_FDR_UNROLL][W];
+    for (; k + UN <= nless; k += UN) {
+        double a[UN], x[UN][W];
 #pragma unroll
-        for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
+        for (int u = 0; u < UN; ++u) {
             a[u] = L.NC[k + u];
 #pragma unroll
             for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
         }
 #pragma unroll
-        for (int u = 0; u < MBX_FDR_UNROLL; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const double au = a[u] - fi;                      // shared by the W coordinates
 #pragma unroll
             for (int q = 0; q < W; ++q) {
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
             if (ps >= base && ps < lim) {
                 const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
                 int kb[2];
-                fdr_exact<2>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                fdr_exact<2, (DC == 40 ? 2 : MBX_FDR_UNROLL)>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
                 L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
             }
         }
