@@ -79,8 +79,10 @@ def _pad51(row):
 def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0, n_logpoint=50):
     """Run `runner(suite_problems, problem_idx, seeds) -> results dict` over the (problem x run) table, sharded over
     ranks and optionally chunked; returns (cost [N, nlog+1], fes [N], ret [N]) as numpy arrays in table order plus the
-    wall time in ms normalised to the whole table (max over ranks of wall / local instances, times N), so that wall / N is the
-    per-instance time whatever the number of ranks."""
+    device time of the whole table in ms: the SUM over ranks of each rank's wall time.  Shards are cost-weighted (the rank that owns the
+    expensive functions owns the fewest instances), so a per-rank `wall / local instances` depends on which functions the rank happened
+    to get; the sum over ranks divided by N is the mean GPU time per instance whatever the number of ranks and however the table was cut
+    (with one rank it is the wall time; with balanced shards it is world x the epoch's wall time)."""
     pidx, run = instance_table(len(problems), runs)
     n_total = len(pidx)
     rank, world = _world()
@@ -100,14 +102,14 @@ def run_pairs(problems, runner, runs, n_instances_cap=0, epoch_salt=0, n_logpoin
     # an empty shard (fewer instances than ranks) still takes part in the all-gather with the right width and device
     local = torch.cat(rows, 0) if rows else torch.zeros(0, n_logpoint + 1 + 3, dtype=torch.float64, device=dev)
     full = unpack_rows(gather_rows(local, n_total, bounds=bounds))
-    # per-instance wall time (the batched engine's T2, see module docstring): this rank's wall over ITS instances, the slowest rank counts
-    per_instance_ms = wall_ms / max(hi - lo, 1)
+    # the table's device time (the batched engine's T2, see the docstring): sum of the ranks' wall times
+    total_ms = wall_ms
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([per_instance_ms], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_instance_ms = float(t.item())
-    return full['cost'].cpu().numpy(), full['fes'].cpu().numpy(), full['return'].cpu().numpy(), per_instance_ms * n_total
+        t = torch.tensor([wall_ms], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_ms = float(t.item())
+    return full['cost'].cpu().numpy(), full['fes'].cpu().numpy(), full['return'].cpu().numpy(), total_ms
 
 
 def _learnable_runner(agent, optimizer, suite_cache, early_stop=True):

@@ -205,3 +205,49 @@ def test_cost_weighted_shards_gather_to_the_unsharded_table_world8():
     want = unpack_rows(pack_rows(_fake_results(0, 65536)))
     for k in want:
         assert np.array_equal(got[k], want[k].numpy()), k
+
+
+def test_train_batched_shards_by_predicted_cost(monkeypatch, tmp_path):
+    """Trainer.train_batched cuts the epoch's (problem x run) table with distributed.partition_bounds like Tester.run_pairs:
+    the shards of all ranks are contiguous, cover the table once, carry global-id Philox seeds, and balance the predicted cost where the
+    equal-count split of the function-sorted table did not.  (The lock-step batch itself needs the GPU: stubbed here, the split is host logic.)"""
+    import types
+    import metabox_amd.environment as env_mod
+    import metabox_amd.suite as suite_mod
+    import metabox_amd.tester as tester_mod
+    from metabox_amd.distributed import instance_table, philox_seed, relative_cost, shard_range
+    from metabox_amd.trainer import Trainer
+    ps, _ = _c5_table()
+    seen = {}
+
+    class _Env:
+        def __init__(self, problems, optimizer, pidx, seeds, suite=None):
+            self.pidx, self.seeds = np.asarray(pidx), np.asarray(seeds)
+
+        def close(self):
+            pass
+
+    class _Agent:
+        def train_batch(self, env):
+            seen[self.rank] = (env.pidx, env.seeds)
+            return True, {'learn_steps': 1, 'return': 0.0}
+
+    monkeypatch.setattr(env_mod, 'BatchedPBO_Env', _Env)
+    monkeypatch.setattr(suite_mod, 'Suite', lambda problems: None)
+    world, runs = 8, 16
+    for rank in range(world):
+        monkeypatch.setattr(tester_mod, '_world', lambda rank=rank: (rank, world))
+        t = Trainer.__new__(Trainer)
+        t.config = types.SimpleNamespace(train_batch_size=runs, log_dir=str(tmp_path), run_time='t')
+        t.optimizer, t.agent = None, _Agent()
+        t.agent.rank = rank
+        t.train_set = types.SimpleNamespace(data=ps)
+        t.train_batched(max_epochs=1)
+    pidx, run = instance_table(len(ps), runs)
+    seeds = philox_seed(run, np.arange(len(pidx)), epoch_salt=1)
+    assert np.array_equal(np.concatenate([seen[r][0] for r in range(world)]), pidx)
+    assert np.array_equal(np.concatenate([seen[r][1] for r in range(world)]), seeds)
+    cost = np.array([relative_cost(p) for p in ps])
+    per = np.array([cost[seen[r][0]].sum() for r in range(world)])
+    eq = np.array([cost[pidx[slice(*shard_range(len(pidx), r, world))]].sum() for r in range(world)])
+    assert per.max() / per.mean() < 1.05 < eq.max() / eq.mean()

@@ -278,9 +278,11 @@ def test_policy_kernel_equals_actor_forward():
     env.close()
 
 
-def test_fused_act_step_equals_policy_then_step():
+@pytest.mark.parametrize('suite_name, fids', [('bbob', (1, 3, 16, 21)), ('bbob-noisy', (101, 115, 128))])
+def test_fused_act_step_equals_policy_then_step(suite_name, fids):
     """mbx_rlepso_act_step (action drawn inside the generation kernel from the actor table) == mbx_gauss_policy + mbx_step,
-    bit for bit, over a whole episode including early stops and re-initialisations; the table rows equal the actor's forward."""
+    bit for bit, over a whole episode including early stops and re-initialisations (and, on the noisy triple, the in-kernel noise
+    draws); the table rows equal the actor's forward."""
     from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
     from metabox_amd.config import get_config
     from metabox_amd.environment import BatchedPBO_Env
@@ -291,7 +293,7 @@ def test_fused_act_step_equals_policy_then_step():
     actor = agent.actor
     h1, h2 = actor.hidden_sizes()
     net = (actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
-    ps = [problems('bbob-noisy', 10)[f] for f in (101, 115, 128)] if False else [problems('bbob', 10)[f] for f in (1, 3, 16, 21)]
+    ps = [problems(suite_name, 10)[f] for f in fids]
     B = 64
     pidx, seeds = np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) * 7919 + 3
     env_a = BatchedPBO_Env(ps, RLEPSO_Optimizer(cfg), pidx, seeds)
@@ -313,7 +315,9 @@ def test_fused_act_step_equals_policy_then_step():
     ra_, rb_ = env_a.results(), env_b.results()
     for key in ra_:
         assert torch.equal(ra_[key], rb_[key]), key
-    assert bool(ra_['fes'].max() >= 20000) and bool((ra_['steps'] < 199).any())         # Sphere instances stopped early
+    assert bool(ra_['fes'].max() >= 20000)
+    if suite_name == 'bbob':
+        assert bool((ra_['steps'] < 199).any())                                         # Sphere instances stopped early
     # rollout_batch('fused') is that loop
     for route in ('fused', 'resident'):                # 'resident' (the default) is the same episode in a single launch
         out = agent.rollout_batch(BatchedPBO_Env(ps, RLEPSO_Optimizer(cfg), pidx, seeds), policy=route)
@@ -388,42 +392,74 @@ def test_resident_ranking_orders_equal_costs_like_the_one_generation_kernel():
     assert max(ties) >= 5, ties
 
 
-@pytest.mark.parametrize('suite_name', ['bbob', 'bbob-noisy'])
-def test_resident_rollout_matches_the_oracle(env, suite_name):
-    """The resident kernel against the C oracle directly (not through k_rlepso_step): 12 generations in ONE launch; the oracle, on the same
-    Philox seeds, replays the actions the kernel drew (trajectory record) and must see the same state / reward / done after every generation
-    and the same population at the end.  (The long-horizon proof -- exact up to proven near-ties -- is test_philox_parity_with_oracle on
-    k_rlepso_step, to which test_resident_rollout_equals_one_launch_per_generation ties this kernel bit for bit; in the first dozen
-    generations the swarm is wide and no comparison is anywhere near a tie.)"""
-    from metabox_amd.suite import Batch
+def _resident_vs_oracle(ps, np_, dim, maxfes, G, seed_mul=6151):
+    """The resident kernel against the C oracle directly (not through k_rlepso_step): G generations in ONE launch of mbx_rlepso_rollout with
+    the trajectory record on; the oracle, on the same Philox seeds, replays the actions the kernel drew and must see the same state / reward /
+    done after every generation and the same population at the end (noisy functions included: the in-kernel noise draws are the oracle's Philox
+    draws).  Returns the launch geometry the batch ran on, so that the caller can assert WHICH instantiation it has just compared."""
+    from metabox_amd.suite import Batch, Suite
     from metabox_amd._abi import ALGO_RLEPSO
-    s, ids = env[suite_name]
-    B, G = len(ids), 12
-    seeds = np.arange(B, dtype=np.uint64) * 6151 + 17
-    batch = Batch(s, ALGO_RLEPSO, np.arange(B), seeds, NP, MAXFES, LOGI, NLOG)
-    table = torch.rand(MAXFES + 2 * NP + 1, 2, 35, generator=torch.Generator().manual_seed(4)).cuda()
+    s = Suite(ps)
+    B, logi = len(ps), maxfes // 50
+    seeds = np.arange(B, dtype=np.uint64) * seed_mul + 17
+    batch = Batch(s, ALGO_RLEPSO, np.arange(B), seeds, np_, maxfes, logi, NLOG)
+    assert batch.rollout_is_resident()
+    table = torch.rand(maxfes + 2 * np_ + 1, 2, 35, generator=torch.Generator().manual_seed(4)).cuda()
     table[:, 1] = 0.05 + 0.3 * table[:, 1]                                      # sigma
     table = table.contiguous()
     batch.reset()
     _, _, _, traj = batch.rlepso_rollout(table, G, trajectory=True)
     torch.cuda.synchronize()
     acts, st, rw, dn = (traj[k].cpu().numpy() for k in ('actions', 'state', 'reward', 'done'))
-    cfg = oracle.make_cfg(1, NP, D, MAXFES, LOGI, NLOG)
+    cfg = oracle.make_cfg(1, np_, dim, maxfes, logi, NLOG)
     for b in range(B):
-        p = s.problems[b]
+        p = ps[b]
         o = oracle.RlepsoOracle(p.desc(), p.bias, cfg, seed=int(seeds[b]))
         o.reset()
         for g in range(G):
             so, ro, do = o.step(acts[g, b])
-            assert so == st[g, b] and ro == rw[g, b] and bool(do) == bool(dn[g, b]), (ids[b], g)
-            assert not do, ids[b]
-        want = oracle.split_rlepso_state(o.state(), NP, D, NLOG)
-        got = oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG)
-        assert close(got['scalars'][oracle.SC_GBEST], want['scalars'][oracle.SC_GBEST]), ids[b]
-        assert got['scalars'][oracle.SC_FES] == want['scalars'][oracle.SC_FES], ids[b]
-        assert close(got['pbest'], want['pbest']) and np.abs(got['pos'] - want['pos']).max() <= 1e-9, ids[b]
-        assert np.array_equal(got['pni'], want['pni']), ids[b]
+            assert so == st[g, b] and ro == rw[g, b] and bool(do) == bool(dn[g, b]), (p.func_id, g)
+            assert not do, p.func_id
+        want = oracle.split_rlepso_state(o.state(), np_, dim, NLOG)
+        got = oracle.split_rlepso_state(batch.read_state(b), np_, dim, NLOG)
+        assert close(got['scalars'][oracle.SC_GBEST], want['scalars'][oracle.SC_GBEST]), p.func_id
+        assert got['scalars'][oracle.SC_FES] == want['scalars'][oracle.SC_FES], p.func_id
+        assert close(got['pbest'], want['pbest']) and np.abs(got['pos'] - want['pos']).max() <= 1e-9, p.func_id
+        assert close(got['ccost'], want['ccost']), p.func_id
+        assert np.array_equal(got['pni'], want['pni']), p.func_id
+    info = batch.launch_info()
     batch.close()
+    return info
+
+
+@pytest.mark.parametrize('suite_name', ['bbob', 'bbob-noisy'])
+def test_resident_rollout_matches_the_oracle(env, suite_name):
+    """k_rlepso_run<256, 100, 10, 5> (the headline kernel), all 24 + 30 functions, 12 generations in one launch.  (The long-horizon proof --
+    exact up to proven near-ties -- is test_philox_parity_with_oracle on k_rlepso_step, to which
+    test_resident_rollout_equals_one_launch_per_generation ties this kernel bit for bit; in the first dozen generations the swarm is wide and no
+    comparison is anywhere near a tie.)"""
+    s, ids = env[suite_name]
+    _resident_vs_oracle(list(s.problems), NP, D, MAXFES, 12)
+
+
+def _suite54(dim):
+    return [problems('bbob', dim)[k] for k in sorted(problems('bbob', dim))] + \
+           [problems('bbob-noisy', dim)[k] for k in sorted(problems('bbob-noisy', dim))]
+
+
+def test_config5_resident_rollout_matches_the_oracle():
+    """The kernel bench.py times for config 5, k_rlepso_run<1024, 128, 40, 5>, tied to the oracle DIRECTLY on all 54 functions (24 bbob + 30
+    noisy: in-kernel noise draws, F22 / F128-F130 on the lean Gallagher route, the row-chunked scalar-operand matvec, the FDR scan unrolled by 2)
+    -- the D = 40 twin of test_resident_rollout_matches_the_oracle.  Reference semantics: src/optimizer/rlepso_optimizer.py:173-263,
+    src/problem/bbob.py:96-146."""
+    info = _resident_vs_oracle(_suite54(40), 128, 40, 80000, 12)
+    assert info['threads'] == 1024 and info['fixed_geometry'] == 2, info
+
+
+def test_dim30_resident_rollout_matches_the_oracle():
+    """k_rlepso_run<512, 100, 30, 5> (bbob --dim 30, the reference's other standard dimension; float64 MFMA matvec route) on 24 + 30 functions."""
+    info = _resident_vs_oracle(_suite54(30), 100, 30, 60000, 12)
+    assert info['threads'] == 512, info
 
 
 def test_resident_rollout_config5_geometry_and_host_loop_route(monkeypatch):
@@ -472,6 +508,48 @@ def test_config5_shape_np128_dim40_mixed_suites():
         # particles beyond n_group * (NP // n_group) never move on their own (w = c = 0): velocity exactly 0
         assert np.all(got['vel'].reshape(NPc, Dc)[125:] == 0) or got['scalars'][oracle.SC_REINIT] > 0
     b.close()
+
+
+def test_config5_full_batch_properties():
+    """BASELINE.json config 5 at its one-GPU size (8192 instances = 65 536 / 8, 54 functions round-robin, NP 128 / D 40) through the resident
+    kernel bench.py times: bit-identical re-run, results independent of batch position / size (every second instance alone reproduces its rows),
+    fes accounting, done absorbing across launches."""
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    ps = _suite54(40)
+    s = Suite(ps)
+    B, NPc, maxfes = 8192, 128, 80000
+    pidx = np.arange(B) % len(ps)
+    seeds = np.arange(B, dtype=np.uint64) // len(ps) + 31
+    table = torch.rand(maxfes + 2 * NPc + 1, 2, 35, generator=torch.Generator().manual_seed(9)).cuda()
+    table[:, 1] = 0.05 + 0.3 * table[:, 1]
+    table = table.contiguous()
+
+    def run(sel, chunks=(5, 3)):
+        b = Batch(s, ALGO_RLEPSO, pidx[sel], seeds[sel], NPc, maxfes, maxfes // 50, 50)
+        assert b.rollout_is_resident() and b.launch_info()['threads'] == 1024
+        b.reset()
+        for n in chunks:
+            b.rlepso_rollout(table, n)
+        r = {k: v.cpu().numpy() for k, v in b.results().items()}
+        st = np.stack([b.read_state(i) for i in (0, len(sel) // 2, len(sel) - 1)])
+        b.close()
+        return r, st
+    full, sfull = run(np.arange(B))
+    again, sagain = run(np.arange(B))
+    for k in full:
+        assert np.array_equal(full[k], again[k]), k
+    assert np.array_equal(sfull, sagain, equal_nan=True)
+    half = np.arange(B)[1::2]
+    part, spart = run(half)
+    for k in full:
+        assert np.array_equal(full[k][half], part[k]), k
+    assert np.array_equal(sfull[2], spart[2], equal_nan=True)                      # instance B - 1 is the last one of both batches
+    one, _ = run(np.arange(B), chunks=(8,))                                        # launch boundaries do not show
+    for k in full:
+        assert np.array_equal(full[k], one[k]), k
+    assert np.all(full['steps'] == 8)
+    assert np.all(full['fes'] >= NPc + NPc * full['steps']) and np.all(full['fes'] <= NPc + 2 * NPc * full['steps'])
 
 
 def test_single_instance_batch_and_error_paths():
