@@ -283,17 +283,19 @@ def other_configs(budget_s=60.0):
             ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
             B = 16384
             env = BatchedPBO_Env(ps, opt, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
-            st = {'s': env.reset(), 'h': torch.zeros(1, B, 50, device='cuda'), 'c': torch.zeros(1, B, 50, device='cuda')}
+            env.reset()
+            net, hh, cc = agent.net, torch.zeros(B, 50, device='cuda'), torch.zeros(B, 50, device='cuda')
+            resident3 = env.batch.lde_rollout_is_resident()
 
-            def run(n, st=st, env=env, agent=agent):
-                for _ in range(n):
-                    st['s'], st['h'], st['c'] = agent.policy_step(env, st['s'], st['h'], st['c'])
+            def run(n, env=env, net=net, hh=hh, cc=cc):
+                env.batch.lde_rollout(net.packed_weights(), net.lstm.hidden_size, hh, cc, n)     # n generations in ONE launch (k_lde_run), PolicyNet inside the kernel
             run(3)
-            dt = _bracket(run, 30)
+            dt = sorted(_bracket(run, 20) for _ in range(3))[1]      # launches of 20 generations like the headline window; median of 3
             D = 30
-            entry(f'config 3: LDE bbob-noisy d=30 pop={np_lde}, 16384 instances (one GPU), LSTM policy included', B, dt,
+            entry(f'config 3: LDE bbob-noisy d=30 pop={np_lde}, 16384 instances (one GPU), LSTM policy included, mbx_lde_rollout (20 generations per launch, median of 3 launches)', B, dt,
                   (2 * np_lde * D + 2 * np_lde) * 8 + 4 * 2 * np_lde + 8 * (np_lde + 10) + (D * D + D + 2) * 8,
-                  {'launch_info': env.batch.launch_info(), 'policy': agent.policy_route()})
+                  {'launch_info': {'kernel': f'k_lde_run<{np_lde}, 30>', 'threads': 64 * ((np_lde + 15) // 16), 'resident': bool(resident3),
+                                   'step_kernel': env.batch.launch_info()}, 'policy': agent.policy_route('resident' if resident3 else 'hip')})
             env.close()
         # ---- config 4: DE-DDQN on protein docking, one GPU's share = 35 problems x 64 runs (seeded fresh Q-net: no checkpoint ships)
         if time.perf_counter() - t_start <= budget_s:

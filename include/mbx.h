@@ -268,6 +268,28 @@ int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_
                        double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out, double* d_reward_out,
                        uint8_t* d_done_out, void* stream);
 
+/* The whole loop of LDE_Agent.rollout_episode (src/agent/lde_agent.py:147-163: `while not is_done: action, h, c = net.sampler(state, h, c);
+ * state, reward, is_done = env.step(action)`) with update() of src/optimizer/lde_optimizer.py:159-198, up to n_gens generations of every
+ * instance in ONE launch: population, fitness order, features and the LSTM's (h, c) stay in LDS between generations, the PolicyNet
+ * (lde_agent.py:8-29) is evaluated inside the workgroup from the packed weights of `net` (mbx_lstm_policy), and the state block is read once
+ * and written once per launch.  Every generation does exactly what mbx_lde_policy followed by mbx_step does, with the same Philox counters:
+ * n_gens such pairs and one call of mbx_lde_rollout leave bit-identical state blocks, (h, c), features, rewards and cost curves.
+ *   d_state_in  [n_instances, NP + 10] float64   the features the last reset / step / rollout produced (may be d_state_out itself)
+ *   d_h, d_c    [n_instances, hidden] float32    LSTM state, updated in place (not touched for instances that were done before the call)
+ * Per-generation records, each may be NULL:
+ *   d_traj_actions [n_gens, n_instances, 2 NP] float32   sampled actions (rows of generations after termination are not written)
+ *   d_traj_state   [n_gens, n_instances, NP + 10] float64   features AFTER the generation (not written after termination)
+ *   d_traj_reward  [n_gens, n_instances] float64   reward (0 after termination);   d_traj_done [n_gens, n_instances] uint8 (1 after termination)
+ * d_state_out [n_instances, NP + 10] / d_done_out: features / is_done after the last executed generation (rows of instances that were done
+ * before the call are not written); d_reward_out: SUM of the rewards of the executed generations.
+ * The resident kernel is built for config 3's geometries (NP 50 / 100 at D 30, hidden 50) and the objective kinds whose row sums need one
+ * array (all of bbob-noisy; bbob without F3, F4, F5, F15, F20, F24); any other batch is stepped with mbx_lde_policy + mbx_step per generation
+ * behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 when the batch is created forces that route).  mbx_lde_rollout_resident: 1 / 0. */
+int mbx_lde_rollout_resident(const mbx_batch* b);
+int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state_in, float* d_h, float* d_c, int n_gens,
+                    float* d_traj_actions, double* d_traj_state, double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out,
+                    double* d_reward_out, uint8_t* d_done_out, void* stream);
+
 /* RL-PSO moves ONE particle per env step, so a rollout is maxFEs - NP steps of D-element arithmetic plus one evaluation:
  * launch latency, not work.  mbx_rlpso_rollout runs `n_steps` consecutive steps of every instance in ONE launch with the
  * actor evaluated inside the kernel (the loop of RL_PSO_Agent.rollout_episode, src/agent/rl_pso_agent.py:112-124).  It is

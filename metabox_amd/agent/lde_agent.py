@@ -142,16 +142,31 @@ class LDE_Agent(Basic_Agent):
         return state, h, c
 
     def policy_route(self, policy='hip'):
-        return {'hip': 'mbx_lde_policy: LSTM cell + both heads + sampling in ONE hand-written launch per generation (gate and head products on the float32 matrix cores, weights in L2)',
+        return {'resident': 'mbx_lde_rollout: PolicyNet + update() for up to n generations per launch inside one resident kernel (k_lde_run), LSTM weights from L2',
+                'hip': 'mbx_lde_policy: LSTM cell + both heads + sampling in ONE hand-written launch per generation (gate and head products on the float32 matrix cores, weights in L2)',
                 'torch': 'PyTorch-ROCm: one LSTM cell + two linear heads over [B, NP + 10] per generation (rocBLAS / hipBLASLt GEMMs)'}[policy]
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, policy='hip'):
+    def rollout_batch(self, env, max_steps=None, policy='resident', gens_per_launch=25):
+        """Whole episodes of a lock-step batch.  'resident' (default): ``mbx_lde_rollout`` -- up to `gens_per_launch` generations of PolicyNet.sampler +
+        env.step per launch, population / fitness order / features / (h, c) on chip in between (k_lde_run; batches whose geometry or objective kinds
+        that kernel does not build are stepped per generation behind the same call); 'hip' / 'torch': one policy launch + one generation launch per
+        generation (``policy_step``).  'resident' and 'hip' give bit-identical trajectories."""
         if max_steps is None:
             bc = env.batch.cfg
             max_steps = -(-(bc.max_fes - bc.np) // bc.np)
         state = env.reset()
         h, cc = self.__zeros(env.B)
+        if policy == 'resident':
+            net = self.__net
+            h, cc = h[0].contiguous(), cc[0].contiguous()
+            g = 0
+            while g < max_steps:
+                n = min(int(gens_per_launch), max_steps - g)
+                env.batch.lde_rollout(net.packed_weights(), net.lstm.hidden_size, h, cc, n)
+                g += n
+            res = env.results()
+            return {'cost': res['cost'], 'fes': res['fes'], 'return': res['return'], 'steps': res['steps'], 'cost_len': res['cost_len']}
         for _ in range(max_steps):
             state, h, cc = self.policy_step(env, state, h, cc, policy)
         res = env.results()

@@ -28,6 +28,7 @@
 #include "mbx_rs.hpp"
 #include "mbx_policy.hpp"
 #include "mbx_lstm_policy.hpp"
+#include "mbx_lde_run.hpp"
 #include "mbx_qnet.hpp"
 #include "mbx_rlpso.hpp"
 #include "mbx_gleet.hpp"
@@ -76,6 +77,7 @@ struct mbx_batch {
     int32_t* d_order = nullptr;
     double* d_pci = nullptr;
     double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (RLEPSO batches; allocated by mbx_batch_create)
+    bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind k_lde_run builds (lde_run_kind_ok)
     bool rollout_per_generation = false;   // MBX_ROLLOUT_PER_GENERATION=1 at batch creation: mbx_rlepso_rollout takes the host-loop route (tests)
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
@@ -469,6 +471,8 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
         case 1: return 133; case 14: case 20: return 130; case 19: case 6: case 24: return 128; case 5: return 114; default: return 121;
         }
     };
+    b->lde_run_kinds_ok = true;
+    for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind);
     std::vector<int32_t> order(n_instances);
     for (int i = 0; i < n_instances; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return weight(problem_idx[a]) > weight(problem_idx[c]); });
@@ -550,6 +554,13 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (cfg->algo == MBX_ALGO_LDE) {
+        {   // mbx_lde_rollout: per-generation rewards / actions of the host-loop route, route flag (read here, never at call time)
+            HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * (sizeof(double) + (size_t)g.action_dim * sizeof(float))));
+            const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");
+            b->rollout_per_generation = per_gen && per_gen[0] == '1';
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(100, 30, 50) * sizeof(double))));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50) * sizeof(double))));
+        }
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -907,6 +918,62 @@ extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens
     }
     if (d_traj_state && d_state_out)
         HIP_TRY(hipMemcpyAsync(d_state_out, d_traj_state + (n_gens - 1) * B, B * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (d_traj_done && d_done_out)
+        HIP_TRY(hipMemcpyAsync(d_done_out, d_traj_done + (n_gens - 1) * B, B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_lde_rollout_resident(const mbx_batch* b)
+{
+    if (!b) return fail(MBX_E_ARG, "mbx_lde_rollout_resident: null batch");
+    if (b->cfg.algo != MBX_ALGO_LDE) return 0;
+    return (b->fixed_geometry == 3 || b->fixed_geometry == 6) && b->lde_run_kinds_ok && !b->rollout_per_generation ? 1 : 0;
+}
+
+extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state_in, float* d_h, float* d_c, int n_gens,
+                               float* d_traj_actions, double* d_traj_state, double* d_traj_reward, uint8_t* d_traj_done,
+                               double* d_state_out, double* d_reward_out, uint8_t* d_done_out, void* stream)
+{
+    if (!b || !net || !net->d_weights || !d_state_in || !d_h || !d_c || !d_state_out) return fail(MBX_E_ARG, "mbx_lde_rollout: bad arguments");
+    if (b->cfg.algo != MBX_ALGO_LDE) return fail(MBX_E_UNSUPPORTED, "mbx_lde_rollout: the batch is not an LDE batch");
+    if (n_gens < 1) return fail(MBX_E_ARG, "mbx_lde_rollout: n_gens must be >= 1");
+    if (b->d_tape) return fail(MBX_E_ARG, "mbx_lde_rollout: a replay tape holds one generation and no policy draws; use mbx_step with recorded actions");
+    if (net->in_dim != b->state_dim || net->out_dim != b->action_dim || net->hidden < 1 || net->hidden > 64)
+        return fail(MBX_E_ARG, "mbx_lde_rollout: network %d -> %d -> %d does not fit the batch (state %d, action %d; hidden <= 64)",
+                    net->in_dim, net->hidden, net->out_dim, b->state_dim, b->action_dim);
+    const int64_t B = b->B, A = b->action_dim, NF = b->state_dim;
+    if (mbx_lde_rollout_resident(b) == 1 && net->hidden == 50) {
+        LdeRunArgs ka{};
+        ka.bp = make_params(b);
+        ka.net = LstmPolicy{net->d_weights, net->in_dim, net->hidden, net->out_dim};
+        ka.state_in = d_state_in; ka.hbuf = d_h; ka.cbuf = d_c; ka.n_gens = n_gens;
+        ka.out = LdeRunOut{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
+        if (b->fixed_geometry == 6)
+            hipLaunchKernelGGL((k_lde_run<100, 30>), dim3(b->B), dim3(lde_run_threads(100)), (size_t)lde_run_lds_doubles(100, 30, 50) * sizeof(double),
+                               (hipStream_t)stream, ka);
+        else
+            hipLaunchKernelGGL((k_lde_run<50, 30>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 30, 50) * sizeof(double),
+                               (hipStream_t)stream, ka);
+        HIP_TRY(hipGetLastError());
+        return MBX_OK;
+    }
+    // any other geometry / objective: mbx_lde_policy + mbx_step per generation, same outputs.  The features travel through d_state_out.
+    if (d_state_in != d_state_out)
+        HIP_TRY(hipMemcpyAsync(d_state_out, d_state_in, (size_t)B * NF * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    double* r_scratch = b->d_scratch;
+    float* a_scratch = (float*)(b->d_scratch + B);
+    for (int g = 0; g < n_gens; ++g) {
+        float* acts = d_traj_actions ? d_traj_actions + g * B * A : a_scratch;
+        if (const int rc = mbx_lde_policy(b, net, d_state_out, d_h, d_c, acts, nullptr, stream)) return rc;
+        double* r = d_traj_reward ? d_traj_reward + g * B : (d_reward_out ? r_scratch : nullptr);
+        uint8_t* dn = d_traj_done ? d_traj_done + g * B : d_done_out;
+        if (const int rc = mbx_step(b, acts, d_state_out, r, dn, stream)) return rc;
+        if (d_traj_state)
+            HIP_TRY(hipMemcpyAsync(d_traj_state + g * B * NF, d_state_out, (size_t)B * NF * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (d_reward_out)
+            hipLaunchKernelGGL(k_sum_rewards, dim3((b->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_reward_out, r, b->B, g == 0);
+    }
     if (d_traj_done && d_done_out)
         HIP_TRY(hipMemcpyAsync(d_done_out, d_traj_done + (n_gens - 1) * B, B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());

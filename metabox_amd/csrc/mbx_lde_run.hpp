@@ -1,0 +1,726 @@
+// mbx_lde_run.hpp — LDE with the instance resident on chip across the generations of a launch, the LSTM policy evaluated inside the
+// workgroup (reference: src/optimizer/lde_optimizer.py:159-198 = update(), src/agent/lde_agent.py:8-29,147-163 = PolicyNet + rollout loop).
+//
+// k_lde_step + k_lstm_policy are two launches per generation with a state round trip through HBM, a workgroup of 512 threads that
+// spends most of its barrier intervals 50-100 threads wide, and 76 KB of LDS (two workgroups per CU); the PMC pass of round 4
+// (profiles/r04a_lde_step_pmc.json) has the vector pipes 41 % busy and the waves waiting 64 % of their cycles.  k_lde_run is organised
+// around the wave instead of the workgroup:
+//   * a wave owns a tile of 16 population rows from the mutation to the end of the element-wise part of the objective.  The trial vector
+//     is computed directly in the A-operand layout of v_mfma_f64_16x16x4_f64 (lane (c, q) holds row c, coordinates 4 s + q), so the first
+//     linear map is 16 matrix instructions fed from registers; the transforms run on the accumulator (C / D layout, lane = (rows q + 4 r,
+//     coordinate 16 ct + c)) and only the values the row sums need are written to the wave's own 16 x D slice of ONE LDS array.  No
+//     workgroup barrier from the policy's action to the row sums; seven (pop 100) / four (pop 50) waves run that chain independently.
+//   * the parents stay in LDS in PHYSICAL rows; the fitness order is an index permutation (ORDER / RANK) instead of a copy of the
+//     population per generation; a surviving trial is written over its parent from the registers that still hold it.
+//   * LDS: parents + one tile array + ~6 KB = 53.9 KB at pop 100 / D 30 -> THREE workgroups per CU (27 KB at pop 50: five).
+//   * the LSTM cell + both heads are ~52 k float32 multiply-adds per generation: one fma chain per output unit in ascending k, the
+//     same chain v_mfma_f32_16x16x4_f32 evaluates in k_lstm_policy (bit-identical: tests/test_gpu_lde.py), weights from L2.
+//   * HBM traffic: the state block is read once and written once per launch.
+// Every generation is the arithmetic of k_lde_step with the same Philox counters, so n launches of mbx_lde_policy + mbx_step and one
+// launch of mbx_lde_rollout leave bit-identical state blocks, (h, c), rewards and features.
+//
+// Objectives: the element-wise part runs in the accumulator layout, so it is written per function kind here (same expressions, same
+// out-of-line math routines, same summation order as eval_rows).  Kinds that need the candidate itself or two arrays in the row sums
+// (3, 4, 5, 15, 20, 24) are not built: mbx_lde_rollout steps batches that contain them with one launch per generation.  The boundary
+// penalty of every kind is exactly +0 here (the midpoint repair keeps a trial inside [lb, ub]) and is added as the literal it is.
+#pragma once
+#include "mbx_lde.hpp"
+#include "mbx_lstm_policy.hpp"
+
+namespace mbx {
+
+struct LdeRunOut {
+    float* traj_actions;         // [n_gens][B][2 NP] sampled actions, or nullptr
+    double* traj_state;          // [n_gens][B][NP + 10] features after the generation, or nullptr
+    double* traj_reward;         // [n_gens][B]
+    uint8_t* traj_done;          // [n_gens][B]
+    double* state_out;           // [B][NP + 10] features after the last executed generation
+    double* reward_out;          // [B] SUM of the rewards of the executed generations, or nullptr
+    uint8_t* done_out;           // [B]
+};
+
+// ONE kernel argument: the kernel reads its fields through the kernarg segment pointer (scalar loads where they are used) instead of holding
+// ~60 argument SGPRs across the generation loop, where they collide with the loop's own uniform values and are spilled to VGPR lanes.
+struct LdeRunArgs {
+    BatchParams bp;
+    LstmPolicy net;
+    const double* state_in;      // [B][NP + 10] features of the last reset / step / rollout
+    float* hbuf;                 // [B][H]
+    float* cbuf;                 // [B][H]
+    int32_t n_gens;
+    LdeRunOut out;
+};
+typedef const LdeRunArgs __attribute__((address_space(4))) LdeRunCArgs;
+__device__ __forceinline__ LdeRunCArgs& lde_run_args()
+{
+    uintptr_t p = (uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                                   // not loop-invariant, not common with any other use: every field access is a fresh s_load
+    return *(LdeRunCArgs*)p;
+}
+
+__host__ __device__ constexpr bool lde_run_kind_ok(int kind)
+{
+    return kind == 1 || kind == 2 || (kind >= 6 && kind <= 14) || (kind >= 16 && kind <= 19) || (kind >= 21 && kind <= 23);
+}
+
+__host__ __device__ constexpr int lde_run_tiles(int NP) { return (NP + 15) / 16; }
+__host__ __device__ constexpr int lde_run_threads(int NP) { return 64 * lde_run_tiles(NP); }
+
+struct LdeRunLds {
+    double *P, *TB, *FIT, *A1, *A2, *FEAT, *HS, *RED, *SCAL, *DSH;
+    float *ACT, *HC;
+    int *RK0, *RK1, *ORDER, *HIST, *FLAG;
+};
+
+// LDS is allocated in 1280-byte granules: 3 workgroups per CU need <= 53 760 B each (pop 100: 53 104 B), 6 need <= 26 880 B (pop 50: 26 704 B)
+__host__ __device__ inline int64_t lde_run_lds_doubles(int NP, int D, int H)
+{
+    const int64_t NE = align2((int64_t)NP * D), P = align2(NP);
+    return 2 * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + 3 * align2((P + 1) / 2) + 4 + align2(D);
+}
+
+__device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, int H)
+{
+    const int64_t NE = align2((int64_t)NP * D), P = align2(NP), PI = align2((P + 1) / 2);
+    LdeRunLds L;
+    double* p = base;
+    L.P = p; p += NE;  L.TB = p; p += NE;
+    L.FIT = p; p += P;
+    L.A1 = p; p += P;            // SORTED (from the ranking to the next row sums) | Gallagher: best key per row
+    L.FEAT = p; L.A2 = p; p += align2(NP + 2 * MBX_LDE_BINS);   // features; dead between the policy's input staging and the next feature phase, where
+                                 // the objective uses the storage: F0 (step ellipsoid: |z_hat_0|) | Gallagher: winning peak per row
+    L.HS = p; p += 8;  L.RED = p; p += 8;  L.SCAL = p; p += 8;
+    L.ACT = (float*)p; p += P;
+    L.HC = (float*)p; p += align2(H);
+    L.RK0 = (int*)p; p += PI;  L.RK1 = (int*)p; p += PI;  L.ORDER = (int*)p; p += PI;
+    L.HIST = (int*)p;            // [5] bin counts, [6] the done flag
+    L.FLAG = L.HIST + 6;
+    p += 4;
+    L.DSH = p;                   // the problem's shift vector (0 where the objective has none)
+    return L;
+}
+
+// LDS traffic between the lanes of ONE wave (a store by one lane, a load of that address by another): the DS unit executes a wave's
+// operations in program order, so all that is needed is that the compiler keeps the order and that the data has landed
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// order-preserving map double -> uint64 (for the LDS max of the Gallagher keys)
+__device__ __forceinline__ unsigned long long f64_sortable(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// timing experiments only (never a shipped build): bit 0 no gate chains, 1 no head chains, 2 cheap hash instead of Philox in the tile phase,
+// 4 no noise in the row phase, 5 no ranking pass
+#ifndef MBX_LDE_ABL
+#define MBX_LDE_ABL 0
+#endif
+// waves per SIMD the register allocation aims at.  pop 100: 3 workgroups x 7 waves per CU need 6 (80 VGPRs, ~30 of them spilled); with 5 (96 VGPRs) only
+// two workgroups fit -- measured on one box, Sphere batch: 0.632 (6) / 0.592 (5) / 0.612 (4) ms per generation, all 30 functions 0.856 (6) against 0.87-0.95 (5):
+// the third workgroup pays on the expensive objectives.  pop 50: 5 workgroups x 4 waves = 5 per SIMD either way, so it takes the 96 registers (0.335 -> 0.286 ms on Sphere).
+#ifndef MBX_LDE_RUN_WAVES
+#define MBX_LDE_RUN_WAVES(NP) ((NP) <= 64 ? 5 : 6)
+#endif
+
+// loop-carried scalars of the instance, in LDS (thread 0 updates them at the end of a generation, every thread reads what it needs at the top of the next)
+enum { LR_FES = 0, LR_HCOUNT, LR_BSF, LR_RSUM, LR_RTOT, LR_LOGI, LR_CLEN };
+
+template <int NPC, int DC, int HC_ = 50>
+__global__ __launch_bounds__(64 * ((NPC + 15) / 16)) __attribute__((amdgpu_waves_per_eu(MBX_LDE_RUN_WAVES(NPC))))
+void k_lde_run(LdeRunArgs args_)
+{
+    (void)args_;                                                   // read through lde_run_args()
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
+    constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
+    static_assert(D > 16 && D <= 32, "two 16-column tiles");
+    const LdeRunLds L = lde_run_carve(smem, NP, D, H);
+    int b, gen0, episode, n_gens;
+    {
+        LdeRunCArgs& ar = lde_run_args();
+        const int tid = threadIdx.x;
+        b = __builtin_amdgcn_readfirstlane(ar.bp.order[blockIdx.x]);
+        n_gens = ar.n_gens;
+        double* S = ar.bp.state + (int64_t)b * ar.bp.state_stride;
+        double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
+        if (sc[MBX_SC_DONE] != 0.) {                               // finished before this launch: state_out keeps the last features
+            if (tid == 0) {
+                if (ar.out.reward_out) ar.out.reward_out[b] = 0.;
+                if (ar.out.done_out) ar.out.done_out[b] = 1;
+                for (int g = 0; g < n_gens; ++g) {
+                    if (ar.out.traj_reward) ar.out.traj_reward[(int64_t)g * ar.bp.B + b] = 0.;
+                    if (ar.out.traj_done) ar.out.traj_done[(int64_t)g * ar.bp.B + b] = 1;
+                }
+            }
+            return;
+        }
+        episode = __builtin_amdgcn_readfirstlane((int)sc[MBX_SC_EPISODE]);
+        gen0 = __builtin_amdgcn_readfirstlane((int)sc[MBX_SC_GEN]);
+        // ---- the state block, once
+        const double* gPop = S + MBX_LDE_ST_POP(NP, D);
+        for (int e = tid; e < NE; e += MBX_NT) L.P[e] = gPop[e];
+        for (int i = tid; i < NP; i += MBX_NT) {
+            const double f = S[MBX_LDE_ST_FIT(NP, D) + i];
+            L.FIT[i] = f; L.A1[i] = f;                             // sorted in HBM: SORTED == FIT
+            L.RK0[i] = i; L.ORDER[i] = i;
+        }
+        if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
+        {
+            const DevProblem* pr = ar.bp.problems + ar.bp.problem_idx[b];
+            const double* dsh = pr->dshift;
+            if (tid < D) L.DSH[tid] = (dsh && !(pr->kind == 21 || pr->kind == 22)) ? dsh[tid] : 0.;      // Gallagher: no shift (peaks pre-rotated)
+        }
+        for (int k = tid; k < NF; k += MBX_NT) L.FEAT[k] = ar.state_in[(int64_t)b * NF + k];
+        if (tid < H) { L.HC[tid] = ar.hbuf[(int64_t)b * H + tid]; L.HC[H + tid] = ar.cbuf[(int64_t)b * H + tid]; }
+        {   // the policy's input [x | h] as float32 (afterwards the feature phase of a generation stages the next one's)
+            float* XS = (float*)L.TB;
+            for (int k = tid; k < K1; k += MBX_NT) XS[k] = k < IN ? (float)ar.state_in[(int64_t)b * NF + k] : ar.hbuf[(int64_t)b * H + (k - IN)];
+        }
+        if (tid == 0) {
+            L.FLAG[0] = 0;
+            L.SCAL[LR_FES] = sc[MBX_SC_FES]; L.SCAL[LR_HCOUNT] = sc[MBX_SC_HCOUNT]; L.SCAL[LR_BSF] = S[MBX_LDE_ST_FIT(NP, D)];
+            L.SCAL[LR_RSUM] = 0.; L.SCAL[LR_RTOT] = sc[MBX_SC_RETURN]; L.SCAL[LR_LOGI] = sc[MBX_SC_LOG_INDEX]; L.SCAL[LR_CLEN] = sc[MBX_SC_COST_LEN];
+        }
+    }
+    __syncthreads();
+    MBX_PHASE_BEGIN
+    int executed = 0;
+
+    for (int it = 0; it < n_gens; ++it) {
+        // Nothing below may look loop-invariant to the compiler: what it hoists out of a loop this long it spills (the first version of this kernel
+        // carried 190 spilled SGPRs and 41 scratch stores in its prologue).  Thread index, argument block and problem record are re-materialised
+        // behind empty asm statements at the top of every generation (cf. opaque_tid() and k_rlepso_run).
+        const int tid = opaque_tid();
+        const int lane = tid & 63, c = lane & 15, q = lane >> 4;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        LdeRunCArgs& ar = lde_run_args();
+        uintptr_t pp_ = (uintptr_t)(ar.bp.problems + __builtin_amdgcn_readfirstlane(ar.bp.problem_idx[b]));
+        asm volatile("" : "+s"(pp_));
+        ConstProblem& P = *(ConstProblem*)pp_;
+#ifdef MBX_LDE_ONLY_KIND
+        const int kind = MBX_LDE_ONLY_KIND;                        // timing experiment: code size (every other kind compiled out)
+#else
+        const int kind = P.kind;
+#endif
+        const double lb = P.lb, ub = P.ub, bias = P.bias;
+        const uint64_t seed = ar.bp.seeds[b];
+        const int gen = gen0 + it + 1;
+        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)episode, true};
+        const double fes = L.SCAL[LR_FES];
+        int* RKa = (it & 1) ? L.RK1 : L.RK0;                        // RANK of the current order; the other array takes the next one
+        int* RKb = (it & 1) ? L.RK0 : L.RK1;
+        const float* WT = ar.net.w;                                // [K1][4H] (WihT | WhhT contiguous), then b, WmuT, WsgT, bmu, bsg
+        const float* bg = WT + (int64_t)K1 * G4;
+        const float* WmuT = bg + G4;
+        const float* WsgT = WmuT + (int64_t)H * A;
+        const float* bmu = WsgT + (int64_t)H * A;
+        const float* bsg = bmu + A;
+        // ================================================================ policy: LSTM cell + heads + sampling (lde_agent.py:8-29)
+        // The tile array is idle between the row sums and the next mutation: it holds the cell's inputs [x | h] as float32 (staged by the
+        // previous generation's feature phase / the prologue), the gate pre-activations and the sigma head's output.  A chain is one fma per k in
+        // ascending k; the weights of LB steps are fetched (L2) before the LB fmas that use them -- few, large batches: the phase is the latency
+        // of its dependent L2 round trips.
+        float* XS = (float*)L.TB;                                  // [K1]
+        float* GT = XS + ((K1 + 3) & ~3);                          // [4H]
+        float* SG = GT + G4;                                       // [A] sigma head, pre-activation
+        constexpr int LB = 40;
+        if (tid < G4) {
+            float acc = bg[tid];
+            const float* wcol = WT + tid;
+#pragma unroll 1
+            for (int k0 = 0; k0 < ((MBX_LDE_ABL & 1) ? 0 : K1); k0 += LB) {
+                float wv[LB];
+#pragma unroll
+                for (int j = 0; j < LB; ++j) wv[j] = k0 + j < K1 ? wcol[(int64_t)(k0 + j) * G4] : 0.f;
+#pragma unroll
+                for (int j = 0; j < LB; ++j) if (k0 + j < K1) acc = __builtin_fmaf(XS[k0 + j], wv[j], acc);
+            }
+            GT[tid] = acc;
+        }
+        __syncthreads();
+        MBX_PHASE(0);                                              // LSTM gates
+        if (tid < H) {
+            const float gi = sigmoidf_(GT[tid]), gf = sigmoidf_(GT[H + tid]);
+            const float gg = tanhf(GT[2 * H + tid]), go = sigmoidf_(GT[3 * H + tid]);
+            const float cn = gf * L.HC[H + tid] + gi * gg;
+            const float hn = go * tanhf(cn);
+            L.HC[H + tid] = cn;
+            L.HC[tid] = hn;
+        }
+        __syncthreads();
+        // heads: thread j < A runs the mu chain of component j, thread A + j the sigma chain (when the workgroup has 2 A threads; else both in thread j)
+        constexpr bool SPLIT = 2 * A <= 64 * TILES;
+        float am = 0.f;
+        if (tid < (SPLIT ? 2 * A : A)) {
+            const int j = SPLIT && tid >= A ? tid - A : tid;
+            const bool sig = SPLIT && tid >= A;
+            const float* W = sig ? WsgT : WmuT;
+            float acc = sig ? bsg[j] : bmu[j], acc2 = SPLIT ? 0.f : bsg[j];
+            float wm[H], ws[SPLIT ? 1 : H];
+#pragma unroll
+            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) { wm[k] = W[(int64_t)k * A + j]; if (!SPLIT) ws[k] = WsgT[(int64_t)k * A + j]; }
+#pragma unroll
+            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) {
+                const float hk = L.HC[k];
+                acc = __builtin_fmaf(hk, wm[k], acc);
+                if (!SPLIT) acc2 = __builtin_fmaf(hk, ws[k], acc2);
+            }
+            if (sig) SG[j] = acc; else am = acc;
+            if (!SPLIT) SG[j] = acc2;
+        }
+        if (SPLIT) __syncthreads();
+        if (tid < A) {
+            const float a = sample_action(rng, tid, am, sigmoidf_(SG[tid]), MBX_POLICY_RLEPSO);
+            L.ACT[tid] = a;
+            if (ar.out.traj_actions) ar.out.traj_actions[((int64_t)it * ar.bp.B + b) * A + tid] = a;
+        }
+        __syncthreads();
+        MBX_PHASE(1);                                              // cell update, heads, sampling
+
+        // ================================================================ the wave's tile: mutation -> first map -> transforms
+        // Branch-free on purpose: every load is unconditional with a clamped index and the padding is selected away afterwards -- a conditional
+        // load costs an EXEC save / restore and a branch each, serialises the LDS round trips behind it, and its mask lives in an SGPR pair (the first
+        // version of this phase ran 16 k cycles per generation alone on a CU, most of them in such chains).
+        const double p_rate = (2. / NP - 1) * fes / ar.bp.max_fes + 1;
+        const int bound = (int)ceil(NP * fmax(0., p_rate));
+        const int my_hist = tid < MBX_LDE_BINS ? lde_unpack_hist(L.HS[MBX_LDE_BINS], tid) : 0;
+        const int jrow = 16 * wave + c;                           // the row of this lane's A-layout elements
+        const bool rvalid = jrow < NP;
+        const int jr_c = rvalid ? jrow : NP - 1;                   // clamped: lanes past the last row compute on a copy of it, nothing of theirs is stored
+        double* TW = L.TB + 16 * wave * D;                         // this wave's slice of the tile array: rows 16 wave .. (row-major, D per row)
+        // the trial vector is parked in the instance's own population block in HBM (free until the end of the launch: the parents live in LDS) and read
+        // back by the lanes of the rows that survive -- 16 registers less across the transforms than holding it, and no compiler-placed spill chain
+        double* park = ar.bp.state + (int64_t)b * ar.bp.state_stride + MBX_LDE_ST_POP(NP, D);
+        const bool gall = kind == 21 || kind == 22;
+        int kq[KS];                                                // coordinate 4 s + q of the A / B fragments, clamped
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kq[s] = 4 * s + q < D ? 4 * s + q : D - 1;
+        double av[KS];                                             // A operand of the first map: trial - shift (0 in the padding)
+        {
+            const int i = RKa[jr_c];                               // position of the row in the fitness order = the individual's index
+            // ---- crossover uniforms of the tile: ONE Philox call per group of four consecutive elements of the SORTED population (site LDE_ELEM,
+            // index e >> 2), like k_lde_step; a row touches 8 groups, lane m of the wave makes the calls of (row m >> 3, group m & 7)
+            uint32_t* UW = (uint32_t*)TW;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int m = lane + 64 * h2, rr = m >> 3, g = m & 7, jr_ = 16 * wave + rr;
+                const int ii = RKa[jr_ < NP ? jr_ : NP - 1];
+                const int t = ((ii * D) >> 2) + g;
+                const U4 w = (MBX_LDE_ABL & 4) ? U4{(uint32_t)t * 2654435761u, (uint32_t)t * 40503u + 7u, (uint32_t)t ^ 0x9E3779B9u, (uint32_t)t * 69069u} : rng.draw((uint32_t)t, MBX_SITE_LDE_ELEM);
+                if (jr_ < NP && 4 * t < NE) *(uint4*)(UW + rr * 32 + 4 * g) = make_uint4(w.x, w.y, w.z, w.w);
+            }
+            // ---- per-individual draws (:101-105, 88-99)
+            const U4 w = (MBX_LDE_ABL & 4) ? U4{(uint32_t)i * 2654435761u, (uint32_t)i * 40503u + 7u, (uint32_t)i ^ 0x9E3779B9u, (uint32_t)i * 69069u} : rng.draw((uint32_t)i, MBX_SITE_LDE_PART);
+            const int pidx = (int)__umulhi(w.x, (uint32_t)bound);
+            int r0 = (int)__umulhi(w.y, (uint32_t)(NP - 1)); r0 += r0 >= i;
+            int r1 = (int)__umulhi(w.z, (uint32_t)(NP - 2));
+            { const int lo = i < r0 ? i : r0, hi = i < r0 ? r0 : i; r1 += r1 >= lo; r1 += r1 >= hi; }
+            const int jr = (int)__umulhi(w.w, (uint32_t)D);
+            const float sf32 = L.ACT[i];
+            const double sf = (double)sf32, cr = (double)L.ACT[NP + i], om = (double)(1.f - sf32);
+            const double* rowP = L.P + L.ORDER[pidx] * D;
+            const double* row0 = L.P + L.ORDER[r0] * D;
+            const double* row1 = L.P + L.ORDER[r1] * D;
+            const double* rowI = L.P + jr_c * D;
+            const uint32_t* urow = UW + (jr_c - 16 * wave) * 32 + ((i * D) & 3);   // (the clamped lanes read the uniforms of the row they are clamped to)
+            double* pk = park + jr_c * D;
+            const bool self = pidx == i;
+            wave_lds_fence();
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += 2) {                   // two coordinates at a time: their 12 LDS reads in flight, then their arithmetic
+                double xi[2], xp[2], x0[2], x1[2], sh[2];
+                uint32_t uw[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int d = kq[s0 + j];
+                    xi[j] = rowI[d]; xp[j] = rowP[d]; x0[j] = row0[d]; x1[j] = row1[d]; uw[j] = urow[d]; sh[j] = L.DSH[d];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int s = s0 + j, d = kq[s];
+                    const double u = d == jr ? 0. : u32d(uw[j]);
+                    // :88-99: x_i + F (x_pbest - x_i) + F (x_r0 - x_r1), written like the reference's tensor arithmetic: the two orders of the first sum
+                    // (pidx < i / pidx > i in k_lde_step) are the same addition, pidx == i leaves x_i
+                    const double blend = sf * xp[j] + om * xi[j];
+                    double m = self ? xi[j] : blend;
+                    m = m + sf * (x0[j] - x1[j]);
+                    double cval = u <= cr ? m : xi[j];
+                    const double rl = (xi[j] + lb) / 2., ru = (xi[j] + ub) / 2.;
+                    cval = cval < lb ? rl : (cval > ub ? ru : cval);
+                    pk[d] = cval;                                  // unconditional: a lane in the padding computes the element it is clamped to, bit for bit what its owner stores
+                    av[s] = (rvalid && 4 * s + q < D) ? cval - sh[j] : 0.;
+                }
+            }
+            wave_lds_fence();                                      // the uniforms are consumed: the slice is free for the transforms' output
+        }
+        MBX_PHASE(7);                                              // (instrumented builds: draws + mutation of wave 0)
+        // ---- z = M1 (x - dshift) on the float64 matrix cores (Gallagher: M1 x, the peaks are pre-rotated): the fma chain of matvec_rows_mfma.
+        // The result goes straight to the wave's slice (C / D layout: lane (c, q) holds rows q + 4 r, coordinates c and 16 + c); everything
+        // element-wise then happens IN PLACE there, one element per lane at a time (loops that are not unrolled: the transforms are out-of-line
+        // calls, and the fewer values are alive across a call the fewer are spilled around it).
+        const int c1 = 16 + c < D ? 16 + c : D - 1;                // second column tile, clamped
+        auto map_tile = [&](const double* __restrict__ M, const double (&a)[KS]) {
+            f64x4 y0 = {0., 0., 0., 0.}, y1 = {0., 0., 0., 0.};
+            double bm0[KS], bm1[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bm0[s] = M[c * D + kq[s]];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bm1[s] = M[c1 * D + kq[s]];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], 4 * s + q < D ? bm0[s] : 0., y0, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], (4 * s + q < D && 16 + c < D) ? bm1[s] : 0., y1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = q + 4 * r;
+                if (16 * wave + lr < NP) {
+                    TW[lr * D + c] = y0[r];
+                    if (16 + c < D) TW[lr * D + 16 + c] = y1[r];
+                }
+            }
+        };
+        map_tile(P.m1, av);
+        MBX_PHASE(8);                                              // (first linear map of wave 0)
+        // element m of a lane: m = 4 ct + r -> (local row q + 4 r, coordinate 16 ct + c)
+        auto elem = [&](int m, int& lr, int& d) -> bool { lr = q + 4 * (m & 3); d = 16 * (m >> 2) + c; return 16 * wave + lr < NP && d < D; };
+        if (kind == 7 && c == 0) {                                 // F7 keeps |z_hat_0| (bbob.py: the max() of the step ellipsoid)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int lr = q + 4 * r; if (16 * wave + lr < NP) L.A2[16 * wave + lr] = fabs(TW[lr * D]); }
+        }
+        if (!(kind == 1 || kind == 13 || gall)) {                  // phase E1 of eval_rows
+            const double s0 = P.s[0];
+            const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
+#pragma unroll 1
+            for (int m = 0; m < 8; ++m) {
+                int lr, d;
+                if (!elem(m, lr, d)) continue;
+                double* pz = TW + lr * D + d;
+                const double z = *pz;
+                double t;
+                switch (kind) {
+                case 2: case 10: { const double o = osc1(z); t = P.v0[d] * (o * o); break; }
+                case 6: { double zi = z; if (zi * P.dshift[d] > 0.) zi *= 100.; t = zi * zi; break; }
+                case 7: t = fabs(z) > 0.5 ? floor(0.5 + z) : floor(0.5 + 10. * z) / 10.; break;
+                case 8: t = s0 * z + 1; break;
+                case 9: case 19: t = z + 0.5; break;
+                case 11: { const double o = osc1(z); t = o * o; break; }
+                case 12: case 17: case 18: t = asy1(z, P.v1[d]); break;
+                case 14: t = m_pow(fabs(z), P.v0[d]); break;
+                case 16: t = osc1(z); break;
+                case 23: {
+                    double temp = 0., p2 = 1., ip2 = 1.;
+                    for (int j = 1; j <= 32; ++j) {
+                        p2 *= 2.; ip2 *= 0.5;
+                        const double a = p2 * z;
+                        temp += fabs(a - floor(a + 0.5)) * ip2;
+                    }
+                    t = m_pow(1 + (d + 1) * temp, kats_exp);
+                    break;
+                }
+                default: t = z; break;
+                }
+                *pz = t;
+            }
+        }
+        if ((kind == 7 || kind == 12 || (kind >= 16 && kind <= 18))) {    // second linear map (F7, F16-F18: M2; F12: M1 again) of the tile just written
+            wave_lds_fence();
+            double av2[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { const double v = TW[(rvalid ? c : 0) * D + kq[s]]; av2[s] = (rvalid && 4 * s + q < D) ? v : 0.; }
+            wave_lds_fence();                                      // every lane holds its A fragment: the slice can take the product
+            map_tile(kind == 12 ? P.m1 : P.m2, av2);
+            if (kind == 16) {                                      // Weierstrass series by angle tripling (eval_rows, phase E2)
+#pragma unroll 1
+                for (int m = 0; m < 8; ++m) {
+                    int lr, d;
+                    if (!elem(m, lr, d)) continue;
+                    double* pz = TW + lr * D + d;
+                    const double base = kTwoPi * (*pz + 0.5);
+                    double cc = m_cos(base), ss = m_sin(base), sum = cc, ak = 1.;
+#pragma unroll
+                    for (int k = 1; k < 12; ++k) {
+                        const double c2 = cc * cc, s2 = ss * ss;
+                        cc = cc * __builtin_fma(-3., s2, c2);
+                        ss = ss * __builtin_fma(3., c2, -s2);
+                        ak *= 0.5;
+                        sum = __builtin_fma(ak, cc, sum);
+                    }
+                    *pz = sum;
+                }
+            }
+        }
+        if ((kind == 17 || kind == 18 || kind == 19)) {              // terms of neighbouring coordinates (bbob.py:642-643, 702-703)
+            // element (row, d) needs (row, d + 1), which another lane owns and overwrites with ITS term: the wave walks m in step -- all lanes read,
+            // then all lanes write -- and in ascending m, so the one neighbour that belongs to a later step (d = 15 -> 16) is still untouched
+#pragma unroll 1
+            for (int m = 0; m < 8; ++m) {
+                int lr, d;
+                const bool ok = elem(m, lr, d) && d < D - 1;       // coordinate D - 1 has no term
+                wave_lds_fence();
+                const double a = ok ? TW[lr * D + d] : 0., nb = ok ? TW[lr * D + d + 1] : 0.;
+                wave_lds_fence();
+                if (ok) {
+                    double t;
+                    if (kind == 19) {
+                        const double aa = a * a - nb;
+                        const double bb = 1. - a;
+                        const double sq = 100. * (aa * aa) + bb * bb;
+                        t = sq / 4000. - m_cos(sq);
+                    } else {
+                        const double sq = sqrt(a * a + nb * nb);
+                        t = sqrt(sq) * (m_pow(m_sin(50 * m_pow(sq, 0.2)), 2) + 1);
+                    }
+                    TW[lr * D + d] = t;
+                }
+            }
+        }
+        __syncthreads();
+        MBX_PHASE(2);                                              // mutation, linear maps, transforms (wave-local)
+
+        // ================================================================ Gallagher: winning peak of every row (block-wide: lane = row, wave = peaks)
+        if (gall) {
+            unsigned long long* GK = (unsigned long long*)L.A1;
+            int* GI = (int*)L.A2;
+            for (int i = tid; i < NP; i += MBX_NT) { GK[i] = 0ull; GI[i] = 0x7fffffff; }
+            __syncthreads();
+            typedef const double __attribute__((address_space(4)))* kptr;
+            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
+            const int npk = P.n_peaks, nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+            const double cexp = -0.5 / D;
+            constexpr int PB = 4, GC = 6;
+            static_assert(D % GC == 0, "whole chunks only");
+            const int mine = wave < npk ? (npk - wave + nw - 1) / nw : 0;
+            double bkey[2] = {-INFINITY, -INFINITY};
+            int bk[2] = {0, 0};
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                if (64 * qq >= NP) break;
+                const int i = lane + 64 * qq;
+                const double* rx = L.TB + (i < NP ? i : NP - 1) * D;
+                for (int j0 = 0; j0 < mine; j0 += PB) {
+                    double acc[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) acc[j] = 0.;
+#pragma unroll 1
+                    for (int c0 = 0; c0 < D; c0 += GC) {
+                        double y[GC];
+#pragma unroll
+                        for (int k = 0; k < GC; ++k) y[k] = rx[c0 + k];
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) {
+                            if (j0 + j < mine) {
+                                const int kk = wave + (j0 + j) * nw;
+                                const kptr ry = py + (int64_t)kk * D + c0;
+                                const kptr ck = pcc + (int64_t)kk * D + c0;
+#pragma unroll
+                                for (int k = 0; k < GC; ++k) { const double zd = y[k] - ry[k]; acc[j] = __builtin_fma(ck[k], zd * zd, acc[j]); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        if (j0 + j < mine) {
+                            const int kk = wave + (j0 + j) * nw;
+                            const double key = plw[kk] + cexp * acc[j];
+                            if (key > bkey[qq]) { bkey[qq] = key; bk[qq] = kk; }
+                        }
+                    }
+                }
+                if (i < NP && mine > 0) atomicMax(&GK[i], f64_sortable(bkey[qq]));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int i = lane + 64 * qq;
+                if (i < NP && mine > 0 && f64_sortable(bkey[qq]) == GK[i]) atomicMin(&GI[i], bk[qq]);   // equal keys: the lower peak index (eval_rows' rule)
+            }
+            __syncthreads();
+        }
+
+        MBX_PHASE(3);                                              // Gallagher peak search
+        // ================================================================ row sums + noise -> trial costs; selection (:55-59)
+        int surv_mine = 0;
+        if (tid < NP) {
+            const int j = tid;
+            const double* z = L.TB + j * D;
+            const double* t = z;
+            const double bh = 0.;                                  // boundary penalty of an in-range candidate: exactly +0 (see the header)
+            double f;
+            switch (kind) {
+            case 1: { double s = 0.; for (int d = 0; d < D; ++d) s += z[d] * z[d]; f = s + bias + bh; break; }
+            case 2: case 10: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = s + bias + bh; break; }
+            case 6: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = m_pow(osc1(s), 0.9) + bias; break; }
+            case 7: {
+                double s = 0.;
+                for (int d = 0; d < D; ++d) s += P.v0[d] * (z[d] * z[d]);
+                f = 0.1 * fmax(L.A2[j] / 1e4, s) + bh + bias;
+                break;
+            }
+            case 8: case 9: {
+                double s = 0.;
+                for (int d = 0; d < D - 1; ++d) {
+                    const double a = z[d] * z[d] - z[d + 1];
+                    const double bb = z[d] - 1;
+                    s += 100 * (a * a) + bb * bb;
+                }
+                f = s + bias + bh;
+                break;
+            }
+            case 11: { double s = 0.; for (int d = 1; d < D; ++d) s += t[d]; f = 1000000 * t[0] + s + bias; break; }
+            case 12: { double s = 0.; for (int d = 1; d < D; ++d) s += 1000000 * (z[d] * z[d]); f = z[0] * z[0] + s + bias; break; }
+            case 13: { double s = 0.; for (int d = 1; d < D; ++d) s += z[d] * z[d]; f = z[0] * z[0] + 100. * sqrt(s) + bias; break; }
+            case 14: { double s = 0.; for (int d = 0; d < D; ++d) s += t[d]; f = m_pow(s, 0.5) + bias + bh; break; }
+            case 16: {
+                double acc = 0.; for (int d = 0; d < D; ++d) acc += t[d];
+                f = 10 * m_pow(acc / D - P.s[0], 3) + 10. / D * bh + bias;
+                break;
+            }
+            case 17: case 18: {
+                double acc = 0.; for (int d = 0; d < D - 1; ++d) acc += t[d];
+                f = m_pow(1. / (D - 1) * acc, 2) + bh + bias;
+                break;
+            }
+            case 19: {
+                double acc = 0.; for (int d = 0; d < D - 1; ++d) acc += t[d];
+                f = P.s[0] + P.s[0] * acc / (D - 1.) + bias + bh;
+                break;
+            }
+            case 21: case 22: {
+                const int ks = ((const int*)L.A2)[j];
+                const double* __restrict__ ry = P.pyr + ks * D;
+                const double* __restrict__ ck = P.pc + ks * D;
+                double acc = 0.;
+                for (int d = 0; d < D; ++d) { const double zd = z[d] - ry[d]; acc += ck[d] * (zd * zd); }
+                const double best = P.pw[ks] * m_exp((-0.5 / D) * acc);
+                const double o = osc1(10 - best);
+                f = o * o + bias + bh;
+                break;
+            }
+            case 23: {
+                double res = 1.; for (int d = 0; d < D; ++d) res *= t[d];
+                const double tmp = 10. / D / D;
+                f = res * tmp - tmp + bh + bias;
+                break;
+            }
+            default: f = NAN; break;
+            }
+            const RowPost post{&rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B, NP};
+            const double nc = (MBX_LDE_ABL & 16) ? f - P.optimum : row_post(P, post, RKa[j], f);        // the noise draw of an individual is indexed by its position in the order
+            surv_mine = nc <= L.FIT[j];
+            if (surv_mine) L.FIT[j] = nc;
+            RKb[j] = 0;                                            // accumulator of the next ranking
+        }
+        // the survivors' flags: one ballot per wave, read by the lanes that own the rows (row j's flag is bit j & 63 of wave j >> 6's ballot)
+        {
+            const unsigned long long bal = __ballot(surv_mine);
+            if (lane == 0) ((unsigned long long*)L.RED)[wave] = bal;
+        }
+        __syncthreads();
+        MBX_PHASE(4);                                              // row sums, noise, selection
+        // ---- survivors take the trial vector (parked in HBM by the lanes that built it, read back by the same lanes); stable ranking of the new fitness values
+        {
+            const unsigned long long bal = ((const unsigned long long*)L.RED)[jrow >> 6];
+            if (rvalid && ((bal >> (jrow & 63)) & 1ull)) {
+                double tv[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) tv[s] = park[jrow * D + kq[s]];        // written by this very lane in the tile phase (and, identically, by the lanes clamped to it)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) if (4 * s + q < D) L.P[jrow * D + 4 * s + q] = tv[s];
+            }
+            // rank = number of individuals that are better, or equally good and earlier in the previous order (the stable sort of __order_by_f).
+            // Thread (i, part) counts over a slice of j; two equal fitness values are rare (a collapsed population), so the first pass counts
+            // `<` and `==` only and the order of the equal ones is looked up when there are any.
+            constexpr int parts = (64 * TILES) / NP > 0 ? (64 * TILES) / NP : 1;
+            for (int w2 = tid; w2 < ((MBX_LDE_ABL & 32) ? 0 : parts * NP); w2 += MBX_NT) {
+                const int part = w2 / NP, i = w2 - part * NP;
+                const int j0 = part * NP / parts, j1 = (part + 1) * NP / parts;
+                const double fi = L.FIT[i];
+                int cnt = 0, eq = 0;
+#pragma unroll 5
+                for (int j = j0; j < j1; ++j) { const double fj = L.FIT[j]; cnt += fj < fi; eq += fj == fi; }
+                if (eq > (i >= j0 && i < j1 ? 1 : 0)) {
+                    const int ri = RKa[i];
+                    for (int j = j0; j < j1; ++j) cnt += (L.FIT[j] == fi && RKa[j] < ri);
+                }
+                if (cnt) atomicAdd(&RKb[i], cnt);
+            }
+            if (tid < MBX_LDE_BINS) L.HS[tid] += (double)my_hist;
+        }
+        __syncthreads();
+        if (tid < NP) { const int r = (MBX_LDE_ABL & 32) ? RKa[tid] : RKb[tid]; if (MBX_LDE_ABL & 32) RKb[tid] = r; L.ORDER[r] = tid; L.A1[r] = L.FIT[tid]; }
+        __syncthreads();
+        MBX_PHASE(5);                                              // survivors, ranking, order
+        // ---- features of the new state (:145-157) and the bookkeeping of update() (:170-198)
+        lde_norm_hist(L.A1, NP, L.FEAT, L.HIST);
+        const double hcount = L.SCAL[LR_HCOUNT] + 1;
+        if (tid < MBX_LDE_BINS) {
+            L.FEAT[NP + tid] = (double)L.HIST[tid];
+            L.FEAT[NP + MBX_LDE_BINS + tid] = L.HS[tid] / hcount;
+        }
+        __syncthreads();                                           // every thread has read fes / hcount of this generation
+        { float* XS = (float*)L.TB; for (int k = tid; k < K1; k += MBX_NT) XS[k] = k < IN ? (float)L.FEAT[k] : L.HC[k - IN]; }   // the next generation's policy input (FEAT is complete; published by the barrier below)
+        if (tid == 0) {
+            L.HS[MBX_LDE_BINS] = lde_pack_hist(L.HIST);
+            const double bsf_next = L.A1[0], bsf_cur = L.SCAL[LR_BSF], fes_next = fes + NP;
+            const double reward = (bsf_cur - bsf_next) / bsf_cur;   // :170
+            int log_index = (int)L.SCAL[LR_LOGI], cost_len = (int)L.SCAL[LR_CLEN];
+            double* sc = ar.bp.state + (int64_t)b * ar.bp.state_stride + MBX_LDE_ST_SCALARS(NP, D);
+            bool dn;
+            {   // log_and_terminate (mbx_rlepso.hpp) on the argument block's fields
+                double* cost = sc + MBX_NSCALAR;
+                if (fes_next >= (double)log_index * ar.bp.log_interval) { log_index += 1; cost[cost_len++] = bsf_next; }
+                dn = fes_next >= ar.bp.max_fes;
+                if (!isnan(P.optimum) && ar.bp.early_stop) dn = dn || bsf_next <= 1e-8;
+                if (dn) {
+                    if (cost_len >= ar.bp.n_logpoint + 1) cost[cost_len - 1] = bsf_next;
+                    else cost[cost_len++] = bsf_next;
+                }
+            }
+            L.SCAL[LR_FES] = fes_next; L.SCAL[LR_HCOUNT] = hcount; L.SCAL[LR_BSF] = bsf_next;
+            L.SCAL[LR_RSUM] += reward; L.SCAL[LR_RTOT] += reward; L.SCAL[LR_LOGI] = log_index; L.SCAL[LR_CLEN] = cost_len;
+            L.FLAG[0] = dn ? 1 : 0;
+            if (ar.out.traj_reward) ar.out.traj_reward[(int64_t)it * ar.bp.B + b] = reward;
+            if (ar.out.traj_done) ar.out.traj_done[(int64_t)it * ar.bp.B + b] = dn ? 1 : 0;
+        }
+        __syncthreads();
+        if (ar.out.traj_state) for (int k = tid; k < NF; k += MBX_NT) ar.out.traj_state[((int64_t)it * ar.bp.B + b) * NF + k] = L.FEAT[k];
+        MBX_PHASE(6);                                              // features, bookkeeping
+        executed = it + 1;
+        if (L.FLAG[0] != 0) break;
+    }
+
+    // ---- the state block, once: population and fitness in fitness order, like k_lde_step leaves them
+    {
+        LdeRunCArgs& ar = lde_run_args();
+        const int tid = threadIdx.x;
+        double* S = ar.bp.state + (int64_t)b * ar.bp.state_stride;
+        double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
+        const int* RK = (executed & 1) ? L.RK1 : L.RK0;
+        double* gPop = S + MBX_LDE_ST_POP(NP, D);
+        const FastDiv fd(D);
+        for (int e = tid; e < NE; e += MBX_NT) { const int j = fd.div(e), d = e - j * D; gPop[RK[j] * D + d] = L.P[e]; }
+        for (int i = tid; i < NP; i += MBX_NT) S[MBX_LDE_ST_FIT(NP, D) + i] = L.A1[i];
+        if (tid < 8) S[MBX_LDE_ST_HSUM(NP, D) + tid] = L.HS[tid];
+        for (int k = tid; k < NF; k += MBX_NT) ar.out.state_out[(int64_t)b * NF + k] = L.FEAT[k];
+        if (tid < H) { ar.hbuf[(int64_t)b * H + tid] = L.HC[tid]; ar.cbuf[(int64_t)b * H + tid] = L.HC[H + tid]; }
+        if (tid == 0) {
+            const bool done = L.FLAG[0] != 0;
+            sc[MBX_SC_GBEST] = L.SCAL[LR_BSF]; sc[MBX_SC_FES] = L.SCAL[LR_FES]; sc[MBX_SC_LOG_INDEX] = L.SCAL[LR_LOGI]; sc[MBX_SC_COST_LEN] = L.SCAL[LR_CLEN];
+            sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] = L.SCAL[LR_RTOT]; sc[MBX_SC_GEN] = gen0 + executed; sc[MBX_SC_HCOUNT] = L.SCAL[LR_HCOUNT];
+            if (ar.out.reward_out) ar.out.reward_out[b] = L.SCAL[LR_RSUM];
+            if (ar.out.done_out) ar.out.done_out[b] = done ? 1 : 0;
+            for (int g = executed; g < n_gens; ++g) {              // generations after the termination: reward 0, done 1 (like k_rlepso_run's records)
+                if (ar.out.traj_reward) ar.out.traj_reward[(int64_t)g * ar.bp.B + b] = 0.;
+                if (ar.out.traj_done) ar.out.traj_done[(int64_t)g * ar.bp.B + b] = 1;
+            }
+        }
+    }
+}
+
+}  // namespace mbx

@@ -222,6 +222,35 @@ class Batch:
         acts = self._actions if sample else None
         return (acts, ms) if want_mu_sigma else acts
 
+    def lde_rollout_is_resident(self):
+        """True when lde_rollout runs the resident kernel k_lde_run (``mbx_lde_rollout_resident``), False for mbx_lde_policy + mbx_step per generation."""
+        return int(self.lib.mbx_lde_rollout_resident(self._h)) == 1
+
+    def lde_rollout(self, weights, hidden, h, c, n_gens, trajectory=False):
+        """Up to `n_gens` generations of PolicyNet.sampler + env.step per instance in ONE launch (``mbx_lde_rollout``): population, fitness order,
+        features and (h, c) stay on chip in between; bit-identical to `n_gens` x (lde_policy + step).  Reads and updates the batch's own state
+        tensor, h / c [B, hidden] in place.  Returns (state, reward summed over the executed generations, done) and, with ``trajectory=True``, a
+        dict of per-generation records: actions [n_gens, B, 2 NP] float32, state [n_gens, B, NP + 10] / reward [n_gens, B] float64, done uint8."""
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        assert h.is_cuda and c.is_cuda and h.dtype == c.dtype == torch.float32 and h.is_contiguous() and c.is_contiguous()
+        assert h.numel() == c.numel() == self.B * hidden
+        need = (self.state_dim + hidden) * 4 * hidden + 4 * hidden + 2 * hidden * self.action_dim + 2 * self.action_dim
+        if weights.numel() != need:
+            raise ValueError(f'packed LSTM policy has {weights.numel()} floats, in {self.state_dim} / hidden {hidden} / out {self.action_dim} needs {need}')
+        n_gens = int(n_gens)
+        traj = None
+        if trajectory:
+            traj = {'actions': torch.zeros(n_gens, self.B, self.action_dim, dtype=torch.float32, device=self.device),
+                    'state': torch.zeros(n_gens, self.B, self.state_dim, dtype=torch.float64, device=self.device),
+                    'reward': torch.empty(n_gens, self.B, dtype=torch.float64, device=self.device),
+                    'done': torch.empty(n_gens, self.B, dtype=torch.uint8, device=self.device)}
+        t = traj or {}
+        net = _abi.LstmPolicy(weights.data_ptr(), self.state_dim, int(hidden), self.action_dim)
+        _abi.check(self.lib.mbx_lde_rollout(self._h, C.byref(net), _ptr(self.state), _ptr(h), _ptr(c), n_gens, _ptr(t.get('actions')),
+                                            _ptr(t.get('state')), _ptr(t.get('reward')), _ptr(t.get('done')), _ptr(self.state), _ptr(self.reward),
+                                            _ptr(self.done), _stream()))
+        return (self.state, self.reward, self.done, traj) if trajectory else (self.state, self.reward, self.done)
+
     def gauss_policy(self, weights, h1, h2, min_sigma, max_sigma, want_mu_sigma=False):
         """RLEPSO / RL-PSO actor over the batch's current state in one launch (``mbx_gauss_policy``).  weights: packed float32 CUDA
         tensor (``Actor.packed_weights``).  Returns the [B, action_dim] float32 action tensor (overwritten by the next

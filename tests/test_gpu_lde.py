@@ -246,3 +246,124 @@ def test_lde_config3_population_through_the_plugin_surface():
     cost = out['cost'].cpu().numpy()
     assert np.all(cost[:, -1] <= cost[:, 0])
     env.close()
+
+
+# ------------------------------------------------------------------------------------------------ resident rollout (k_lde_run, mbx_lde_rollout)
+def _lde_net(NP, seed=3):
+    """The PolicyNet config 3 runs at this population: the shipped bbob-easy weights at the reference's NP = 50, a seeded fresh net at NP = 100."""
+    import os
+    from metabox_amd.agent import LDE_Agent
+    from metabox_amd.config import get_config
+    cfg = get_config(['--problem', 'bbob-noisy', '--dim', '30', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    if NP != 50:
+        cfg.NP_override = NP
+    torch.manual_seed(seed)
+    agent = LDE_Agent(cfg)
+    if NP == 50:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        agent.load_exported_weights(np.load(os.path.join(root, 'metabox_amd', 'agent_model', 'lde_bbob_easy.npz')))
+    return agent.to('cuda').net
+
+
+def _lde_rollout_case(suite_name, fids, NP, B, chunks, resident=True, maxfes=60000, early_stop=True):
+    """One mbx_lde_rollout launch per chunk against mbx_lde_policy + mbx_step per generation on a twin batch: per-generation actions, features,
+    rewards, done flags, the LSTM's (h, c), whole state blocks and result tables must agree bit for bit."""
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_LDE
+    dim = 30
+    ps = [problems(suite_name, dim)[f] for f in fids]
+    s = Suite(ps)
+    net = _lde_net(NP)
+    w, H = net.packed_weights(), net.lstm.hidden_size
+    pidx, seeds = np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) * 7919 + 5
+    a = Batch(s, ALGO_LDE, pidx, seeds, NP, maxfes, maxfes // 50, 50, early_stop=early_stop)
+    b = Batch(s, ALGO_LDE, pidx, seeds, NP, maxfes, maxfes // 50, 50, early_stop=early_stop)
+    assert a.lde_rollout_is_resident() == resident
+    a.reset(); b.reset()
+    ha, ca = torch.zeros(B, H, device='cuda'), torch.zeros(B, H, device='cuda')
+    hb, cb = torch.zeros(B, H, device='cuda'), torch.zeros(B, H, device='cuda')
+    for n in chunks:
+        st, rw, dn, traj = a.lde_rollout(w, H, ha, ca, n, trajectory=True)
+        st, rw, dn = st.clone(), rw.clone(), dn.clone()
+        rsum = torch.zeros(B, dtype=torch.float64, device='cuda')
+        for g in range(n):
+            live = (b.done == 0).clone()
+            hprev, cprev = hb.clone(), cb.clone()
+            acts = b.lde_policy(w, H, hb, cb).clone()
+            hb[~live] = hprev[~live]; cb[~live] = cprev[~live]       # (the per-generation policy kernel also advances finished instances; the rollout leaves them)
+            sb, rb, db = b.step(acts)
+            assert torch.equal(traj['actions'][g][live], acts[live]), (g, 'actions')
+            assert torch.equal(traj['reward'][g], rb) and torch.equal(traj['done'][g], db), (g, 'reward / done')
+            assert torch.equal(traj['state'][g][live], sb[live]), (g, 'features')
+            rsum += rb
+        assert torch.equal(st, sb) and torch.equal(dn, db) and torch.equal(rw, rsum)
+        assert torch.equal(ha, hb) and torch.equal(ca, cb)
+        torch.cuda.synchronize()
+        for k in range(0, B, max(1, B // 16)):
+            sa_, sb_ = a.read_state(k), b.read_state(k)
+            assert np.array_equal(sa_, sb_, equal_nan=True), (k, np.flatnonzero(sa_ != sb_)[:8])
+    ra, rb_ = a.results(), b.results()
+    for key in ra:
+        assert torch.equal(ra[key], rb_[key]), key
+    out = {k: v.cpu().numpy() for k, v in ra.items()}
+    a.close(); b.close()
+    return out
+
+
+@pytest.mark.parametrize('NP', [50, 100])
+def test_lde_resident_rollout_equals_policy_plus_step(NP):
+    """k_lde_run (population, order, features and the LSTM state on chip across the generations of a launch; PolicyNet inside the workgroup)
+    == k_lstm_policy + k_lde_step per generation, bit for bit: all 30 noisy functions (config 3's suite) in uneven chunks, then the bbob
+    functions whose kinds the resident kernel builds, then whole short episodes with the stop rule (launches that start with finished
+    instances, terminations inside a launch)."""
+    noisy = tuple(sorted(problems('bbob-noisy', 30)))
+    _lde_rollout_case('bbob-noisy', noisy, NP, 60, (1, 6, 13, 2))
+    _lde_rollout_case('bbob', (1, 2, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 21, 22, 23), NP, 36, (3, 8))
+    r = _lde_rollout_case('bbob-noisy', (101, 107, 116, 122, 128), NP, 20, (4, 9, 30), maxfes=NP * 12)
+    assert np.all(r['fes'] >= NP * 12) and np.all(r['steps'] == 11)          # every instance terminated inside the second launch
+
+
+def test_lde_rollout_host_loop_route(monkeypatch):
+    """Behind the same entry point: objective kinds the resident kernel does not build (F3, F15, F24: two arrays in the row sums / the candidate
+    itself), another geometry (D = 10), and MBX_ROLLOUT_PER_GENERATION=1 take mbx_lde_policy + mbx_step per generation -- same records."""
+    _lde_rollout_case('bbob', (1, 3, 15, 24), 50, 8, (2, 5), resident=False)
+    monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')
+    _lde_rollout_case('bbob-noisy', (101, 128), 100, 8, (3, 4), resident=False)
+
+
+@pytest.mark.parametrize('NP', [50, 100])
+def test_lde_resident_rollout_matches_the_oracle(NP):
+    """The resident kernel against the C oracle directly: 10 generations of all 30 noisy functions in ONE launch; the oracle, on the same Philox
+    seeds, replays the actions the in-kernel PolicyNet drew and must see the same features / rewards after every generation and the same
+    population at the end."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_LDE
+    s, ids = _suite('bbob-noisy', 30)
+    B, G, dim, maxfes = len(ids), 10, 30, 60000
+    net = _lde_net(NP)
+    w, H = net.packed_weights(), net.lstm.hidden_size
+    seeds = np.arange(B, dtype=np.uint64) * 104729 + 3
+    batch = Batch(s, ALGO_LDE, np.arange(B), seeds, NP, maxfes, maxfes // 50, 50)
+    assert batch.lde_rollout_is_resident()
+    st0 = batch.reset().cpu().numpy().copy()
+    h, c = torch.zeros(B, H, device='cuda'), torch.zeros(B, H, device='cuda')
+    _, _, _, traj = batch.lde_rollout(w, H, h, c, G, trajectory=True)
+    torch.cuda.synchronize()
+    acts, feats, rw = (traj[k].cpu().numpy() for k in ('actions', 'state', 'reward'))
+    cfg = oracle.make_cfg(2, NP, dim, maxfes, maxfes // 50, 50)
+    for b in range(B):
+        p = s.problems[b]
+        o = oracle.LdeOracle(p.desc(), p.bias, cfg, seed=int(seeds[b]))
+        f0 = o.reset()
+        assert np.abs(f0 - st0[b]).max() <= 1e-7, ids[b]
+        for g in range(G):
+            f, rew, d = o.step(acts[g, b])
+            assert np.abs(f - feats[g, b]).max() <= 1e-5, (ids[b], g)
+            assert abs(rew - rw[g, b]) <= 1e-5 * abs(rew) + 1e-9, (ids[b], g)
+        want = oracle.split_lde_state(o.state(), NP, dim, 50)
+        got = oracle.split_lde_state(batch.read_state(b), NP, dim, 50)
+        assert close(got['fit'], want['fit']), ids[b]
+        assert np.abs(got['pop'] - want['pop']).max() <= 1e-9, ids[b]
+        assert np.array_equal(got['hsum'][:5], want['hsum'][:5])
+    batch.close()

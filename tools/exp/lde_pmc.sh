@@ -30,6 +30,8 @@ for k, cs in sorted(v.items()):
     m['dispatches'] = max(len(x) for x in cs.values())
     g = m.get('GRBM_GUI_ACTIVE')
     if g:
+        g = g / 8                                                 # GRBM_GUI_ACTIVE comes summed over the 8 XCDs
+        m['kernel_cycles'] = g
         simd_cycles = 1024 * g                                   # 1024 SIMDs
         if 'SQ_ACTIVE_INST_VALU' in m: m['valu_busy_frac'] = 4 * m['SQ_ACTIVE_INST_VALU'] / simd_cycles      # quad-cycles
         if 'SQ_ACTIVE_INST_LDS' in m: m['lds_inst_busy_frac'] = 4 * m['SQ_ACTIVE_INST_LDS'] / simd_cycles
