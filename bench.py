@@ -153,39 +153,88 @@ def pmc_traffic_per_launch(live_per_launch, resident=False):
 
 
 def pmc_traffic_in_run(instances, timeout_s=150):
-    """HBM bytes per env-step of k_rlepso_run measured DURING this bench run, the way MI355X_MICROARCH.md prescribes: two separate rocprofv3
-    passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; no trace domains) of a child `bench.py --steps 20 --warmup 2 --repeats 1` (generations 3-22 of an
-    episode: every instance live, one 20-generation launch), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of that launch (FETCH_SIZE under-reports
-    these loads x2 on gfx950, WRITE_SIZE is 1:1: calibration in profiles/README.md), divided by its instances x 20 env-steps.
-    Returns (bytes per env-step, note) or (None, reason)."""
-    import csv, glob, re, shutil, subprocess, tempfile
+    """HBM bytes per env-step of k_rlepso_run AND its vector-ALU utilisation at the clock the chip really ran at, measured DURING this bench run the way
+    MI355X_MICROARCH.md prescribes: separate rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, one pass of SQ / GRBM counters; no trace domains) of
+    a child `bench.py --steps 20 --warmup 2 --repeats 1` (generations 3-22 of an episode: every instance live, one 20-generation launch).
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of that launch (FETCH_SIZE under-reports these loads x2 on gfx950, WRITE_SIZE is 1:1: calibration in
+    profiles/README.md), divided by its instances x 20 env-steps.  clock = GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration (its timestamps in
+    the counter file).  Returns (bytes per env-step, note, valu dict or None) or (None, reason, None)."""
+    import csv, glob, shutil, subprocess, tempfile
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if exe is None:
-        return None, 'rocprofv3 not found'
+        return None, 'rocprofv3 not found', None
     tmp = tempfile.mkdtemp(prefix='mbx_pmc_')
-    got = {}
+    got, valu = {}, None
+    sq_pass = 'GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_SALU'
     try:
-        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
-            out = os.path.join(tmp, counter)
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE', sq_pass):
+            out = os.path.join(tmp, counter.split()[0])
             env = dict(os.environ, MBX_BENCH_CHILD='1', TMPDIR='/tmp')
-            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable, os.path.abspath(__file__), '--steps', '20',
+            cmd = [exe, '--pmc', *counter.split(), '--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable, os.path.abspath(__file__), '--steps', '20',
                    '--warmup', '2', '--repeats', '1', '--instances', str(instances), '--no-cpu-baseline', '--no-other-configs']
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
-            vals = []
+            rows = {}                                       # dispatch id -> {counter: value, 't0', 't1'}
             for path in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if 'k_rlepso_run' in row['Kernel_Name'] and row['Counter_Name'] == counter:
-                            vals.append(float(row['Counter_Value']))
-            if r.returncode != 0 or not vals:
-                return None, f'rocprofv3 --pmc {counter} pass failed (rc {r.returncode})'
-            got[counter] = max(vals)                      # the 20-generation launch (the other dispatch is the 2-generation warm-up)
+                        if 'k_rlepso_run' in row['Kernel_Name']:
+                            d = rows.setdefault(row['Dispatch_Id'], {})
+                            d[row['Counter_Name']] = float(row['Counter_Value'])
+                            if row.get('Start_Timestamp') and row.get('End_Timestamp'):
+                                d['t0'], d['t1'] = float(row['Start_Timestamp']), float(row['End_Timestamp'])
+            first = counter.split()[0]
+            rows = [d for d in rows.values() if first in d]
+            if r.returncode != 0 or not rows:
+                if counter is sq_pass:
+                    break                                       # the traffic figure stands without the VALU pass
+                return None, f'rocprofv3 --pmc {first} pass failed (rc {r.returncode})', None
+            big = max(rows, key=lambda d: d[first])             # the 20-generation launch (the other dispatch is the 2-generation warm-up)
+            if counter is not sq_pass:
+                got[counter] = big[counter]
+                continue
+            dur_ns = big.get('t1', 0.) - big.get('t0', 0.)
+            cyc = big['GRBM_GUI_ACTIVE'] / 8.                    # summed over the 8 XCDs
+            if dur_ns > 0 and cyc > 0 and 'SQ_ACTIVE_INST_VALU' in big:
+                f64 = sum(big.get(k, 0.) for k in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64'))
+                valu = {'bound': 'valu', 'measured_in_run': True, 'clock_ghz': cyc / dur_ns,
+                        'profiled_launch_us': dur_ns / 1e3, 'generations_in_profiled_launch': 20,
+                        'wave_instructions_per_generation': big['SQ_INSTS_VALU'] / 20.,
+                        'wave_instructions_per_env_step': big['SQ_INSTS_VALU'] / (instances * 20.),
+                        'f64_share': f64 / big['SQ_INSTS_VALU'] if big.get('SQ_INSTS_VALU') else None,
+                        'salu_per_valu': big.get('SQ_INSTS_SALU', 0.) / big['SQ_INSTS_VALU'] if big.get('SQ_INSTS_VALU') else None,
+                        'active_lanes_per_instruction': big['SQ_THREAD_CYCLES_VALU'] / big['SQ_ACTIVE_INST_VALU'] if big.get('SQ_THREAD_CYCLES_VALU') else None,
+                        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues a vector instruction; 1024 SIMDs x the launch's cycles is all there is
+                        'issue_busy_us_per_generation': big['SQ_ACTIVE_INST_VALU'] * 4. / 1024. / (cyc / dur_ns) / 1e3 / 20.,
+                        'frac': big['SQ_ACTIVE_INST_VALU'] * 4. / (1024. * cyc),
+                        'source': 'collected during this run: one rocprofv3 --pmc pass (GRBM_GUI_ACTIVE + 7 SQ counters) of the child window; clock = GRBM_GUI_ACTIVE / 8 XCDs / '
+                                  'the dispatch\'s own duration; frac = SIMD cycles issuing a VALU instruction / all SIMD cycles of the launch'}
         return (2 * got['FETCH_SIZE'] + got['WRITE_SIZE']) * 1024 / (instances * 20), \
-            f"2 x FETCH_SIZE ({got['FETCH_SIZE']:.0f} KB) + WRITE_SIZE ({got['WRITE_SIZE']:.0f} KB) of one 20-generation launch with {instances} live instances"
+            f"2 x FETCH_SIZE ({got['FETCH_SIZE']:.0f} KB) + WRITE_SIZE ({got['WRITE_SIZE']:.0f} KB) of one 20-generation launch with {instances} live instances", valu
     except Exception as e:                                # a profiler hiccup must never take the bench line down
-        return None, f'{type(e).__name__}: {e}'
+        return None, f'{type(e).__name__}: {e}', None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def policy_mfma_profile():
+    """Matrix-pipe utilisation of the policy kernels that use the matrix cores (north_star: 'MFMA utilisation on the policy GEMM'), from the newest committed
+    profile (tools/exp/mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)).  Not collected during the run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_utilisation.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d = d.get('kernels', d)
+            out = {k.replace('mbx::', ''): round(v['mfma_pipe_utilisation'], 4) for k, v in d.items()
+                   if isinstance(v, dict) and 'mfma_pipe_utilisation' in v and ('k_lstm_policy' in k or 'k_qnet_argmax' in k)}
+            if out:
+                return {'measured_in_run': False, 'source': 'profiles/' + os.path.basename(path), 'peak': 'float32 MFMA 157.3 TFLOP/s (1 instruction per 32 cycles per SIMD)',
+                        'utilisation': out,
+                        'note': 'the headline policy is the memoised actor table (no matrix work on the step path); k_qnet_argmax is config 4\'s Q-network, k_lstm_policy LDE\'s '
+                                'PolicyNet on the one-launch-per-generation route (mbx_lde_rollout evaluates it inside k_lde_run as float32 fma chains)'}
+        except (OSError, ValueError, KeyError, TypeError):
+            continue
+    return None
 
 
 def valu_roofline(live_per_gen, avg_gen_s, resident=False):
@@ -202,7 +251,7 @@ def valu_roofline(live_per_gen, avg_gen_s, resident=False):
                 'f64_share': v['wave_instructions_per_launch']['f64_add_mul_fma'] / v['wave_instructions_per_launch']['total'],
                 'issue_bound_us': [lo, hi], 'measured_us': avg_gen_s * 1e6,
                 'frac': [lo / (avg_gen_s * 1e6), hi / (avg_gen_s * 1e6)],
-                'active_lanes_per_instruction': v.get('active_lanes_per_valu_instruction'),
+                'measured_in_run': False, 'active_lanes_per_instruction': v.get('active_lanes_per_valu_instruction'),
                 'source': f'profiles/{name} (rocprofv3 --pmc passes of this command, not collected during this run) + profiles/r02_valu_issue_rates.txt'}
     except (KeyError, TypeError, ZeroDivisionError):
         return None
@@ -323,7 +372,12 @@ def other_configs(budget_s=60.0):
                               # two divisions, Lennard-Jones / Coulomb / switching terms ~24; eval_rows_protein in mbx_device.hpp) x 10^4 pairs + 300 x 12 x 3 for the
                               # displaced coordinates; peak = 1024 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz (f64 FMA issues in 4 cycles, profiles/r02_valu_issue_rates.txt)
                               'compute_roofline': {'bound': 'valu_f64', 'flops_per_env_step': 3.6e5, 'achieved': B * 3.6e5 / dt / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s',
-                                                   'frac': B * 3.6e5 / dt / 1e12 / 78.6, 'note': 'whole step, Q-network launch (mbx_ddqn_qnet) included; the kernel visits the 4950 pairs i < j (the tables are symmetric), the flop count is the nominal one of all 10^4 pairs'}})
+                                                   'frac': B * 3.6e5 / dt / 1e12 / 78.6,
+                                                   # what the kernel executes: the 4950 pairs i < j (symmetric tables) x 35 flop + 10 800 for the coordinates; of those pairs the waves whose
+                                                   # pairs all lie beyond the 9 A cut-off skip the arithmetic (~60 % of the list: eval_rows_protein), so this is an upper bound on executed work
+                                                   'executed_flops_per_env_step': 4950 * 35 + 10800,
+                                                   'achieved_executed': B * (4950 * 35 + 10800) / dt / 1e12, 'frac_executed': B * (4950 * 35 + 10800) / dt / 1e12 / 78.6,
+                                                   'note': 'whole step, Q-network launch (mbx_ddqn_qnet) included; `frac` prices the NOMINAL work of all 10^4 pairs (throughput of useful work), `frac_executed` the pairs the kernel visits (i < j; an upper bound: waves beyond the cut-off skip)'}})
             env.close()
         # ---- config 5: RLEPSO on the mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances per GPU, act + step fused
         if time.perf_counter() - t_start <= budget_s:
@@ -432,7 +486,15 @@ def main():
     if args.policy in ('resident', 'fused', 'hip') and args.graph_policy:
         raise SystemExit('--graph-policy applies to --policy torch / table')
     # fused: the actor evaluated at every reachable state, once (rebuilt whenever the weights change; they do not during a rollout)
-    fused_table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma) if args.policy in ('fused', 'resident') else None
+    fused_table, table_build_us = None, None
+    if args.policy in ('fused', 'resident'):
+        fused_table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)     # the one launch that is redone when the weights change, outside every timed window
+        e0.record()
+        fused_table = env.batch.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+        e1.record()
+        torch.cuda.synchronize()
+        table_build_us = e0.elapsed_time(e1) * 1e3
     resident = args.policy == 'resident'
 
     def policy(st):
@@ -449,6 +511,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     K, W = args.steps, args.warmup
     # Kernel timing: ONE event per `stride` generations on the launch stream; consecutive events bracket `stride` back-to-back generation
     # kernels (act + step is a single launch, nothing else runs on the stream), so every kernel of the timed region is covered and an event
@@ -588,6 +652,14 @@ def main():
     kern_ms = span_ms / span_kernels * K                # generation-kernel time of K timed generations, averaged over every bracketed kernel of every repeat
     n_launch_all = len(launches)
 
+    # per-rank diagnostics for the multi-GPU line: who ran where, how long each rank's median window took, how many env-steps it carried
+    diag = torch.tensor([float(rank), float(torch.cuda.current_device()), windows[med][0] / K * 1e3, float(windows[med][1]), kern_ms / K * 1e3], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        gathered = [torch.zeros_like(diag) for _ in range(world)]
+        dist.all_gather(gathered, diag)
+        diag_rows = [g.cpu().tolist() for g in gathered]
+    else:
+        diag_rows = [diag.cpu().tolist()]
     tot = torch.tensor([kern_ms, float(sum(w[1] for w in windows))], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -608,9 +680,9 @@ def main():
         bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         traffic, traffic_src = pmc_traffic_per_launch(live_per_launch, resident)
-        traffic_in_run, traffic_note = False, None
+        traffic_in_run, traffic_note, valu_in_run = False, None, None
         if resident and world == 1 and not args.no_pmc and not os.environ.get('MBX_BENCH_CHILD'):
-            per_step, traffic_note = pmc_traffic_in_run(B)
+            per_step, traffic_note, valu_in_run = pmc_traffic_in_run(B)
             if per_step is not None:
                 traffic, traffic_in_run = per_step * live_per_launch, True
         first_gen = W % EPISODE_GENS + 1
@@ -620,9 +692,13 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             # the K-generation window measured `repeats` times (see timed_window); value / ms_per_step are the median repeat's, spread = (max - min) / median
             # of the repeats' wall times, timed_region_s = the sum of all timed brackets
+            'backend': (dist.get_backend() if dist is not None else None),
+            'ranks_seen': [{'rank': int(r[0]), 'device': int(r[1])} for r in diag_rows],
+            'per_rank': {'ms_per_step': [r[2] for r in diag_rows], 'live_env_steps': [r[3] for r in diag_rows], 'kernel_us_per_generation': [r[4] for r in diag_rows]},
             'repeats': repeats, 'spread': float((times.max() - times.min()) / np.median(times)) if repeats > 1 else 0.0,
             'timed_region_s': float(times.sum()),
-            'repeat_ms_per_step': {'min': float(times.min() / K * 1e3), 'median': float(np.median(times) / K * 1e3), 'max': float(times.max() / K * 1e3)},
+            'repeat_ms_per_step': {'min': float(times.min() / K * 1e3), 'median': float(np.median(times) / K * 1e3), 'max': float(times.max() / K * 1e3),
+                                   'slowest_repeat': int(times.argmax()), 'max_without_first': float(times[1:].max() / K * 1e3) if repeats > 1 else None},
             'config': {'workload': f'RLEPSO_Agent + RLEPSO_Optimizer, bbob dim=10 pop=100, {B} lock-step instances per GPU '
                                    f'({fn_desc} round-robin x seeds), maxFEs=20000 (199 generations/episode), '
                                    f'{stop_desc}, policy = exported bbob_easy RLEPSO weights sampled on device',
@@ -640,6 +716,7 @@ def main():
                                          f'minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)') if resident else
                                         (f'one HIP event every {stride} generations on the launch stream; consecutive events bracket {stride} back-to-back '
                                          f'generation kernels (all of them are covered), minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)'),
+                       'policy_table_build_us': table_build_us,
                        'timed_window': f'{K} consecutive lock-step generations starting at generation {first_gen} of an episode of {EPISODE_GENS} '
                                        f'(episodes restart with mbx_reset inside the window when it is longer)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -653,7 +730,11 @@ def main():
                          'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
                          'env_steps_per_launch': live_per_launch, 'generations_per_launch': gens_per_launch,
                          'avg_generation_us': avg_gen_s * 1e6, 'live_instances_per_generation': live_per_gen,
-                         'valu': valu_roofline(live_per_gen, avg_gen_s, resident)},
+                         # the kernel is bound by vector-instruction issue, not by HBM: `valu` is the fraction of SIMD cycles that issue a VALU
+                         # instruction at the clock the chip really sustained (measured in this run when rocprofv3 is there; else priced from the committed profile)
+                         'binding': 'valu',
+                         'valu': valu_in_run or valu_roofline(live_per_gen, avg_gen_s, resident),
+                         'policy_mfma': policy_mfma_profile()},
         }
         if world == 1 and not args.no_other_configs:
             try:

@@ -59,10 +59,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r['avg_generation_us'] * r['generations_per_launch'] - r['avg_kernel_us']) <= 1e-6 * r['avg_kernel_us']
     assert 'generation' in d['config']['timed_window'] and 'event pair' in d['config']['kernel_timing']
     v = r['valu']
-    assert v is None or (v['bound'] == 'valu' and 0 < v['frac'][0] <= v['frac'][1] and v['wave_instructions_per_generation'] > 1e6)
+    assert r['binding'] == 'valu'
+    if v is not None and v.get('measured_in_run'):      # collected during the run: a point value at the measured clock
+        assert v['bound'] == 'valu' and 0.2 < v['frac'] < 1.0 and 1.2 < v['clock_ghz'] < 2.6 and v['wave_instructions_per_generation'] > 1e6
+        assert 5e3 < v['wave_instructions_per_env_step'] < 5e4 and 30 < v['active_lanes_per_instruction'] <= 64
+    else:
+        assert v is None or (v['bound'] == 'valu' and 0 < v['frac'][0] <= v['frac'][1] and v['wave_instructions_per_generation'] > 1e6)
+    pm = r['policy_mfma']
+    assert pm is None or (pm['measured_in_run'] is False and all(0 < u < 1 for u in pm['utilisation'].values()))
+    assert d['config']['policy_table_build_us'] > 0
+    assert d['backend'] is None and d['ranks_seen'] == [{'rank': 0, 'device': 0}] and len(d['per_rank']['ms_per_step']) == 1
     oc = d['other_configs']
     assert isinstance(oc, list) and len(oc) == 4, oc
     assert [e['config'].split(':')[0] for e in oc] == ['config 3', 'config 3', 'config 4', 'config 5']
+    c4 = oc[2]['compute_roofline']
+    assert 0 < c4['frac_executed'] < c4['frac'] < 1 and c4['executed_flops_per_env_step'] == 4950 * 35 + 10800
+    assert all(e['launch_info']['kernel'].startswith('k_lde_run') and e['launch_info']['resident'] for e in oc[:2])
     for e in oc:
         assert e['ms_per_step'] > 0 and abs(e['env_steps_per_s'] - e['instances'] / (e['ms_per_step'] * 1e-3)) <= 1e-6 * e['env_steps_per_s']
         assert 0 < e['roofline_frac'] < 1
@@ -102,3 +114,13 @@ def test_bench_under_torchrun_two_ranks_one_device():
     assert d['config']['parallelism'] == 'instances sharded x2' and d['config']['instances_per_gpu'] == 4096
     assert 12 * 4096 < d['config']['live_env_steps'] <= 2 * 12 * 4096          # both ranks' instances are in the aggregate
     assert 'other_configs' not in d and 'cpu_baseline' not in d                 # side legs only at N = 1
+    # the multi-rank line diagnoses itself: backend, which rank ran on which device, every rank's own window time and env-steps
+    assert d['backend'] == 'gloo' and sorted(r['rank'] for r in d['ranks_seen']) == [0, 1] and all(r['device'] == 0 for r in d['ranks_seen'])
+    pr = d['per_rank']
+    assert len(pr['ms_per_step']) == len(pr['live_env_steps']) == len(pr['kernel_us_per_generation']) == 2
+    assert abs(sum(pr['live_env_steps']) - d['config']['live_env_steps']) <= 1e-6 * d['config']['live_env_steps']
+    assert max(pr['ms_per_step']) <= d['ms_per_step'] * 1.0001 and min(pr['ms_per_step']) > 0
+    # a launch whose world size is not --gpus refuses to run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-other-configs', '--no-pmc'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
