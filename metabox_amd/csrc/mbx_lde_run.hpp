@@ -142,11 +142,13 @@ void k_lde_run(LdeRunArgs args_)
     static_assert(D > 16 && D <= 32, "two 16-column tiles");
     const LdeRunLds L = lde_run_carve(smem, NP, D, H);
     int b, gen0, episode, n_gens;
+    uint32_t seed_lo, seed_hi;
     {
         LdeRunCArgs& ar = lde_run_args();
         const int tid = threadIdx.x;
         b = __builtin_amdgcn_readfirstlane(ar.bp.order[blockIdx.x]);
         n_gens = ar.n_gens;
+        { const uint64_t sd = ar.bp.seeds[b]; seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sd); seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sd >> 32)); }
         double* S = ar.bp.state + (int64_t)b * ar.bp.state_stride;
         double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
         if (sc[MBX_SC_DONE] != 0.) {                               // finished before this launch: state_out keeps the last features
@@ -209,9 +211,8 @@ void k_lde_run(LdeRunArgs args_)
         const int kind = P.kind;
 #endif
         const double lb = P.lb, ub = P.ub, bias = P.bias;
-        const uint64_t seed = ar.bp.seeds[b];
         const int gen = gen0 + it + 1;
-        const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)gen, (uint32_t)episode, true};
+        const Rng rng{seed_lo, seed_hi, (uint32_t)gen, (uint32_t)episode, true};
         const double fes = L.SCAL[LR_FES];
         int* RKa = (it & 1) ? L.RK1 : L.RK0;                        // RANK of the current order; the other array takes the next one
         int* RKb = (it & 1) ? L.RK0 : L.RK1;
