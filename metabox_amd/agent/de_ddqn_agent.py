@@ -114,11 +114,17 @@ class DE_DDQN_Agent(Basic_Agent):
         return {'cost': env.optimizer.cost, 'fes': env.optimizer.fes, 'return': total}
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, graph=False, policy='hip'):
+    def rollout_batch(self, env, max_steps=None, graph=False, policy=None):
         """Lock-step rollout: greedy action of the Q-network for the whole batch, then the fused DE-DDQN step kernel.
         policy = 'hip' (default): the Q-network + argmax as ONE launch on the float32 matrix cores (``mbx_ddqn_qnet``, reads the batch's own
         state tensor); 'torch': the PyTorch module (5 small GEMMs + element-wise launches; also what any non-reference architecture uses).
-        ``graph=True`` captures the PyTorch forward once into a hipGraph and replays it every step (round 2: not faster than eager)."""
+        ``graph=True`` captures the PyTorch forward once into a hipGraph and replays it every step (round 2: not faster than eager).
+        Default: ``config.ddqn_policy`` (--ddqn_policy, 'hip').  The two routes evaluate the same float32 network with different summation orders (one
+        fma chain per unit in ascending k on the matrix cores / torch's tiled GEMMs), so Q values agree to ~1e-6 and the greedy action can differ where
+        two Q values are that close: trajectories are route-dependent (both valid); tests/test_ddqn.py bounds the disagreement.  'torch' reproduces
+        results obtained before round 3."""
+        if policy is None:
+            policy = getattr(self.__config, 'ddqn_policy', 'hip')
         if max_steps is None:
             bc = env.batch.cfg
             max_steps = bc.max_fes - bc.np                # one evaluation per step
@@ -184,6 +190,7 @@ class DE_DDQN_Agent(Basic_Agent):
         the target network, refreshed every update_target_steps updates) follow -- the reference's loop (de_ddqn_agent.py:70-106)
         with a batch axis.  By construction the data : update ratio is B times the reference's.  Gradients are averaged across ranks.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'})."""
+        self._mbx_replicated = True                        # gradients are averaged over ranks (the replay buffers are per-rank working state, not checkpointed separately)
         from ..distributed import all_ranks_any
         cfg, dev = self.__config, env.batch.device
         net, tgt = self.__pred_func, self.__target_func

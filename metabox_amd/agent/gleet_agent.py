@@ -293,6 +293,7 @@ class GLEET_Agent(Basic_Agent):
         averaged across ranks when torch.distributed is initialised.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'}) with per-batch means."""
         from ..distributed import all_ranks_any, average_gradients
+        self._mbx_replicated = True                        # gradient-synchronised over ranks: rank 0 writes the checkpoints (agent/utils.save_class)
         c = self.__config
         actor, critic = self.actor, self.critic
         params = list(actor.parameters()) + list(critic.parameters())

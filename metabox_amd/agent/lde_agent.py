@@ -245,6 +245,7 @@ class LDE_Agent(Basic_Agent):
         (log-probability of action + 1e-8, discounted returns, back-propagation through the collection-phase LSTM steps) is the one
         tests/test_training_parity.py pins against the reference for train_episode."""
         from ..distributed import all_ranks_any, average_gradients
+        self._mbx_replicated = True                        # gradient-synchronised over ranks: rank 0 writes the checkpoints (agent/utils.save_class)
         c = self.__config
         dev = env.batch.device
         state = env.reset().to(torch.float32).clone()

@@ -309,6 +309,7 @@ class RLEPSO_Agent(Basic_Agent):
                  BatchedPBO_Env on the GPU and no actions are forced, else 'step'.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps', 'last_losses'})."""
         from ..distributed import all_ranks_any, average_gradients
+        self._mbx_replicated = True                        # gradient-synchronised over ranks: rank 0 writes the checkpoints (agent/utils.save_class)
         config = self.__config
         gamma, n_step, K_epochs, eps_clip = config.gamma, config.n_step, config.K_epochs, config.eps_clip
         actor, critic = self.__actor, self.__critic

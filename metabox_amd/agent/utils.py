@@ -43,12 +43,16 @@ class ReplayBuffer:
 
 def save_class(dir, file_name, saving_class):
     """Pickle `saving_class` to ``<dir><file_name>.pkl`` (dir is used as a string prefix, like the reference does).
-    Multi-rank training keeps every rank's policy identical and in lock step (distributed.average_gradients / all_ranks_any), so all
-    ranks reach a checkpoint threshold at the same optimizer step: only rank 0 writes, and it writes to a temporary file that is renamed
-    over the target, so a reader never sees a half-written pickle."""
+    With torch.distributed initialised: an agent whose training is data-parallel and gradient-synchronised (its ``train_batch`` sets
+    ``_mbx_replicated``: every rank holds the same parameters and reaches a checkpoint threshold at the same optimizer step) is written by rank 0
+    only; any other object (per-rank state: a tabular Q-function, a replay buffer, a train_episode loop that runs under a process group) is
+    written by EVERY rank, ranks > 0 under ``<file_name>.rank<r>.pkl``, so nothing is dropped silently.  Writes go to a temporary file that is
+    renamed over the target: a reader never sees a half-written pickle."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
-        return
+        if getattr(saving_class, '_mbx_replicated', False):
+            return
+        file_name = f'{file_name}.rank{dist.get_rank()}'
     pathlib.Path(dir).mkdir(parents=True, exist_ok=True)
     target = f'{dir}{file_name}.pkl'
     tmp = f'{target}.tmp{os.getpid()}'

@@ -2,7 +2,7 @@
 
 Every option name, type and default of MetaBox's ``get_config`` is kept so existing command lines keep working; the
 derived fields (maxFEs, n_logpoint, log_interval, save_interval, run-stamped directories, the two comparison baselines
-that are always appended) follow the same rules.  Engine-specific additions: --n_instances, --test_runs,
+that are always appended) follow the same rules.  Engine-specific additions: --n_instances, --ddqn_policy, --test_runs,
 --rollout_runs, --fixed_horizon.
 """
 import argparse
@@ -54,6 +54,7 @@ _FLAGS = [
     ('scratch_rollout', dict(type=str)),
     # batch engine
     ('n_instances', dict(type=int, default=0)),      # cap on instances per kernel launch (0: the whole problem x run table)
+    ('ddqn_policy', dict(type=str, default='hip', choices=['hip', 'torch'])),   # DE-DDQN rollouts: Q-network + argmax as one MFMA launch (mbx_ddqn_qnet) or the PyTorch module
     ('test_runs', dict(type=int, default=51)),       # tester.py:196
     ('rollout_runs', dict(type=int, default=5)),     # tester.py:321
 ]

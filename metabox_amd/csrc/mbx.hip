@@ -447,28 +447,31 @@ extern "C" int64_t mbx_tape_stride(const mbx_algo_cfg* c)
 }
 
 // Longest-processing-time-first launch order: workgroups of the expensive objectives are dispatched first so that they do not form the
-// tail of the launch (per-kind weights = measured us per 4096-instance generation).
+// tail of the launch.
 static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
 {
     const mbx_suite* s = b->suite;
     const int n_instances = b->B;
     auto weight = [&](int pi) -> int {
         const int k = s->h_problems[pi].kind;
+        // per-kind weights = ns per instance-generation x 10 of the resident RLEPSO kernel, tools/kbench_costs.py at the round-4 head (the table
+        // metabox_amd/distributed.py: COST_NS holds for the inter-rank partition): D = 40 / NP = 128 for the large dimensions, D = 10 / NP = 100 otherwise
         if (s->dim >= 16 && k != MBX_KIND_PROTEIN) {
-            // large dimensions (tools/exp/kind_costs.py: RLEPSO D = 40, NP = 128, us per generation of 4096 instances of that function, round 3): the
-            // matvecs and the peak search weigh more than at D = 10, Gallagher-21 moves up to second place
             switch (k) {
-            case 21: return 1314; case 22: return 1049; case 16: return 1024; case 15: return 1008; case 17: case 18: return 988; case 3: return 928;
-            case 23: return 902; case 4: return 880; case 7: return 843; case 12: return 829; case 2: case 10: case 11: return 803; case 24: return 776;
-            case 14: return 754; case 19: return 735; case 20: return 715; case 6: return 707; case 5: return 625; default: return 694;
+            case 21: return 3094; case 22: return 2433; case 16: return 2414; case 15: return 2377; case 17: return 2348; case 18: return 2340;
+            case 3: return 2187; case 23: return 2116; case 4: return 2048; case 2: return 1964; case 12: return 1926; case 7: return 1889;
+            case 11: return 1868; case 10: return 1862; case 24: return 1803; case 14: return 1730; case 19: return 1718; case 1: return 1706;
+            case 20: return 1636; case 6: return 1614; case 8: return 1593; case 9: return 1591; case 13: return 1572; case 5: return 1416;
+            default: return 1700;
             }
         }
         switch (k) {
-        case MBX_KIND_PROTEIN: return 3000;
-        // (round 3, profiles/r03b_phase_cycles_per_function.jsonl: one-generation kernel, us per generation of 4096 instances of that function)
-        case 21: return 189; case 3: case 16: return 163; case 15: return 160; case 17: case 18: return 159; case 23: return 157;
-        case 2: return 150; case 4: return 146; case 22: return 140; case 10: case 11: return 137; case 12: return 136; case 7: return 135;
-        case 1: return 133; case 14: case 20: return 130; case 19: case 6: case 24: return 128; case 5: return 114; default: return 121;
+        case MBX_KIND_PROTEIN: return 30000;
+        case 21: return 399; case 3: return 365; case 16: return 343; case 15: return 338; case 17: return 331; case 4: return 330;
+        case 18: return 328; case 23: return 323; case 2: return 314; case 11: return 293; case 10: return 290; case 12: return 286;
+        case 7: return 285; case 22: return 282; case 6: return 276; case 1: return 271; case 14: return 269; case 19: case 20: return 265;
+        case 5: case 24: return 260; case 8: return 256; case 9: return 251; case 13: return 245;
+        default: return 270;
         }
     };
     b->lde_run_kinds_ok = true;

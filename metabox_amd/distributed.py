@@ -27,23 +27,24 @@ def instance_table(n_problems, runs, sort_by_problem=True):
 
 
 # ns per instance-generation of the RLEPSO generation kernel by BBOB function kind (1..24), measured on one MI355X with tools/kbench_costs.py
-# (a batch that holds one kind only, fixed horizon, resident rollout): D = 10 / NP = 100 and D = 40 / NP = 128.  Only the RATIOS matter: they
-# weight the inter-rank partition below.  Noisy functions cost what their base kind costs (the noise is O(NP) per generation).
+# (a batch that holds one kind only, fixed horizon, resident rollout; re-measured at the round-4 head: gpurun_out/costs.json) at D = 10 / NP = 100, D = 30 / NP = 100 and
+# D = 40 / NP = 128.  Only the RATIOS matter: they weight the inter-rank partition below and -- the same numbers, rounded -- the launch order inside a batch
+# (upload_launch_order in csrc/mbx.hip).  Noisy functions cost what their base kind costs (the noise is O(NP) per generation).
 COST_NS = {
-    10: {1: 30.6, 2: 36.6, 3: 41.9, 4: 38.0, 5: 27.5, 6: 31.6, 7: 33.1, 8: 29.9, 9: 29.7, 10: 36.5, 11: 36.5, 12: 33.5, 13: 29.8, 14: 32.3,
-         15: 42.1, 16: 51.2, 17: 50.0, 18: 50.0, 19: 32.5, 20: 32.8, 21: 48.0, 22: 35.5, 23: 39.8, 24: 32.9},
-    40: {1: 193., 2: 215., 3: 240., 4: 225., 5: 165., 6: 250., 7: 255., 8: 195., 9: 230., 10: 250., 11: 250., 12: 240., 13: 235., 14: 240.,
-         15: 299., 16: 402., 17: 330., 18: 330., 19: 245., 20: 215., 21: 525., 22: 513., 23: 330., 24: 260.},
+    10: {1: 27.07, 2: 31.38, 3: 36.52, 4: 32.96, 5: 26.02, 6: 27.64, 7: 28.51, 8: 25.59, 9: 25.12, 10: 28.97, 11: 29.27, 12: 28.57, 13: 24.49, 14: 26.87, 15: 33.82, 16: 34.26, 17: 33.08, 18: 32.85, 19: 26.5, 20: 26.54, 21: 39.9, 22: 28.19, 23: 32.28, 24: 26.03},
+    30: {1: 84.86, 2: 100.99, 3: 112.79, 4: 102.7, 5: 73.29, 6: 81.22, 7: 90.62, 8: 78.32, 9: 78.39, 10: 91.78, 11: 91.66, 12: 93.63, 13: 76.91, 14: 84.95, 15: 112.8, 16: 118.18, 17: 113.17, 18: 113.63, 19: 83.24, 20: 80.5, 21: 144.75, 22: 97.63, 23: 104.35, 24: 86.63},
+    40: {1: 170.55, 2: 196.38, 3: 218.71, 4: 204.83, 5: 141.62, 6: 161.38, 7: 188.86, 8: 159.29, 9: 159.13, 10: 186.16, 11: 186.83, 12: 192.59, 13: 157.15, 14: 173.03, 15: 237.71, 16: 241.36, 17: 234.78, 18: 233.98, 19: 171.84, 20: 163.6, 21: 309.43, 22: 243.34, 23: 211.59, 24: 180.31},
 }
 
 
 def relative_cost(problem):
     """Predicted cost of one generation of one instance of `problem`, in the units of COST_NS (the table of the nearer dimension; problems without a
-    BBOB kind -- protein docking -- all cost the same)."""
+    BBOB kind -- protein docking -- all cost the same; the table of the nearest measured dimension: 10 / 30 / 40)."""
     kind = getattr(problem, 'kind', None)
     if kind is None:
         return 1.0
-    table = COST_NS[10] if getattr(problem, 'dim', 10) <= 20 else COST_NS[40]
+    dim = getattr(problem, 'dim', 10)
+    table = COST_NS[10] if dim <= 20 else (COST_NS[30] if dim <= 35 else COST_NS[40])
     return float(table.get(int(kind), np.mean(list(table.values()))))
 
 

@@ -166,7 +166,7 @@ def test_cost_partition_balances_config5_and_keeps_global_order():
         per = np.array([cost[b[r]:b[r + 1]].sum() for r in range(world)])
         assert per.max() / per.mean() <= 1.001, (world, per.max() / per.mean())
     eq = np.array([cost[slice(*shard_range(len(pidx), r, 8))].sum() for r in range(8)])
-    assert eq.max() / eq.mean() > 1.25                               # what the equal-count split did
+    assert eq.max() / eq.mean() > 1.15                               # what the equal-count split did (1.23 with the round-4 cost table, 1.7 with round 3's)
     # degenerate inputs: fewer instances than ranks (empty shards are legal), zero ranks' worth of cost, a single rank
     assert list(cost_partition([1., 1.], 4)) in ([0, 0, 1, 1, 2], [0, 1, 1, 2, 2], [0, 0, 1, 2, 2], [0, 1, 1, 1, 2])
     assert list(cost_partition([], 3)) == [0, 0, 0, 0] and list(cost_partition([3., 1.], 1)) == [0, 2]
@@ -251,3 +251,33 @@ def test_train_batched_shards_by_predicted_cost(monkeypatch, tmp_path):
     per = np.array([cost[seen[r][0]].sum() for r in range(world)])
     eq = np.array([cost[pidx[slice(*shard_range(len(pidx), r, world))]].sum() for r in range(world)])
     assert per.max() / per.mean() < 1.05 < eq.max() / eq.mean()
+
+
+def _save_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from metabox_amd.agent.utils import save_class
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    import types
+    save_class(out_dir, 'replicated', {'rank': rank})             # a plain object: per-rank state
+    save_class(out_dir, 'agent', types.SimpleNamespace(_mbx_replicated=True, payload=1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_save_class_writes_replicated_agents_once_and_per_rank_state_per_rank(tmp_path):
+    """save_class used to return silently on every rank != 0 whenever a process group was up.  Now only objects that declare themselves
+    replicated (the gradient-synchronised train_batch paths set `_mbx_replicated`) are left to rank 0; anything else is written by every rank."""
+    ctx = mp.get_context('spawn')
+    port = 37500 + os.getpid() % 2000
+    out_dir = str(tmp_path) + '/'
+    procs = [ctx.Process(target=_save_worker, args=(r, 2, port, out_dir)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    names = sorted(os.listdir(out_dir))
+    assert names == ['agent.pkl', 'replicated.pkl', 'replicated.rank1.pkl'], names
