@@ -339,9 +339,9 @@ def other_configs(budget_s=60.0):
             def run(n, env=env, net=net, hh=hh, cc=cc):
                 env.batch.lde_rollout(net.packed_weights(), net.lstm.hidden_size, hh, cc, n)     # n generations in ONE launch (k_lde_run), PolicyNet inside the kernel
             run(3)
-            dt = sorted(_bracket(run, 20) for _ in range(3))[1]      # launches of 20 generations like the headline window; median of 3
+            dt = sorted(_bracket(run, 50) for _ in range(3))[1]      # launches of 50 generations (the default of rollout_batch; an episode is 1199 / 599 generations); median of 3
             D = 30
-            entry(f'config 3: LDE bbob-noisy d=30 pop={np_lde}, 16384 instances (one GPU), LSTM policy included, mbx_lde_rollout (20 generations per launch, median of 3 launches)', B, dt,
+            entry(f'config 3: LDE bbob-noisy d=30 pop={np_lde}, 16384 instances (one GPU), LSTM policy included, mbx_lde_rollout (50 generations per launch, median of 3 launches)', B, dt,
                   (2 * np_lde * D + 2 * np_lde) * 8 + 4 * 2 * np_lde + 8 * (np_lde + 10) + (D * D + D + 2) * 8,
                   {'launch_info': {'kernel': f'k_lde_run<{np_lde}, 30>', 'threads': 64 * ((np_lde + 15) // 16), 'resident': bool(resident3),
                                    'step_kernel': env.batch.launch_info()}, 'policy': agent.policy_route('resident' if resident3 else 'hip')})

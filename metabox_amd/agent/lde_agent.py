@@ -147,7 +147,7 @@ class LDE_Agent(Basic_Agent):
                 'torch': 'PyTorch-ROCm: one LSTM cell + two linear heads over [B, NP + 10] per generation (rocBLAS / hipBLASLt GEMMs)'}[policy]
 
     @torch.no_grad()
-    def rollout_batch(self, env, max_steps=None, policy='resident', gens_per_launch=25):
+    def rollout_batch(self, env, max_steps=None, policy='resident', gens_per_launch=50):
         """Whole episodes of a lock-step batch.  'resident' (default): ``mbx_lde_rollout`` -- up to `gens_per_launch` generations of PolicyNet.sampler +
         env.step per launch, population / fitness order / features / (h, c) on chip in between (k_lde_run; batches whose geometry or objective kinds
         that kernel does not build are stepped per generation behind the same call); 'hip' / 'torch': one policy launch + one generation launch per

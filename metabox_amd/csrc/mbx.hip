@@ -456,6 +456,14 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
         const int k = s->h_problems[pi].kind;
         // per-kind weights = ns per instance-generation x 10 of the resident RLEPSO kernel, tools/kbench_costs.py at the round-4 head (the table
         // metabox_amd/distributed.py: COST_NS holds for the inter-rank partition): D = 40 / NP = 128 for the large dimensions, D = 10 / NP = 100 otherwise
+        if (b->cfg.algo == MBX_ALGO_LDE && s->dim >= 16 && k != MBX_KIND_PROTEIN) {
+            // LDE at D = 30 (k_lde_run, pop 100; tools/exp/lde_run.py --functions, round 4): us per generation of 16 384 instances of that kind / 10.  The cost
+            // ranking differs from RLEPSO's (no FDR scan to dilute the objective: Schaffers and the Gallagher search weigh 2-2.5x Sphere).
+            switch (k) {
+            case 21: case 22: return 155; case 17: case 18: return 121; case 16: case 23: return 110; case 15: case 3: case 4: return 100; case 2: case 10: case 11: return 92;
+            case 14: case 12: return 81; case 7: return 78; case 19: case 24: case 20: return 77; case 8: case 9: case 6: return 66; default: return 62;
+            }
+        }
         if (s->dim >= 16 && k != MBX_KIND_PROTEIN) {
             switch (k) {
             case 21: return 3094; case 22: return 2433; case 16: return 2414; case 15: return 2377; case 17: return 2348; case 18: return 2340;
