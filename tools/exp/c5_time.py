@@ -19,7 +19,7 @@ B = 8192
 b = Batch(s, ALGO_RLEPSO, np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 3, 128, 80000, 1600, 50, early_stop=False)
 table = b.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
 b.reset(); b.rlepso_rollout(table, 4); torch.cuda.synchronize()
-ts = []
+ts = []; G = int(os.environ.get("C5_GENS", 20))
 for _ in range(5):
-    t0 = time.perf_counter(); b.rlepso_rollout(table, 20); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 20)
+    t0 = time.perf_counter(); b.rlepso_rollout(table, G); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / G)
 print(json.dumps({'lib': os.path.basename(os.environ.get('MBX_LIB', 'libmbx.so')), 'config5_ms_per_generation': round(sorted(ts)[2] * 1e3, 4), 'all': [round(t * 1e3, 4) for t in ts]}))
