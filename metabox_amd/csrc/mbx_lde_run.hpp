@@ -116,6 +116,83 @@ __device__ __forceinline__ unsigned long long f64_sortable(double v)
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+// Gallagher: the winning peak of every row (block-wide: lane = row, wave = a subset of the peaks, scalar-operand peak tables).  Out of line on purpose: inlined, this
+// block (unrolled 4 peaks x 6 coordinates) costs every OTHER objective kind 4 % (Sphere batch at pop 100: 0.599 -> 0.574 ms with it compiled out) through the register
+// allocation and the code size of the generation body.  The LDS arrays arrive as generic pointers and are cast back to the LDS address space.
+#ifndef MBX_LDE_GALL_ATTR
+#define MBX_LDE_GALL_ATTR __noinline__          // (__forceinline__ for the A/B)
+#endif
+template <int NP, int D>
+__device__ MBX_LDE_GALL_ATTR void lde_gallagher_search(double* TB_, unsigned long long* GK_, int* GI_, ConstProblem* Pp)
+{
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    typedef __attribute__((address_space(3))) int lds_i32;
+    lds_f64* TB = (lds_f64*)TB_;
+    lds_u64* GK = (lds_u64*)GK_;
+    lds_i32* GI = (lds_i32*)GI_;
+    // function arguments arrive in VGPRs: without this the problem record, and with it the peak tables, would be read by per-lane vector loads instead of scalar ones
+    const uint64_t pu_ = (uint64_t)(uintptr_t)Pp;
+    const uint64_t pu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pu_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pu_ >> 32)) << 32);
+    ConstProblem& P = *(ConstProblem*)(uintptr_t)pu;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            for (int i = tid; i < NP; i += (int)blockDim.x) { GK[i] = 0ull; GI[i] = 0x7fffffff; }
+            __syncthreads();
+            typedef const double __attribute__((address_space(4)))* kptr;
+            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
+            const int npk = P.n_peaks, nw = __builtin_amdgcn_readfirstlane(MBX_NW);
+            const double cexp = -0.5 / D;
+            constexpr int PB = 4, GC = 6;
+            static_assert(D % GC == 0, "whole chunks only");
+            const int mine = wave < npk ? (npk - wave + nw - 1) / nw : 0;
+            double bkey[2] = {-INFINITY, -INFINITY};
+            int bk[2] = {0, 0};
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                if (64 * qq >= NP) break;
+                const int i = lane + 64 * qq;
+                const lds_f64* rx = TB + (i < NP ? i : NP - 1) * D;
+                for (int j0 = 0; j0 < mine; j0 += PB) {
+                    double acc[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) acc[j] = 0.;
+#pragma unroll 1
+                    for (int c0 = 0; c0 < D; c0 += GC) {
+                        double y[GC];
+#pragma unroll
+                        for (int k = 0; k < GC; ++k) y[k] = rx[c0 + k];
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) {
+                            if (j0 + j < mine) {
+                                const int kk = wave + (j0 + j) * nw;
+                                const kptr ry = py + (int64_t)kk * D + c0;
+                                const kptr ck = pcc + (int64_t)kk * D + c0;
+#pragma unroll
+                                for (int k = 0; k < GC; ++k) { const double zd = y[k] - ry[k]; acc[j] = __builtin_fma(ck[k], zd * zd, acc[j]); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        if (j0 + j < mine) {
+                            const int kk = wave + (j0 + j) * nw;
+                            const double key = plw[kk] + cexp * acc[j];
+                            if (key > bkey[qq]) { bkey[qq] = key; bk[qq] = kk; }
+                        }
+                    }
+                }
+                if (i < NP && mine > 0) __hip_atomic_fetch_max(&GK[i], f64_sortable(bkey[qq]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int i = lane + 64 * qq;
+                if (i < NP && mine > 0 && f64_sortable(bkey[qq]) == GK[i]) __hip_atomic_fetch_min(&GI[i], bk[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // equal keys: the lower peak index (eval_rows' rule)
+            }
+            __syncthreads();
+}
+
 // timing experiments only (never a shipped build): bit 0 no gate chains, 1 no head chains, 2 cheap hash instead of Philox in the tile phase,
 // 4 no noise in the row phase, 5 no ranking pass
 #ifndef MBX_LDE_ABL
@@ -485,65 +562,7 @@ void k_lde_run(LdeRunArgs args_)
         MBX_PHASE(2);                                              // mutation, linear maps, transforms (wave-local)
 
         // ================================================================ Gallagher: winning peak of every row (block-wide: lane = row, wave = peaks)
-        if (gall) {
-            unsigned long long* GK = (unsigned long long*)L.A1;
-            int* GI = (int*)L.A2;
-            for (int i = tid; i < NP; i += MBX_NT) { GK[i] = 0ull; GI[i] = 0x7fffffff; }
-            __syncthreads();
-            typedef const double __attribute__((address_space(4)))* kptr;
-            const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
-            const int npk = P.n_peaks, nw = __builtin_amdgcn_readfirstlane(MBX_NW);
-            const double cexp = -0.5 / D;
-            constexpr int PB = 4, GC = 6;
-            static_assert(D % GC == 0, "whole chunks only");
-            const int mine = wave < npk ? (npk - wave + nw - 1) / nw : 0;
-            double bkey[2] = {-INFINITY, -INFINITY};
-            int bk[2] = {0, 0};
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                if (64 * qq >= NP) break;
-                const int i = lane + 64 * qq;
-                const double* rx = L.TB + (i < NP ? i : NP - 1) * D;
-                for (int j0 = 0; j0 < mine; j0 += PB) {
-                    double acc[PB];
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) acc[j] = 0.;
-#pragma unroll 1
-                    for (int c0 = 0; c0 < D; c0 += GC) {
-                        double y[GC];
-#pragma unroll
-                        for (int k = 0; k < GC; ++k) y[k] = rx[c0 + k];
-#pragma unroll
-                        for (int j = 0; j < PB; ++j) {
-                            if (j0 + j < mine) {
-                                const int kk = wave + (j0 + j) * nw;
-                                const kptr ry = py + (int64_t)kk * D + c0;
-                                const kptr ck = pcc + (int64_t)kk * D + c0;
-#pragma unroll
-                                for (int k = 0; k < GC; ++k) { const double zd = y[k] - ry[k]; acc[j] = __builtin_fma(ck[k], zd * zd, acc[j]); }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        if (j0 + j < mine) {
-                            const int kk = wave + (j0 + j) * nw;
-                            const double key = plw[kk] + cexp * acc[j];
-                            if (key > bkey[qq]) { bkey[qq] = key; bk[qq] = kk; }
-                        }
-                    }
-                }
-                if (i < NP && mine > 0) atomicMax(&GK[i], f64_sortable(bkey[qq]));
-            }
-            __syncthreads();
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int i = lane + 64 * qq;
-                if (i < NP && mine > 0 && f64_sortable(bkey[qq]) == GK[i]) atomicMin(&GI[i], bk[qq]);   // equal keys: the lower peak index (eval_rows' rule)
-            }
-            __syncthreads();
-        }
-
+        if (gall) lde_gallagher_search<NP, D>(L.TB, (unsigned long long*)L.A1, (int*)L.A2, &P);
         MBX_PHASE(3);                                              // Gallagher peak search
         // ================================================================ row sums + noise -> trial costs; selection (:55-59)
         int surv_mine = 0;
