@@ -193,6 +193,148 @@ __device__ MBX_LDE_GALL_ATTR void lde_gallagher_search(double* TB_, unsigned lon
             __syncthreads();
 }
 
+// z[row][d] of a wave's 16-row tile <- sum_k M[d][k] a[row][k] on the float64 matrix cores: lane (c, q) supplies A = a[row c][4 s + q] and B = M[column tile][4 s + q], the
+// accumulator tiles (C / D layout: rows q + 4 r, coordinates c and 16 + c) go to the wave's slice TW.  The fma chain of matvec_rows_mfma (ascending k from +0).
+template <int NP, int D, class TWP>
+__device__ __forceinline__ void lde_map_tile(const double* __restrict__ M, const double (&a)[(D + 3) / 4], TWP TW, int wave, int c, int q)
+{
+    constexpr int KS = (D + 3) / 4;
+    const int c1 = 16 + c < D ? 16 + c : D - 1;                    // second column tile, clamped
+    f64x4 y0 = {0., 0., 0., 0.}, y1 = {0., 0., 0., 0.};
+    double bm0[KS], bm1[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bm0[s] = M[c * D + (4 * s + q < D ? 4 * s + q : D - 1)];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bm1[s] = M[c1 * D + (4 * s + q < D ? 4 * s + q : D - 1)];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], 4 * s + q < D ? bm0[s] : 0., y0, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], (4 * s + q < D && 16 + c < D) ? bm1[s] : 0., y1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lr = q + 4 * r;
+        if (16 * wave + lr < NP) {
+            TW[lr * D + c] = y0[r];
+            if (16 + c < D) TW[lr * D + 16 + c] = y1[r];
+        }
+    }
+}
+
+// Everything element-wise between the first linear map and the row sums (phases E1, C, E2 of eval_rows), IN PLACE in the wave's slice, one element per lane at a
+// time.  Out of line like the Gallagher search: the generation body (policy, mutation, ranking) is register-allocated without it, and the kinds that have
+// nothing element-wise never call it.
+template <int NP, int D>
+__device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, ConstProblem* Pp, int kind_)
+{
+    typedef __attribute__((address_space(3))) double lds_f64;
+    lds_f64* TW = (lds_f64*)TW_;
+    lds_f64* A2 = (lds_f64*)A2_;
+    constexpr int KS = (D + 3) / 4;
+    const uint64_t pu_ = (uint64_t)(uintptr_t)Pp;
+    const uint64_t pu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pu_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pu_ >> 32)) << 32);
+    ConstProblem& P = *(ConstProblem*)(uintptr_t)pu;
+    const int kind = __builtin_amdgcn_readfirstlane(kind_);
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool rvalid = 16 * wave + c < NP;
+    int kq[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kq[s] = 4 * s + q < D ? 4 * s + q : D - 1;
+        // element m of a lane: m = 4 ct + r -> (local row q + 4 r, coordinate 16 ct + c)
+        auto elem = [&](int m, int& lr, int& d) -> bool { lr = q + 4 * (m & 3); d = 16 * (m >> 2) + c; return 16 * wave + lr < NP && d < D; };
+        if (kind == 7 && c == 0) {                                 // F7 keeps |z_hat_0| (bbob.py: the max() of the step ellipsoid)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int lr = q + 4 * r; if (16 * wave + lr < NP) A2[16 * wave + lr] = fabs(TW[lr * D]); }
+        }
+        {                                                          // phase E1 of eval_rows
+            const double s0 = P.s[0];
+            const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
+#pragma unroll 1
+            for (int m = 0; m < 8; ++m) {
+                int lr, d;
+                if (!elem(m, lr, d)) continue;
+                lds_f64* pz = TW + lr * D + d;
+                const double z = *pz;
+                double t;
+                switch (kind) {
+                case 2: case 10: { const double o = osc1(z); t = P.v0[d] * (o * o); break; }
+                case 6: { double zi = z; if (zi * P.dshift[d] > 0.) zi *= 100.; t = zi * zi; break; }
+                case 7: t = fabs(z) > 0.5 ? floor(0.5 + z) : floor(0.5 + 10. * z) / 10.; break;
+                case 8: t = s0 * z + 1; break;
+                case 9: case 19: t = z + 0.5; break;
+                case 11: { const double o = osc1(z); t = o * o; break; }
+                case 12: case 17: case 18: t = asy1(z, P.v1[d]); break;
+                case 14: t = m_pow(fabs(z), P.v0[d]); break;
+                case 16: t = osc1(z); break;
+                case 23: {
+                    double temp = 0., p2 = 1., ip2 = 1.;
+                    for (int j = 1; j <= 32; ++j) {
+                        p2 *= 2.; ip2 *= 0.5;
+                        const double a = p2 * z;
+                        temp += fabs(a - floor(a + 0.5)) * ip2;
+                    }
+                    t = m_pow(1 + (d + 1) * temp, kats_exp);
+                    break;
+                }
+                default: t = z; break;
+                }
+                *pz = t;
+            }
+        }
+        if ((kind == 7 || kind == 12 || (kind >= 16 && kind <= 18))) {    // second linear map (F7, F16-F18: M2; F12: M1 again) of the tile just written
+            wave_lds_fence();
+            double av2[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { const double v = TW[(rvalid ? c : 0) * D + kq[s]]; av2[s] = (rvalid && 4 * s + q < D) ? v : 0.; }
+            wave_lds_fence();                                      // every lane holds its A fragment: the slice can take the product
+            lde_map_tile<NP, D>(kind == 12 ? P.m1 : P.m2, av2, TW, wave, c, q);
+            if (kind == 16) {                                      // Weierstrass series by angle tripling (eval_rows, phase E2)
+#pragma unroll 1
+                for (int m = 0; m < 8; ++m) {
+                    int lr, d;
+                    if (!elem(m, lr, d)) continue;
+                    lds_f64* pz = TW + lr * D + d;
+                    const double base = kTwoPi * (*pz + 0.5);
+                    double cc = m_cos(base), ss = m_sin(base), sum = cc, ak = 1.;
+#pragma unroll
+                    for (int k = 1; k < 12; ++k) {
+                        const double c2 = cc * cc, s2 = ss * ss;
+                        cc = cc * __builtin_fma(-3., s2, c2);
+                        ss = ss * __builtin_fma(3., c2, -s2);
+                        ak *= 0.5;
+                        sum = __builtin_fma(ak, cc, sum);
+                    }
+                    *pz = sum;
+                }
+            }
+        }
+        if ((kind == 17 || kind == 18 || kind == 19)) {              // terms of neighbouring coordinates (bbob.py:642-643, 702-703)
+            // element (row, d) needs (row, d + 1), which another lane owns and overwrites with ITS term: the wave walks m in step -- all lanes read,
+            // then all lanes write -- and in ascending m, so the one neighbour that belongs to a later step (d = 15 -> 16) is still untouched
+#pragma unroll 1
+            for (int m = 0; m < 8; ++m) {
+                int lr, d;
+                const bool ok = elem(m, lr, d) && d < D - 1;       // coordinate D - 1 has no term
+                wave_lds_fence();
+                const double a = ok ? TW[lr * D + d] : 0., nb = ok ? TW[lr * D + d + 1] : 0.;
+                wave_lds_fence();
+                if (ok) {
+                    double t;
+                    if (kind == 19) {
+                        const double aa = a * a - nb;
+                        const double bb = 1. - a;
+                        const double sq = 100. * (aa * aa) + bb * bb;
+                        t = sq / 4000. - m_cos(sq);
+                    } else {
+                        const double sq = sqrt(a * a + nb * nb);
+                        t = sqrt(sq) * (m_pow(m_sin(50 * m_pow(sq, 0.2)), 2) + 1);
+                    }
+                    TW[lr * D + d] = t;
+                }
+            }
+        }
+}
+
 // timing experiments only (never a shipped build): bit 0 no gate chains, 1 no head chains, 2 cheap hash instead of Philox in the tile phase,
 // 4 no noise in the row phase, 5 no ranking pass
 #ifndef MBX_LDE_ABL
@@ -442,122 +584,9 @@ void k_lde_run(LdeRunArgs args_)
         // The result goes straight to the wave's slice (C / D layout: lane (c, q) holds rows q + 4 r, coordinates c and 16 + c); everything
         // element-wise then happens IN PLACE there, one element per lane at a time (loops that are not unrolled: the transforms are out-of-line
         // calls, and the fewer values are alive across a call the fewer are spilled around it).
-        const int c1 = 16 + c < D ? 16 + c : D - 1;                // second column tile, clamped
-        auto map_tile = [&](const double* __restrict__ M, const double (&a)[KS]) {
-            f64x4 y0 = {0., 0., 0., 0.}, y1 = {0., 0., 0., 0.};
-            double bm0[KS], bm1[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) bm0[s] = M[c * D + kq[s]];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) bm1[s] = M[c1 * D + kq[s]];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], 4 * s + q < D ? bm0[s] : 0., y0, 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], (4 * s + q < D && 16 + c < D) ? bm1[s] : 0., y1, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = q + 4 * r;
-                if (16 * wave + lr < NP) {
-                    TW[lr * D + c] = y0[r];
-                    if (16 + c < D) TW[lr * D + 16 + c] = y1[r];
-                }
-            }
-        };
-        map_tile(P.m1, av);
+        lde_map_tile<NP, D>(P.m1, av, TW, wave, c, q);
         MBX_PHASE(8);                                              // (first linear map of wave 0)
-        // element m of a lane: m = 4 ct + r -> (local row q + 4 r, coordinate 16 ct + c)
-        auto elem = [&](int m, int& lr, int& d) -> bool { lr = q + 4 * (m & 3); d = 16 * (m >> 2) + c; return 16 * wave + lr < NP && d < D; };
-        if (kind == 7 && c == 0) {                                 // F7 keeps |z_hat_0| (bbob.py: the max() of the step ellipsoid)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const int lr = q + 4 * r; if (16 * wave + lr < NP) L.A2[16 * wave + lr] = fabs(TW[lr * D]); }
-        }
-        if (!(kind == 1 || kind == 13 || gall)) {                  // phase E1 of eval_rows
-            const double s0 = P.s[0];
-            const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
-#pragma unroll 1
-            for (int m = 0; m < 8; ++m) {
-                int lr, d;
-                if (!elem(m, lr, d)) continue;
-                double* pz = TW + lr * D + d;
-                const double z = *pz;
-                double t;
-                switch (kind) {
-                case 2: case 10: { const double o = osc1(z); t = P.v0[d] * (o * o); break; }
-                case 6: { double zi = z; if (zi * P.dshift[d] > 0.) zi *= 100.; t = zi * zi; break; }
-                case 7: t = fabs(z) > 0.5 ? floor(0.5 + z) : floor(0.5 + 10. * z) / 10.; break;
-                case 8: t = s0 * z + 1; break;
-                case 9: case 19: t = z + 0.5; break;
-                case 11: { const double o = osc1(z); t = o * o; break; }
-                case 12: case 17: case 18: t = asy1(z, P.v1[d]); break;
-                case 14: t = m_pow(fabs(z), P.v0[d]); break;
-                case 16: t = osc1(z); break;
-                case 23: {
-                    double temp = 0., p2 = 1., ip2 = 1.;
-                    for (int j = 1; j <= 32; ++j) {
-                        p2 *= 2.; ip2 *= 0.5;
-                        const double a = p2 * z;
-                        temp += fabs(a - floor(a + 0.5)) * ip2;
-                    }
-                    t = m_pow(1 + (d + 1) * temp, kats_exp);
-                    break;
-                }
-                default: t = z; break;
-                }
-                *pz = t;
-            }
-        }
-        if ((kind == 7 || kind == 12 || (kind >= 16 && kind <= 18))) {    // second linear map (F7, F16-F18: M2; F12: M1 again) of the tile just written
-            wave_lds_fence();
-            double av2[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { const double v = TW[(rvalid ? c : 0) * D + kq[s]]; av2[s] = (rvalid && 4 * s + q < D) ? v : 0.; }
-            wave_lds_fence();                                      // every lane holds its A fragment: the slice can take the product
-            map_tile(kind == 12 ? P.m1 : P.m2, av2);
-            if (kind == 16) {                                      // Weierstrass series by angle tripling (eval_rows, phase E2)
-#pragma unroll 1
-                for (int m = 0; m < 8; ++m) {
-                    int lr, d;
-                    if (!elem(m, lr, d)) continue;
-                    double* pz = TW + lr * D + d;
-                    const double base = kTwoPi * (*pz + 0.5);
-                    double cc = m_cos(base), ss = m_sin(base), sum = cc, ak = 1.;
-#pragma unroll
-                    for (int k = 1; k < 12; ++k) {
-                        const double c2 = cc * cc, s2 = ss * ss;
-                        cc = cc * __builtin_fma(-3., s2, c2);
-                        ss = ss * __builtin_fma(3., c2, -s2);
-                        ak *= 0.5;
-                        sum = __builtin_fma(ak, cc, sum);
-                    }
-                    *pz = sum;
-                }
-            }
-        }
-        if ((kind == 17 || kind == 18 || kind == 19)) {              // terms of neighbouring coordinates (bbob.py:642-643, 702-703)
-            // element (row, d) needs (row, d + 1), which another lane owns and overwrites with ITS term: the wave walks m in step -- all lanes read,
-            // then all lanes write -- and in ascending m, so the one neighbour that belongs to a later step (d = 15 -> 16) is still untouched
-#pragma unroll 1
-            for (int m = 0; m < 8; ++m) {
-                int lr, d;
-                const bool ok = elem(m, lr, d) && d < D - 1;       // coordinate D - 1 has no term
-                wave_lds_fence();
-                const double a = ok ? TW[lr * D + d] : 0., nb = ok ? TW[lr * D + d + 1] : 0.;
-                wave_lds_fence();
-                if (ok) {
-                    double t;
-                    if (kind == 19) {
-                        const double aa = a * a - nb;
-                        const double bb = 1. - a;
-                        const double sq = 100. * (aa * aa) + bb * bb;
-                        t = sq / 4000. - m_cos(sq);
-                    } else {
-                        const double sq = sqrt(a * a + nb * nb);
-                        t = sqrt(sq) * (m_pow(m_sin(50 * m_pow(sq, 0.2)), 2) + 1);
-                    }
-                    TW[lr * D + d] = t;
-                }
-            }
-        }
+        if (!(kind == 1 || kind == 13 || gall)) lde_tile_transforms<NP, D>(TW, L.A2, &P, kind);      // (Sphere-like kinds and Gallagher: nothing element-wise)
         __syncthreads();
         MBX_PHASE(2);                                              // mutation, linear maps, transforms (wave-local)
 
