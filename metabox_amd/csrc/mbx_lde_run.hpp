@@ -69,14 +69,15 @@ __host__ __device__ constexpr int lde_run_threads(int NP) { return 64 * lde_run_
 struct LdeRunLds {
     double *P, *TB, *FIT, *A1, *A2, *FEAT, *HS, *RED, *SCAL, *DSH;
     float *ACT, *HC;
-    int *RK0, *RK1, *ORDER, *HIST, *FLAG;
+    uint8_t *RK, *ORDER;         // rank of a physical row / row at a rank (NP <= 255)
+    int *ACC, *HIST, *FLAG;      // ACC: the ranking's per-row counters
 };
 
-// LDS is allocated in 1280-byte granules: 3 workgroups per CU need <= 53 760 B each (pop 100: 53 104 B), 6 need <= 26 880 B (pop 50: 26 704 B)
+// LDS is allocated in 1280-byte granules: 3 workgroups per CU need <= 53 760 B each (pop 100: 52 768 B), 6 need <= 26 880 B (pop 50: 26 864 B)
 __host__ __device__ inline int64_t lde_run_lds_doubles(int NP, int D, int H)
 {
     const int64_t NE = align2((int64_t)NP * D), P = align2(NP);
-    return 2 * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + 3 * align2((P + 1) / 2) + 4 + align2(D);
+    return 2 * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + align2((P + 1) / 2) + 2 * align2((P + 7) / 8) + 4 + align2(D);
 }
 
 __device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, int H)
@@ -92,7 +93,7 @@ __device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, 
     L.HS = p; p += 8;  L.RED = p; p += 8;  L.SCAL = p; p += 8;
     L.ACT = (float*)p; p += P;
     L.HC = (float*)p; p += align2(H);
-    L.RK0 = (int*)p; p += PI;  L.RK1 = (int*)p; p += PI;  L.ORDER = (int*)p; p += PI;
+    L.ACC = (int*)p; p += PI;  L.RK = (uint8_t*)p; p += align2((P + 7) / 8);  L.ORDER = (uint8_t*)p; p += align2((P + 7) / 8);
     L.HIST = (int*)p;            // [5] bin counts, [6] the done flag
     L.FLAG = L.HIST + 6;
     p += 4;
@@ -425,11 +426,12 @@ __device__ MBX_LDE_POL_ATTR void lde_policy_step(float* XS_, float* HC_, float* 
         __syncthreads();
 }
 
-// waves per SIMD the register allocation aims at.  pop 100: 3 workgroups x 7 waves per CU need 6 (80 VGPRs, ~30 of them spilled); with 5 (96 VGPRs) only
-// two workgroups fit -- measured on one box, Sphere batch: 0.632 (6) / 0.592 (5) / 0.612 (4) ms per generation, all 30 functions 0.856 (6) against 0.87-0.95 (5):
-// the third workgroup pays on the expensive objectives.  pop 50: 5 workgroups x 4 waves = 5 per SIMD either way, so it takes the 96 registers (0.335 -> 0.286 ms on Sphere).
+// waves per SIMD the register allocation aims at: 6 (80 VGPRs) -- pop 100: 3 workgroups x 7 waves per CU; pop 50: 6 workgroups x 4 waves (26 880 B of LDS each, the
+// rank tables as bytes).  History (one box each): with the first versions' ~30 spilled registers 96 VGPRs / five workgroups was the faster pop-50 build (0.335 -> 0.286 ms
+// on Sphere); with the transforms, the policy and the Gallagher search out of line the 80-register build spills 13 (pop 100) / a handful (pop 50) and the sixth
+// workgroup wins: 0.408 -> 0.401 ms on all 30 functions.
 #ifndef MBX_LDE_RUN_WAVES
-#define MBX_LDE_RUN_WAVES(NP) ((NP) <= 64 ? 5 : 6)
+#define MBX_LDE_RUN_WAVES(NP) 6
 #endif
 
 // loop-carried scalars of the instance, in LDS (thread 0 updates them at the end of a generation, every thread reads what it needs at the top of the next)
@@ -474,7 +476,7 @@ void k_lde_run(LdeRunArgs args_)
         for (int i = tid; i < NP; i += MBX_NT) {
             const double f = S[MBX_LDE_ST_FIT(NP, D) + i];
             L.FIT[i] = f; L.A1[i] = f;                             // sorted in HBM: SORTED == FIT
-            L.RK0[i] = i; L.ORDER[i] = i;
+            L.RK[i] = (uint8_t)i; L.ORDER[i] = (uint8_t)i;
         }
         if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
         {
@@ -518,8 +520,8 @@ void k_lde_run(LdeRunArgs args_)
         const int gen = gen0 + it + 1;
         const Rng rng{seed_lo, seed_hi, (uint32_t)gen, (uint32_t)episode, true};
         const double fes = L.SCAL[LR_FES];
-        int* RKa = (it & 1) ? L.RK1 : L.RK0;                        // RANK of the current order; the other array takes the next one
-        int* RKb = (it & 1) ? L.RK0 : L.RK1;
+        const uint8_t* RKa = L.RK;                                 // rank of every physical row in the current fitness order
+        int* RKb = L.ACC;                                          // accumulator of the next ranking
         // ================================================================ policy: LSTM cell + heads + sampling (lde_agent.py:8-29), out of line (lde_policy_step)
         lde_policy_step<NP, H, 64 * TILES>((float*)L.TB, L.HC, L.ACT, ar.net.w, seed_lo, seed_hi, (uint32_t)gen, (uint32_t)episode,
                                            ar.out.traj_actions ? ar.out.traj_actions + ((int64_t)it * ar.bp.B + b) * A : nullptr);
@@ -724,7 +726,7 @@ void k_lde_run(LdeRunArgs args_)
             if (tid < MBX_LDE_BINS) L.HS[tid] += (double)my_hist;
         }
         __syncthreads();
-        if (tid < NP) { const int r = (MBX_LDE_ABL & 32) ? RKa[tid] : RKb[tid]; if (MBX_LDE_ABL & 32) RKb[tid] = r; L.ORDER[r] = tid; L.A1[r] = L.FIT[tid]; }
+        if (tid < NP) { const int r = (MBX_LDE_ABL & 32) ? RKa[tid] : RKb[tid]; L.RK[tid] = (uint8_t)r; L.ORDER[r] = (uint8_t)tid; L.A1[r] = L.FIT[tid]; }
         __syncthreads();
         MBX_PHASE(5);                                              // survivors, ranking, order
         // ---- features of the new state (:145-157) and the bookkeeping of update() (:170-198)
@@ -772,7 +774,7 @@ void k_lde_run(LdeRunArgs args_)
         const int tid = threadIdx.x;
         double* S = ar.bp.state + (int64_t)b * ar.bp.state_stride;
         double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
-        const int* RK = (executed & 1) ? L.RK1 : L.RK0;
+        const uint8_t* RK = L.RK;
         double* gPop = S + MBX_LDE_ST_POP(NP, D);
         const FastDiv fd(D);
         for (int e = tid; e < NE; e += MBX_NT) { const int j = fd.div(e), d = e - j * D; gPop[RK[j] * D + d] = L.P[e]; }
