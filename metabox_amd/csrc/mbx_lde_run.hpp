@@ -73,7 +73,7 @@ struct LdeRunLds {
     int *ACC, *HIST, *FLAG;      // ACC: the ranking's per-row counters
 };
 
-// LDS is allocated in 1280-byte granules: 3 workgroups per CU need <= 53 760 B each (pop 100: 52 768 B), 6 need <= 26 880 B (pop 50: 26 864 B)
+// LDS is allocated in 1280-byte granules: 3 workgroups per CU need <= 53 760 B each (pop 100: 52 768 B), 6 need <= 26 880 B (pop 50: 26 880 B)
 __host__ __device__ inline int64_t lde_run_lds_doubles(int NP, int D, int H)
 {
     const int64_t NE = align2((int64_t)NP * D), P = align2(NP);
@@ -117,11 +117,6 @@ __device__ __forceinline__ unsigned long long f64_sortable(double v)
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// timing experiments only (never a shipped build): bit 0 no gate chains, 1 no head chains, 2 cheap hash instead of Philox in the tile phase,
-// 4 no noise in the row phase, 5 no ranking pass
-#ifndef MBX_LDE_ABL
-#define MBX_LDE_ABL 0
-#endif
 // Gallagher: the winning peak of every row (block-wide: lane = row, wave = a subset of the peaks, scalar-operand peak tables).  Out of line on purpose: inlined, this
 // block (unrolled 4 peaks x 6 coordinates) costs every OTHER objective kind 4 % (Sphere batch at pop 100: 0.599 -> 0.574 ms with it compiled out) through the register
 // allocation and the code size of the generation body.  The LDS arrays arrive as generic pointers and are cast back to the LDS address space.
@@ -341,95 +336,14 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
         }
 }
 
-// LDE's PolicyNet for ONE instance (lde_agent.py:8-29, 147-163): LSTM cell NP + 10 -> H, mu / sigma heads H -> 2 NP, Normal sample, clip -- the arithmetic of
-// k_lstm_policy, one float32 fma chain per unit in ascending k from the bias.  XS: [x | h] as float32 (staged by the caller), then scratch for the gate
-// pre-activations and the sigma head; HC: h | c, updated in place; ACT: the sampled action.  All threads of the workgroup call; ends with a barrier.
-// Out of line (register allocation of the generation body, see lde_tile_transforms); arguments are made wave-uniform again.
-#ifndef MBX_LDE_POL_ATTR
-#define MBX_LDE_POL_ATTR __noinline__
+// timing experiments only (never a shipped build): bit 0 no gate chains, 1 no head chains, 2 cheap hash instead of Philox in the tile phase,
+// 4 no noise in the row phase, 5 no ranking pass
+#ifndef MBX_LDE_ABL
+#define MBX_LDE_ABL 0
 #endif
-template <int NP, int H, int THREADS>
-__device__ MBX_LDE_POL_ATTR void lde_policy_step(float* XS_, float* HC_, float* ACT_, const float* w_, uint32_t seed_lo, uint32_t seed_hi, uint32_t gen, uint32_t episode, float* traj_row_)
-{
-    typedef __attribute__((address_space(3))) float lds_f32;
-    constexpr int IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
-    auto uni64 = [](uint64_t v) { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32); };
-    lds_f32* HC = (lds_f32*)HC_;
-    lds_f32* ACT = (lds_f32*)ACT_;
-    const float* WT = (const float*)(uintptr_t)uni64((uint64_t)(uintptr_t)w_);       // [K1][4H] (WihT | WhhT contiguous), then b, WmuT, WsgT, bmu, bsg
-    float* traj_row = (float*)(uintptr_t)uni64((uint64_t)(uintptr_t)traj_row_);
-    const float* bg = WT + (int64_t)K1 * G4;
-    const float* WmuT = bg + G4;
-    const float* WsgT = WmuT + (int64_t)H * A;
-    const float* bmu = WsgT + (int64_t)H * A;
-    const float* bsg = bmu + A;
-    const Rng rng{(uint32_t)__builtin_amdgcn_readfirstlane((int)seed_lo), (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_hi), (uint32_t)__builtin_amdgcn_readfirstlane((int)gen),
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)episode), true};
-    const int tid = threadIdx.x;
-        // The tile array is idle between the row sums and the next mutation: it holds the cell's inputs [x | h] as float32 (staged by the
-        // previous generation's feature phase / the prologue), the gate pre-activations and the sigma head's output.  A chain is one fma per k in
-        // ascending k; the weights of LB steps are fetched (L2) before the LB fmas that use them -- few, large batches: the phase is the latency
-        // of its dependent L2 round trips.
-        lds_f32* XS = (lds_f32*)XS_;                              // [K1]
-        lds_f32* GT = XS + ((K1 + 3) & ~3);                          // [4H]
-        lds_f32* SG = GT + G4;                                       // [A] sigma head, pre-activation
-        constexpr int LB = 40;
-        if (tid < G4) {
-            float acc = bg[tid];
-            const float* wcol = WT + tid;
-#pragma unroll 1
-            for (int k0 = 0; k0 < ((MBX_LDE_ABL & 1) ? 0 : K1); k0 += LB) {
-                float wv[LB];
-#pragma unroll
-                for (int j = 0; j < LB; ++j) wv[j] = k0 + j < K1 ? wcol[(int64_t)(k0 + j) * G4] : 0.f;
-#pragma unroll
-                for (int j = 0; j < LB; ++j) if (k0 + j < K1) acc = __builtin_fmaf(XS[k0 + j], wv[j], acc);
-            }
-            GT[tid] = acc;
-        }
-        __syncthreads();
-        if (tid < H) {
-            const float gi = sigmoidf_(GT[tid]), gf = sigmoidf_(GT[H + tid]);
-            const float gg = tanhf(GT[2 * H + tid]), go = sigmoidf_(GT[3 * H + tid]);
-            const float cn = gf * HC[H + tid] + gi * gg;
-            const float hn = go * tanhf(cn);
-            HC[H + tid] = cn;
-            HC[tid] = hn;
-        }
-        __syncthreads();
-        // heads: thread j < A runs the mu chain of component j, thread A + j the sigma chain (when the workgroup has 2 A threads; else both in thread j)
-        constexpr bool SPLIT = 2 * A <= THREADS;
-        float am = 0.f;
-        if (tid < (SPLIT ? 2 * A : A)) {
-            const int j = SPLIT && tid >= A ? tid - A : tid;
-            const bool sig = SPLIT && tid >= A;
-            const float* W = sig ? WsgT : WmuT;
-            float acc = sig ? bsg[j] : bmu[j], acc2 = SPLIT ? 0.f : bsg[j];
-            float wm[H], ws[SPLIT ? 1 : H];
-#pragma unroll
-            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) { wm[k] = W[(int64_t)k * A + j]; if (!SPLIT) ws[k] = WsgT[(int64_t)k * A + j]; }
-#pragma unroll
-            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) {
-                const float hk = HC[k];
-                acc = __builtin_fmaf(hk, wm[k], acc);
-                if (!SPLIT) acc2 = __builtin_fmaf(hk, ws[k], acc2);
-            }
-            if (sig) SG[j] = acc; else am = acc;
-            if (!SPLIT) SG[j] = acc2;
-        }
-        if (SPLIT) __syncthreads();
-        if (tid < A) {
-            const float a = sample_action(rng, tid, am, sigmoidf_(SG[tid]), MBX_POLICY_RLEPSO);
-            ACT[tid] = a;
-            if (traj_row) traj_row[tid] = a;
-        }
-        __syncthreads();
-}
-
 // waves per SIMD the register allocation aims at: 6 (80 VGPRs) -- pop 100: 3 workgroups x 7 waves per CU; pop 50: 6 workgroups x 4 waves (26 880 B of LDS each, the
-// rank tables as bytes).  History (one box each): with the first versions' ~30 spilled registers 96 VGPRs / five workgroups was the faster pop-50 build (0.335 -> 0.286 ms
-// on Sphere); with the transforms, the policy and the Gallagher search out of line the 80-register build spills 13 (pop 100) / a handful (pop 50) and the sixth
-// workgroup wins: 0.408 -> 0.401 ms on all 30 functions.
+// rank tables as bytes).  With the first versions' ~30 spilled registers 96 VGPRs / five workgroups was the faster pop-50 build; with the transforms and the Gallagher
+// search out of line the 80-register build spills 13 (pop 100) / a handful (pop 50) and the two are level (0.381 / 0.380 ms, same box).
 #ifndef MBX_LDE_RUN_WAVES
 #define MBX_LDE_RUN_WAVES(NP) 6
 #endif
@@ -522,9 +436,72 @@ void k_lde_run(LdeRunArgs args_)
         const double fes = L.SCAL[LR_FES];
         const uint8_t* RKa = L.RK;                                 // rank of every physical row in the current fitness order
         int* RKb = L.ACC;                                          // accumulator of the next ranking
-        // ================================================================ policy: LSTM cell + heads + sampling (lde_agent.py:8-29), out of line (lde_policy_step)
-        lde_policy_step<NP, H, 64 * TILES>((float*)L.TB, L.HC, L.ACT, ar.net.w, seed_lo, seed_hi, (uint32_t)gen, (uint32_t)episode,
-                                           ar.out.traj_actions ? ar.out.traj_actions + ((int64_t)it * ar.bp.B + b) * A : nullptr);
+        const float* WT = ar.net.w;                                // [K1][4H] (WihT | WhhT contiguous), then b, WmuT, WsgT, bmu, bsg
+        const float* bg = WT + (int64_t)K1 * G4;
+        const float* WmuT = bg + G4;
+        const float* WsgT = WmuT + (int64_t)H * A;
+        const float* bmu = WsgT + (int64_t)H * A;
+        const float* bsg = bmu + A;
+        // ================================================================ policy: LSTM cell + heads + sampling (lde_agent.py:8-29)
+        // The tile array is idle between the row sums and the next mutation: it holds the cell's inputs [x | h] as float32 (staged by the
+        // previous generation's feature phase / the prologue), the gate pre-activations and the sigma head's output.  A chain is one fma per k in
+        // ascending k; the weights of LB steps are fetched (L2) before the LB fmas that use them -- few, large batches: the phase is the latency
+        // of its dependent L2 round trips.
+        float* XS = (float*)L.TB;                                  // [K1]
+        float* GT = XS + ((K1 + 3) & ~3);                          // [4H]
+        float* SG = GT + G4;                                       // [A] sigma head, pre-activation
+        constexpr int LB = 40;
+        if (tid < G4) {
+            float acc = bg[tid];
+            const float* wcol = WT + tid;
+#pragma unroll 1
+            for (int k0 = 0; k0 < ((MBX_LDE_ABL & 1) ? 0 : K1); k0 += LB) {
+                float wv[LB];
+#pragma unroll
+                for (int j = 0; j < LB; ++j) wv[j] = k0 + j < K1 ? wcol[(int64_t)(k0 + j) * G4] : 0.f;
+#pragma unroll
+                for (int j = 0; j < LB; ++j) if (k0 + j < K1) acc = __builtin_fmaf(XS[k0 + j], wv[j], acc);
+            }
+            GT[tid] = acc;
+        }
+        __syncthreads();
+        MBX_PHASE(0);                                              // LSTM gates
+        if (tid < H) {
+            const float gi = sigmoidf_(GT[tid]), gf = sigmoidf_(GT[H + tid]);
+            const float gg = tanhf(GT[2 * H + tid]), go = sigmoidf_(GT[3 * H + tid]);
+            const float cn = gf * L.HC[H + tid] + gi * gg;
+            const float hn = go * tanhf(cn);
+            L.HC[H + tid] = cn;
+            L.HC[tid] = hn;
+        }
+        __syncthreads();
+        // heads: thread j < A runs the mu chain of component j, thread A + j the sigma chain (when the workgroup has 2 A threads; else both in thread j)
+        constexpr bool SPLIT = 2 * A <= 64 * TILES;
+        float am = 0.f;
+        if (tid < (SPLIT ? 2 * A : A)) {
+            const int j = SPLIT && tid >= A ? tid - A : tid;
+            const bool sig = SPLIT && tid >= A;
+            const float* W = sig ? WsgT : WmuT;
+            float acc = sig ? bsg[j] : bmu[j], acc2 = SPLIT ? 0.f : bsg[j];
+            float wm[H], ws[SPLIT ? 1 : H];
+#pragma unroll
+            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) { wm[k] = W[(int64_t)k * A + j]; if (!SPLIT) ws[k] = WsgT[(int64_t)k * A + j]; }
+#pragma unroll
+            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) {
+                const float hk = L.HC[k];
+                acc = __builtin_fmaf(hk, wm[k], acc);
+                if (!SPLIT) acc2 = __builtin_fmaf(hk, ws[k], acc2);
+            }
+            if (sig) SG[j] = acc; else am = acc;
+            if (!SPLIT) SG[j] = acc2;
+        }
+        if (SPLIT) __syncthreads();
+        if (tid < A) {
+            const float a = sample_action(rng, tid, am, sigmoidf_(SG[tid]), MBX_POLICY_RLEPSO);
+            L.ACT[tid] = a;
+            if (ar.out.traj_actions) ar.out.traj_actions[((int64_t)it * ar.bp.B + b) * A + tid] = a;
+        }
+        __syncthreads();
         MBX_PHASE(1);                                              // cell update, heads, sampling
 
         // ================================================================ the wave's tile: mutation -> first map -> transforms
