@@ -77,6 +77,7 @@ struct mbx_batch {
     int32_t* d_order = nullptr;
     double* d_pci = nullptr;
     double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (RLEPSO batches; allocated by mbx_batch_create)
+    float* d_lstm_pack = nullptr;          // k-blocked copy of the PolicyNet weights for k_lde_run (k_lde_repack at every mbx_lde_rollout call)
     bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind k_lde_run builds (lde_run_kind_ok)
     bool rollout_per_generation = false;   // MBX_ROLLOUT_PER_GENERATION=1 at batch creation: mbx_rlepso_rollout takes the host-loop route (tests)
     int64_t state_stride = 0;
@@ -569,6 +570,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
             HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * (sizeof(double) + (size_t)g.action_dim * sizeof(float))));
             const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");
             b->rollout_per_generation = per_gen && per_gen[0] == '1';
+            HIP_TRY(hipMalloc(&b->d_lstm_pack, (size_t)lde_run_pack_floats(g.state_dim, 64, g.action_dim) * sizeof(float)));      // hidden <= 64
             HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(100, 30, 50) * sizeof(double))));
             HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50) * sizeof(double))));
         }
@@ -611,7 +613,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
 extern "C" int mbx_batch_destroy(mbx_batch* b)
 {
     if (!b) return MBX_OK;
-    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order); (void)hipFree(b->d_pci); (void)hipFree(b->d_scratch);
+    (void)hipFree(b->d_problem_idx); (void)hipFree(b->d_seeds); (void)hipFree(b->d_state); (void)hipFree(b->d_order); (void)hipFree(b->d_pci); (void)hipFree(b->d_scratch); (void)hipFree(b->d_lstm_pack);
     delete b;
     return MBX_OK;
 }
@@ -957,7 +959,11 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
     if (mbx_lde_rollout_resident(b) == 1 && net->hidden == 50) {
         LdeRunArgs ka{};
         ka.bp = make_params(b);
-        ka.net = LstmPolicy{net->d_weights, net->in_dim, net->hidden, net->out_dim};
+        {   // the weights may have changed since the last call: rebuild the k-blocked copy the kernel reads (one small launch, ~3 us)
+            const LstmPolicy src{net->d_weights, net->in_dim, net->hidden, net->out_dim};
+            hipLaunchKernelGGL(k_lde_repack, dim3(64), dim3(256), 0, (hipStream_t)stream, src, b->d_lstm_pack);
+        }
+        ka.net = LstmPolicy{b->d_lstm_pack, net->in_dim, net->hidden, net->out_dim};
         ka.state_in = d_state_in; ka.hbuf = d_h; ka.cbuf = d_c; ka.n_gens = n_gens;
         ka.out = LdeRunOut{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
         if (b->fixed_geometry == 6)

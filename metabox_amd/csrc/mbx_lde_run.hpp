@@ -39,11 +39,47 @@ struct LdeRunOut {
     uint8_t* done_out;           // [B]
 };
 
+// k-blocked copy of the packed PolicyNet weights for k_lde_run: a thread of the in-kernel policy owns ONE output unit and walks k, so four consecutive k of its unit
+// are stored side by side -- gates: [ceil(K1 / 4)][4H] float4, bias [4H], mu head: [ceil(H / 4)][A] float4, sigma head likewise, bmu [A], bsg [A]; the padding
+// k >= K1 / H is zero -- one 16-byte load per four k-steps instead of four 4-byte loads with an address each (half the instructions of the gate phase).  Rebuilt by a
+// tiny launch at every mbx_lde_rollout call (the weights may have changed) into a buffer the batch owns.
+__host__ __device__ inline int64_t lde_run_pack_floats(int IN, int H, int A)
+{
+    const int64_t K1 = IN + H, G4 = 4 * H;
+    return 4 * ((K1 + 3) / 4) * G4 + G4 + 2 * 4 * (int64_t)((H + 3) / 4) * A + 2 * A;
+}
+__global__ void k_lde_repack(LstmPolicy net, float* __restrict__ dst)
+{
+    const int IN = net.in_dim, H = net.hidden, A = net.out_dim, K1 = IN + H, G4 = 4 * H, KB1 = (K1 + 3) / 4, KBH = (H + 3) / 4;
+    const float* W = net.w;                                         // [K1][G4] | b [G4] | WmuT [H][A] | WsgT [H][A] | bmu [A] | bsg [A]
+    const float* bg = W + (int64_t)K1 * G4;
+    const float* Wmu = bg + G4;
+    const float* Wsg = Wmu + (int64_t)H * A;
+    const float* bmu = Wsg + (int64_t)H * A;
+    float* dg = dst;
+    float* dbg = dg + (int64_t)4 * KB1 * G4;
+    float* dmu = dbg + G4;
+    float* dsg = dmu + (int64_t)4 * KBH * A;
+    float* dbm = dsg + (int64_t)4 * KBH * A;
+    const int64_t n1 = (int64_t)4 * KB1 * G4, n2 = (int64_t)4 * KBH * A;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n1 + G4 + 2 * n2 + 2 * A; t += (int64_t)gridDim.x * blockDim.x) {
+        if (t < n1) { const int kk = (int)(t & 3), u = (int)((t >> 2) % G4), kb = (int)((t >> 2) / G4), k = 4 * kb + kk; dg[t] = k < K1 ? W[(int64_t)k * G4 + u] : 0.f; }
+        else if (t < n1 + G4) dbg[t - n1] = bg[t - n1];
+        else if (t < n1 + G4 + 2 * n2) {
+            const int64_t r = t - n1 - G4;
+            const bool sg = r >= n2;
+            const int64_t q = sg ? r - n2 : r;
+            const int kk = (int)(q & 3), j = (int)((q >> 2) % A), kb = (int)((q >> 2) / A), k = 4 * kb + kk;
+            (sg ? dsg : dmu)[q] = k < H ? (sg ? Wsg : Wmu)[(int64_t)k * A + j] : 0.f;
+        } else dbm[t - n1 - G4 - 2 * n2] = bmu[t - n1 - G4 - 2 * n2];          // bmu | bsg are contiguous in both layouts
+    }
+}
+
 // ONE kernel argument: the kernel reads its fields through the kernarg segment pointer (scalar loads where they are used) instead of holding
 // ~60 argument SGPRs across the generation loop, where they collide with the loop's own uniform values and are spilled to VGPR lanes.
 struct LdeRunArgs {
     BatchParams bp;
-    LstmPolicy net;
+    LstmPolicy net;              // net.w: the k-BLOCKED copy (k_lde_repack), not the caller's packed weights
     const double* state_in;      // [B][NP + 10] features of the last reset / step / rollout
     float* hbuf;                 // [B][H]
     float* cbuf;                 // [B][H]
@@ -402,7 +438,7 @@ void k_lde_run(LdeRunArgs args_)
         if (tid < H) { L.HC[tid] = ar.hbuf[(int64_t)b * H + tid]; L.HC[H + tid] = ar.cbuf[(int64_t)b * H + tid]; }
         {   // the policy's input [x | h] as float32 (afterwards the feature phase of a generation stages the next one's)
             float* XS = (float*)L.TB;
-            for (int k = tid; k < K1; k += MBX_NT) XS[k] = k < IN ? (float)ar.state_in[(int64_t)b * NF + k] : ar.hbuf[(int64_t)b * H + (k - IN)];
+            for (int k = tid; k < 4 * ((K1 + 3) / 4); k += MBX_NT) XS[k] = k < IN ? (float)ar.state_in[(int64_t)b * NF + k] : (k < K1 ? ar.hbuf[(int64_t)b * H + (k - IN)] : 0.f);
         }
         if (tid == 0) {
             L.FLAG[0] = 0;
@@ -436,11 +472,12 @@ void k_lde_run(LdeRunArgs args_)
         const double fes = L.SCAL[LR_FES];
         const uint8_t* RKa = L.RK;                                 // rank of every physical row in the current fitness order
         int* RKb = L.ACC;                                          // accumulator of the next ranking
-        const float* WT = ar.net.w;                                // [K1][4H] (WihT | WhhT contiguous), then b, WmuT, WsgT, bmu, bsg
-        const float* bg = WT + (int64_t)K1 * G4;
-        const float* WmuT = bg + G4;
-        const float* WsgT = WmuT + (int64_t)H * A;
-        const float* bmu = WsgT + (int64_t)H * A;
+        constexpr int KB1 = (K1 + 3) / 4, KBH = (H + 3) / 4;
+        const float4* WG = (const float4*)ar.net.w;                // k-blocked (lde_run_pack_floats): gates [KB1][4H] float4 | b [4H] | mu [KBH][A] float4 | sigma likewise | bmu | bsg
+        const float* bg = ar.net.w + (int64_t)4 * KB1 * G4;
+        const float4* WMU = (const float4*)(bg + G4);
+        const float4* WSG = WMU + (int64_t)KBH * A;
+        const float* bmu = (const float*)(WSG + (int64_t)KBH * A);
         const float* bsg = bmu + A;
         // ================================================================ policy: LSTM cell + heads + sampling (lde_agent.py:8-29)
         // The tile array is idle between the row sums and the next mutation: it holds the cell's inputs [x | h] as float32 (staged by the
@@ -450,17 +487,23 @@ void k_lde_run(LdeRunArgs args_)
         float* XS = (float*)L.TB;                                  // [K1]
         float* GT = XS + ((K1 + 3) & ~3);                          // [4H]
         float* SG = GT + G4;                                       // [A] sigma head, pre-activation
-        constexpr int LB = 40;
+        constexpr int LBQ = 10;                                    // float4 (= 4 k-steps) per batch
         if (tid < G4) {
             float acc = bg[tid];
-            const float* wcol = WT + tid;
+            const float4* wcol = WG + tid;
 #pragma unroll 1
-            for (int k0 = 0; k0 < ((MBX_LDE_ABL & 1) ? 0 : K1); k0 += LB) {
-                float wv[LB];
+            for (int kb0 = 0; kb0 < ((MBX_LDE_ABL & 1) ? 0 : KB1); kb0 += LBQ) {
+                float4 wv[LBQ];
 #pragma unroll
-                for (int j = 0; j < LB; ++j) wv[j] = k0 + j < K1 ? wcol[(int64_t)(k0 + j) * G4] : 0.f;
+                for (int j = 0; j < LBQ; ++j) wv[j] = kb0 + j < KB1 ? wcol[(int64_t)(kb0 + j) * G4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int j = 0; j < LB; ++j) if (k0 + j < K1) acc = __builtin_fmaf(XS[k0 + j], wv[j], acc);
+                for (int j = 0; j < LBQ; ++j) {
+                    if (kb0 + j < KB1) {
+                        const float4 x = *(const float4*)(XS + 4 * (kb0 + j));      // (XS is zero beyond K1: the padded steps add fma(0, 0, acc) = acc, like the MFMA kernel's)
+                        acc = __builtin_fmaf(x.x, wv[j].x, acc); acc = __builtin_fmaf(x.y, wv[j].y, acc);
+                        acc = __builtin_fmaf(x.z, wv[j].z, acc); acc = __builtin_fmaf(x.w, wv[j].w, acc);
+                    }
+                }
             }
             GT[tid] = acc;
         }
@@ -481,16 +524,17 @@ void k_lde_run(LdeRunArgs args_)
         if (tid < (SPLIT ? 2 * A : A)) {
             const int j = SPLIT && tid >= A ? tid - A : tid;
             const bool sig = SPLIT && tid >= A;
-            const float* W = sig ? WsgT : WmuT;
+            const float4* W = (sig ? WSG : WMU) + j;
             float acc = sig ? bsg[j] : bmu[j], acc2 = SPLIT ? 0.f : bsg[j];
-            float wm[H], ws[SPLIT ? 1 : H];
+            float4 wm[KBH], ws[SPLIT ? 1 : KBH];
 #pragma unroll
-            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) { wm[k] = W[(int64_t)k * A + j]; if (!SPLIT) ws[k] = WsgT[(int64_t)k * A + j]; }
+            for (int kb = 0; kb < ((MBX_LDE_ABL & 2) ? 1 : KBH); ++kb) { wm[kb] = W[(int64_t)kb * A]; if (!SPLIT) ws[kb] = WSG[(int64_t)kb * A + j]; }
 #pragma unroll
-            for (int k = 0; k < ((MBX_LDE_ABL & 2) ? 1 : H); ++k) {
-                const float hk = L.HC[k];
-                acc = __builtin_fmaf(hk, wm[k], acc);
-                if (!SPLIT) acc2 = __builtin_fmaf(hk, ws[k], acc2);
+            for (int kb = 0; kb < ((MBX_LDE_ABL & 2) ? 1 : KBH); ++kb) {
+                // h[k] for k >= H reads into the cell state behind it (finite) against a zero weight: the padded steps of the MFMA kernel
+                const float h0 = L.HC[4 * kb], h1 = L.HC[4 * kb + 1], h2 = L.HC[4 * kb + 2], h3 = L.HC[4 * kb + 3];
+                acc = __builtin_fmaf(h0, wm[kb].x, acc); acc = __builtin_fmaf(h1, wm[kb].y, acc); acc = __builtin_fmaf(h2, wm[kb].z, acc); acc = __builtin_fmaf(h3, wm[kb].w, acc);
+                if (!SPLIT) { acc2 = __builtin_fmaf(h0, ws[kb].x, acc2); acc2 = __builtin_fmaf(h1, ws[kb].y, acc2); acc2 = __builtin_fmaf(h2, ws[kb].z, acc2); acc2 = __builtin_fmaf(h3, ws[kb].w, acc2); }
             }
             if (sig) SG[j] = acc; else am = acc;
             if (!SPLIT) SG[j] = acc2;
@@ -714,7 +758,7 @@ void k_lde_run(LdeRunArgs args_)
             L.FEAT[NP + MBX_LDE_BINS + tid] = L.HS[tid] / hcount;
         }
         __syncthreads();                                           // every thread has read fes / hcount of this generation
-        { float* XS = (float*)L.TB; for (int k = tid; k < K1; k += MBX_NT) XS[k] = k < IN ? (float)L.FEAT[k] : L.HC[k - IN]; }   // the next generation's policy input (FEAT is complete; published by the barrier below)
+        { float* XS = (float*)L.TB; for (int k = tid; k < 4 * ((K1 + 3) / 4); k += MBX_NT) XS[k] = k < IN ? (float)L.FEAT[k] : (k < K1 ? L.HC[k - IN] : 0.f); }   // the next generation's policy input (FEAT is complete; published by the barrier below)
         if (tid == 0) {
             L.HS[MBX_LDE_BINS] = lde_pack_hist(L.HIST);
             const double bsf_next = L.A1[0], bsf_cur = L.SCAL[LR_BSF], fes_next = fes + NP;
