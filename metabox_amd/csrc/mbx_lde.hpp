@@ -72,17 +72,22 @@ __device__ __forceinline__ int lde_hist_bin(double v, double first, double last)
 
 // __maxmin_norm + np.histogram of an ASCENDING fitness vector F[0..NP) (lde_optimizer.py:81-87,148-151):
 // NORM[i] = normalised fitness, HIST[0..5) = bin counts.  All threads call.
-__device__ __forceinline__ void lde_norm_hist(const double* F, int NP, double* NORM, int* HIST)
+// HIST_ZEROED: the caller cleared HIST before its last barrier (one barrier interval less); NORMF: a float32 copy of the normalised values (the policy's input)
+template <bool HIST_ZEROED = false>
+__device__ __forceinline__ void lde_norm_hist(const double* F, int NP, double* NORM, int* HIST, float* NORMF = nullptr)
 {
     const int tid = threadIdx.x;
-    if (tid < MBX_LDE_BINS) HIST[tid] = 0;
-    __syncthreads();
+    if constexpr (!HIST_ZEROED) {
+        if (tid < MBX_LDE_BINS) HIST[tid] = 0;
+        __syncthreads();
+    }
     const double mn = F[0], mx = F[NP - 1];
     double first = 0., last = mx != mn ? (mx - mn) / (mx - mn) : 0.;
     if (first == last) { first -= 0.5; last += 0.5; }
     for (int i = tid; i < NP; i += MBX_NT) {
         const double v = mx != mn ? (F[i] - mn) / (mx - mn) : 0.;
         if (NORM) NORM[i] = v;
+        if (NORMF) NORMF[i] = (float)v;
         atomicAdd(&HIST[lde_hist_bin(v, first, last)], 1);
     }
     __syncthreads();

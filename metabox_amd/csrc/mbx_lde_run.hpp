@@ -396,6 +396,7 @@ void k_lde_run(LdeRunArgs args_)
     constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
     constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
     static_assert(D > 16 && D <= 32, "two 16-column tiles");
+    static_assert(4 * ((K1 + 3) / 4) - IN <= 64, "the hidden state is staged by one wave");
     const LdeRunLds L = lde_run_carve(smem, NP, D, H);
     int b, gen0, episode, n_gens;
     uint32_t seed_lo, seed_hi;
@@ -744,23 +745,17 @@ void k_lde_run(LdeRunArgs args_)
                 }
                 if (cnt) atomicAdd(&RKb[i], cnt);
             }
-            if (tid < MBX_LDE_BINS) L.HS[tid] += (double)my_hist;
+            if (tid < MBX_LDE_BINS) { L.HS[tid] += (double)my_hist; L.HIST[tid] = 0; }
         }
         __syncthreads();
         if (tid < NP) { const int r = (MBX_LDE_ABL & 32) ? RKa[tid] : RKb[tid]; L.RK[tid] = (uint8_t)r; L.ORDER[r] = (uint8_t)tid; L.A1[r] = L.FIT[tid]; }
+        // the next generation's policy input [x | h] as float32 in the (idle) tile array: h here, the features by the threads that make them
+        if (tid >= MBX_NT - 64) { float* XS = (float*)L.TB; const int k = IN + (tid - (MBX_NT - 64)); if (k < 4 * ((K1 + 3) / 4)) XS[k] = k < K1 ? L.HC[k - IN] : 0.f; }
         __syncthreads();
         MBX_PHASE(5);                                              // survivors, ranking, order
-        // ---- features of the new state (:145-157) and the bookkeeping of update() (:170-198)
-        lde_norm_hist(L.A1, NP, L.FEAT, L.HIST);
-        const double hcount = L.SCAL[LR_HCOUNT] + 1;
-        if (tid < MBX_LDE_BINS) {
-            L.FEAT[NP + tid] = (double)L.HIST[tid];
-            L.FEAT[NP + MBX_LDE_BINS + tid] = L.HS[tid] / hcount;
-        }
-        __syncthreads();                                           // every thread has read fes / hcount of this generation
-        { float* XS = (float*)L.TB; for (int k = tid; k < 4 * ((K1 + 3) / 4); k += MBX_NT) XS[k] = k < IN ? (float)L.FEAT[k] : (k < K1 ? L.HC[k - IN] : 0.f); }   // the next generation's policy input (FEAT is complete; published by the barrier below)
-        if (tid == 0) {
-            L.HS[MBX_LDE_BINS] = lde_pack_hist(L.HIST);
+        // ---- features of the new state (:145-157) and the bookkeeping of update() (:170-198).  The bookkeeping needs the best fitness only: lane 0 of the LAST wave (no
+        // rows of the normalisation there) runs it beside the normalisation instead of behind it.
+        if (tid == MBX_NT - 64) {
             const double bsf_next = L.A1[0], bsf_cur = L.SCAL[LR_BSF], fes_next = fes + NP;
             const double reward = (bsf_cur - bsf_next) / bsf_cur;   // :170
             int log_index = (int)L.SCAL[LR_LOGI], cost_len = (int)L.SCAL[LR_CLEN];
@@ -776,12 +771,21 @@ void k_lde_run(LdeRunArgs args_)
                     else cost[cost_len++] = bsf_next;
                 }
             }
-            L.SCAL[LR_FES] = fes_next; L.SCAL[LR_HCOUNT] = hcount; L.SCAL[LR_BSF] = bsf_next;
+            L.SCAL[LR_FES] = fes_next; L.SCAL[LR_HCOUNT] += 1.; L.SCAL[LR_BSF] = bsf_next;      // (fes is in every thread's registers; the new history length is read below, behind the barrier)
             L.SCAL[LR_RSUM] += reward; L.SCAL[LR_RTOT] += reward; L.SCAL[LR_LOGI] = log_index; L.SCAL[LR_CLEN] = cost_len;
             L.FLAG[0] = dn ? 1 : 0;
             if (ar.out.traj_reward) ar.out.traj_reward[(int64_t)it * ar.bp.B + b] = reward;
             if (ar.out.traj_done) ar.out.traj_done[(int64_t)it * ar.bp.B + b] = dn ? 1 : 0;
         }
+        lde_norm_hist<true>(L.A1, NP, L.FEAT, L.HIST, (float*)L.TB);      // (HIST cleared before the ranking's barrier)
+        if (tid < MBX_LDE_BINS) {
+            float* XS = (float*)L.TB;
+            const double hcount = L.SCAL[LR_HCOUNT];
+            const double f1 = (double)L.HIST[tid], f2 = L.HS[tid] / hcount;
+            L.FEAT[NP + tid] = f1; L.FEAT[NP + MBX_LDE_BINS + tid] = f2;
+            XS[NP + tid] = (float)f1; XS[NP + MBX_LDE_BINS + tid] = (float)f2;
+        }
+        if (tid == 64) L.HS[MBX_LDE_BINS] = lde_pack_hist(L.HIST);
         __syncthreads();
         if (ar.out.traj_state) for (int k = tid; k < NF; k += MBX_NT) ar.out.traj_state[((int64_t)it * ar.bp.B + b) * NF + k] = L.FEAT[k];
         MBX_PHASE(6);                                              // features, bookkeeping
