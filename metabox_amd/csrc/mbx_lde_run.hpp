@@ -260,7 +260,7 @@ __device__ __forceinline__ void lde_map_tile(const double* __restrict__ M, const
 // Everything element-wise between the first linear map and the row sums (phases E1, C, E2 of eval_rows), IN PLACE in the wave's slice, one element per lane at a
 // time.  Out of line like the Gallagher search: the generation body (policy, mutation, ranking) is register-allocated without it, and the kinds that have
 // nothing element-wise never call it.
-template <int NP, int D>
+template <int NP, int D, int KIND = 0>
 __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, ConstProblem* Pp, int kind_)
 {
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -270,7 +270,7 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
     const uint64_t pu_ = (uint64_t)(uintptr_t)Pp;
     const uint64_t pu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pu_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pu_ >> 32)) << 32);
     ConstProblem& P = *(ConstProblem*)(uintptr_t)pu;
-    const int kind = __builtin_amdgcn_readfirstlane(kind_);
+    const int kind = KIND ? KIND : __builtin_amdgcn_readfirstlane(kind_);      // KIND: the caller's compile-time kind (lde_run_generations)
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool rvalid = 16 * wave + c < NP;
@@ -387,67 +387,29 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
 // loop-carried scalars of the instance, in LDS (thread 0 updates them at the end of a generation, every thread reads what it needs at the top of the next)
 enum { LR_FES = 0, LR_HCOUNT, LR_BSF, LR_RSUM, LR_RTOT, LR_LOGI, LR_CLEN };
 
-template <int NPC, int DC, int HC_ = 50>
-__global__ __launch_bounds__(64 * ((NPC + 15) / 16)) __attribute__((amdgpu_waves_per_eu(MBX_LDE_RUN_WAVES(NPC))))
-void k_lde_run(LdeRunArgs args_)
+// The generations of ONE launch (everything between the prologue that stages the state block and the epilogue that writes it back).  Out of line, and instantiated once per
+// objective kind of the noisy suite besides the any-kind form (KIND = 0: the kind is read from the problem record): a workgroup runs the loop of ITS kind, register-allocated
+// and scheduled without the other kinds' code (the any-kind kernel ran a Sphere batch 10 % slower than a build with everything but Sphere compiled out).  One launch for the
+// mixed batch all the same: one launch per kind on side streams lost more in the eight tails than the specialisation gained (docs/EXPERIMENTS.md).
+// Arguments arrive in VGPRs and are made wave-uniform again (the address of the kernel's argument block among them); the LDS carve-up is rebuilt from the dynamic LDS symbol.  Returns the number of generations executed.
+template <int NPC, int DC, int HC_, int KIND>
+__device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_, int n_gens_, uint32_t seed_lo_, uint32_t seed_hi_, uint32_t karg_lo_, uint32_t karg_hi_)
 {
-    (void)args_;                                                   // read through lde_run_args()
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
     constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
-    static_assert(D > 16 && D <= 32, "two 16-column tiles");
     static_assert(4 * ((K1 + 3) / 4) - IN <= 64, "the hidden state is staged by one wave");
     const LdeRunLds L = lde_run_carve(smem, NP, D, H);
-    int b, gen0, episode, n_gens;
-    uint32_t seed_lo, seed_hi;
-    {
-        LdeRunCArgs& ar = lde_run_args();
-        const int tid = threadIdx.x;
-        b = __builtin_amdgcn_readfirstlane(ar.bp.order[blockIdx.x]);
-        n_gens = ar.n_gens;
-        { const uint64_t sd = ar.bp.seeds[b]; seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sd); seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sd >> 32)); }
-        double* S = ar.bp.state + (int64_t)b * ar.bp.state_stride;
-        double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
-        if (sc[MBX_SC_DONE] != 0.) {                               // finished before this launch: state_out keeps the last features
-            if (tid == 0) {
-                if (ar.out.reward_out) ar.out.reward_out[b] = 0.;
-                if (ar.out.done_out) ar.out.done_out[b] = 1;
-                for (int g = 0; g < n_gens; ++g) {
-                    if (ar.out.traj_reward) ar.out.traj_reward[(int64_t)g * ar.bp.B + b] = 0.;
-                    if (ar.out.traj_done) ar.out.traj_done[(int64_t)g * ar.bp.B + b] = 1;
-                }
-            }
-            return;
-        }
-        episode = __builtin_amdgcn_readfirstlane((int)sc[MBX_SC_EPISODE]);
-        gen0 = __builtin_amdgcn_readfirstlane((int)sc[MBX_SC_GEN]);
-        // ---- the state block, once
-        const double* gPop = S + MBX_LDE_ST_POP(NP, D);
-        for (int e = tid; e < NE; e += MBX_NT) L.P[e] = gPop[e];
-        for (int i = tid; i < NP; i += MBX_NT) {
-            const double f = S[MBX_LDE_ST_FIT(NP, D) + i];
-            L.FIT[i] = f; L.A1[i] = f;                             // sorted in HBM: SORTED == FIT
-            L.RK[i] = (uint8_t)i; L.ORDER[i] = (uint8_t)i;
-        }
-        if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
-        {
-            const DevProblem* pr = ar.bp.problems + ar.bp.problem_idx[b];
-            const double* dsh = pr->dshift;
-            if (tid < D) L.DSH[tid] = (dsh && !(pr->kind == 21 || pr->kind == 22)) ? dsh[tid] : 0.;      // Gallagher: no shift (peaks pre-rotated)
-        }
-        for (int k = tid; k < NF; k += MBX_NT) L.FEAT[k] = ar.state_in[(int64_t)b * NF + k];
-        if (tid < H) { L.HC[tid] = ar.hbuf[(int64_t)b * H + tid]; L.HC[H + tid] = ar.cbuf[(int64_t)b * H + tid]; }
-        {   // the policy's input [x | h] as float32 (afterwards the feature phase of a generation stages the next one's)
-            float* XS = (float*)L.TB;
-            for (int k = tid; k < 4 * ((K1 + 3) / 4); k += MBX_NT) XS[k] = k < IN ? (float)ar.state_in[(int64_t)b * NF + k] : (k < K1 ? ar.hbuf[(int64_t)b * H + (k - IN)] : 0.f);
-        }
-        if (tid == 0) {
-            L.FLAG[0] = 0;
-            L.SCAL[LR_FES] = sc[MBX_SC_FES]; L.SCAL[LR_HCOUNT] = sc[MBX_SC_HCOUNT]; L.SCAL[LR_BSF] = S[MBX_LDE_ST_FIT(NP, D)];
-            L.SCAL[LR_RSUM] = 0.; L.SCAL[LR_RTOT] = sc[MBX_SC_RETURN]; L.SCAL[LR_LOGI] = sc[MBX_SC_LOG_INDEX]; L.SCAL[LR_CLEN] = sc[MBX_SC_COST_LEN];
-        }
-    }
-    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(b_), gen0 = __builtin_amdgcn_readfirstlane(gen0_), episode = __builtin_amdgcn_readfirstlane(episode_);
+    const int n_gens = __builtin_amdgcn_readfirstlane(n_gens_);
+    const uint32_t seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_lo_), seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_hi_);
+    // the kernel's argument block: its address is an argument (in a callee s[8:9] -- what __builtin_amdgcn_kernarg_segment_ptr() reads -- is the IMPLICIT argument pointer)
+    const uint32_t karg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_lo_), karg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_hi_);
+    auto lde_run_args = [&]() -> LdeRunCArgs& {
+        uintptr_t p = (uintptr_t)(((uint64_t)karg_hi << 32) | karg_lo);
+        asm volatile("" : "+s"(p));                               // (not common with any other use: every field access is a fresh s_load)
+        return *(LdeRunCArgs*)p;
+    };
     MBX_PHASE_BEGIN
     int executed = 0;
 
@@ -465,7 +427,7 @@ void k_lde_run(LdeRunArgs args_)
 #ifdef MBX_LDE_ONLY_KIND
         const int kind = MBX_LDE_ONLY_KIND;                        // timing experiment: code size (every other kind compiled out)
 #else
-        const int kind = P.kind;
+        const int kind = KIND ? KIND : P.kind;
 #endif
         const double lb = P.lb, ub = P.ub, bias = P.bias;
         const int gen = gen0 + it + 1;
@@ -632,7 +594,7 @@ void k_lde_run(LdeRunArgs args_)
         // calls, and the fewer values are alive across a call the fewer are spilled around it).
         lde_map_tile<NP, D>(P.m1, av, TW, wave, c, q);
         MBX_PHASE(8);                                              // (first linear map of wave 0)
-        if (!(kind == 1 || kind == 13 || gall)) lde_tile_transforms<NP, D>(TW, L.A2, &P, kind);      // (Sphere-like kinds and Gallagher: nothing element-wise)
+        if (!(kind == 1 || kind == 13 || gall)) lde_tile_transforms<NP, D, KIND>(TW, L.A2, &P, kind);      // (Sphere-like kinds and Gallagher: nothing element-wise)
         __syncthreads();
         MBX_PHASE(2);                                              // mutation, linear maps, transforms (wave-local)
 
@@ -792,6 +754,86 @@ void k_lde_run(LdeRunArgs args_)
         executed = it + 1;
         if (L.FLAG[0] != 0) break;
     }
+    return executed;
+}
+
+template <int NPC, int DC, int HC_ = 50>
+__global__ __launch_bounds__(64 * ((NPC + 15) / 16)) __attribute__((amdgpu_waves_per_eu(MBX_LDE_RUN_WAVES(NPC))))
+void k_lde_run(LdeRunArgs args_)
+{
+    (void)args_;                                                   // read through lde_run_args()
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
+    constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
+    static_assert(D > 16 && D <= 32, "two 16-column tiles");
+    const LdeRunLds L = lde_run_carve(smem, NP, D, H);
+    int b, gen0, episode, n_gens, kind0;
+    uint32_t seed_lo, seed_hi;
+    {
+        LdeRunCArgs& ar = lde_run_args();
+        const int tid = threadIdx.x;
+        b = __builtin_amdgcn_readfirstlane(ar.bp.order[blockIdx.x]);
+        n_gens = ar.n_gens;
+        { const uint64_t sd = ar.bp.seeds[b]; seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sd); seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sd >> 32)); }
+        double* S = ar.bp.state + (int64_t)b * ar.bp.state_stride;
+        double* sc = S + MBX_LDE_ST_SCALARS(NP, D);
+        if (sc[MBX_SC_DONE] != 0.) {                               // finished before this launch: state_out keeps the last features
+            if (tid == 0) {
+                if (ar.out.reward_out) ar.out.reward_out[b] = 0.;
+                if (ar.out.done_out) ar.out.done_out[b] = 1;
+                for (int g = 0; g < n_gens; ++g) {
+                    if (ar.out.traj_reward) ar.out.traj_reward[(int64_t)g * ar.bp.B + b] = 0.;
+                    if (ar.out.traj_done) ar.out.traj_done[(int64_t)g * ar.bp.B + b] = 1;
+                }
+            }
+            return;
+        }
+        episode = __builtin_amdgcn_readfirstlane((int)sc[MBX_SC_EPISODE]);
+        gen0 = __builtin_amdgcn_readfirstlane((int)sc[MBX_SC_GEN]);
+        // ---- the state block, once
+        const double* gPop = S + MBX_LDE_ST_POP(NP, D);
+        for (int e = tid; e < NE; e += MBX_NT) L.P[e] = gPop[e];
+        for (int i = tid; i < NP; i += MBX_NT) {
+            const double f = S[MBX_LDE_ST_FIT(NP, D) + i];
+            L.FIT[i] = f; L.A1[i] = f;                             // sorted in HBM: SORTED == FIT
+            L.RK[i] = (uint8_t)i; L.ORDER[i] = (uint8_t)i;
+        }
+        if (tid < 8) L.HS[tid] = S[MBX_LDE_ST_HSUM(NP, D) + tid];
+        {
+            const DevProblem* pr = ar.bp.problems + ar.bp.problem_idx[b];
+            kind0 = __builtin_amdgcn_readfirstlane(pr->kind);
+            const double* dsh = pr->dshift;
+            if (tid < D) L.DSH[tid] = (dsh && !(pr->kind == 21 || pr->kind == 22)) ? dsh[tid] : 0.;      // Gallagher: no shift (peaks pre-rotated)
+        }
+        for (int k = tid; k < NF; k += MBX_NT) L.FEAT[k] = ar.state_in[(int64_t)b * NF + k];
+        if (tid < H) { L.HC[tid] = ar.hbuf[(int64_t)b * H + tid]; L.HC[H + tid] = ar.cbuf[(int64_t)b * H + tid]; }
+        {   // the policy's input [x | h] as float32 (afterwards the feature phase of a generation stages the next one's)
+            float* XS = (float*)L.TB;
+            for (int k = tid; k < 4 * ((K1 + 3) / 4); k += MBX_NT) XS[k] = k < IN ? (float)ar.state_in[(int64_t)b * NF + k] : (k < K1 ? ar.hbuf[(int64_t)b * H + (k - IN)] : 0.f);
+        }
+        if (tid == 0) {
+            L.FLAG[0] = 0;
+            L.SCAL[LR_FES] = sc[MBX_SC_FES]; L.SCAL[LR_HCOUNT] = sc[MBX_SC_HCOUNT]; L.SCAL[LR_BSF] = S[MBX_LDE_ST_FIT(NP, D)];
+            L.SCAL[LR_RSUM] = 0.; L.SCAL[LR_RTOT] = sc[MBX_SC_RETURN]; L.SCAL[LR_LOGI] = sc[MBX_SC_LOG_INDEX]; L.SCAL[LR_CLEN] = sc[MBX_SC_COST_LEN];
+        }
+    }
+    __syncthreads();
+    int executed;
+    const uint64_t karg = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+#define MBX_LDE_GENS(K) lde_run_generations<NPC, DC, HC_, K>(b, gen0, episode, n_gens, seed_lo, seed_hi, (uint32_t)karg, (uint32_t)(karg >> 32))
+    switch (kind0) {                                               // the kinds of the noisy suite (problem/bbob.py: _NOISY); anything else takes the any-kind loop
+    case 1: executed = MBX_LDE_GENS(1); break;
+    case 7: executed = MBX_LDE_GENS(7); break;
+    case 8: executed = MBX_LDE_GENS(8); break;
+    case 10: executed = MBX_LDE_GENS(10); break;
+    case 14: executed = MBX_LDE_GENS(14); break;
+    case 17: executed = MBX_LDE_GENS(17); break;
+    case 19: executed = MBX_LDE_GENS(19); break;
+    case 21: executed = MBX_LDE_GENS(21); break;
+    default: executed = MBX_LDE_GENS(0); break;
+    }
+#undef MBX_LDE_GENS
+    executed = __builtin_amdgcn_readfirstlane(executed);
 
     // ---- the state block, once: population and fitness in fitness order, like k_lde_step leaves them
     {
