@@ -78,6 +78,7 @@ struct mbx_batch {
     double* d_pci = nullptr;
     double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (RLEPSO batches; allocated by mbx_batch_create)
     float* d_lstm_pack = nullptr;          // k-blocked copy of the PolicyNet weights for k_lde_run (k_lde_repack at every mbx_lde_rollout call)
+    bool rl_run_kinds_ok = false;          // RLEPSO: every problem of the batch is one of the 24 BBOB kinds the per-kind k_rlepso_run geometries have a body for (rl_run_kind_ok)
     bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind k_lde_run builds (lde_run_kind_ok)
     bool rollout_per_generation = false;   // MBX_ROLLOUT_PER_GENERATION=1 at batch creation: mbx_rlepso_rollout takes the host-loop route (tests)
     int64_t state_stride = 0;
@@ -484,6 +485,8 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
         }
     };
     b->lde_run_kinds_ok = true;
+    b->rl_run_kinds_ok = true;
+    for (int i = 0; i < n_instances; ++i) b->rl_run_kinds_ok = b->rl_run_kinds_ok && rl_run_kind_ok(s->h_problems[problem_idx[i]].kind);
     for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind);
     std::vector<int32_t> order(n_instances);
     for (int i = 0; i < n_instances; ++i) order[i] = i;
@@ -887,6 +890,7 @@ extern "C" int mbx_rlepso_rollout_resident(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "mbx_rlepso_rollout_resident: null batch");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return 0;
+    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !b->rl_run_kinds_ok) return 0;
     return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7) && !b->rollout_per_generation ? 1 : 0;
 }
 

@@ -681,16 +681,19 @@ __device__ __forceinline__ double row_post(const PT& P, const RowPost& rp, int i
     return isnan(P.optimum) ? f : f - P.optimum;
 }
 
-template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0>
+// KIND: the caller knows the function kind at compile time (k_rlepso_run's per-kind generation loops): every other kind's code is compiled out.
+template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0, int KIND = 0>
 __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* post = nullptr)
 {
-    if (P.kind == MBX_KIND_PROTEIN) {
-        eval_rows_protein<DC, PT, protein_prefetch(DC)>(P, L, n);
-        if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
-        return;
+    if constexpr (KIND == 0) {
+        if (P.kind == MBX_KIND_PROTEIN) {
+            eval_rows_protein<DC, PT, protein_prefetch(DC)>(P, L, n);
+            if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
+            return;
+        }
     }
     constexpr bool CMP = DC == MBX_COMPOSITE_DC;                   // composite out-of-line transforms (osc1_composite): the headline geometry only
-    const int D = DC ? DC : P.dim, NE = n * D, kind = P.kind, tid = opaque_tid();
+    const int D = DC ? DC : P.dim, NE = n * D, kind = KIND ? KIND : P.kind, tid = opaque_tid();
     const double ub = P.ub, bias = P.bias;
     const double* X = L.X;
     double* Z = L.Z;
@@ -1173,7 +1176,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
 // cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
 // rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
 // (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
-template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0>
+template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0, int KIND = 0>
 __device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
@@ -1182,7 +1185,7 @@ __device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, 
     for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, post, i, L.X[i * P.dim] * L.X[i * P.dim] + P.bias);
     __syncthreads();
 #else
-    eval_rows<DC, MD, PT, KC>(P, L, n, &post);
+    eval_rows<DC, MD, PT, KC, KIND>(P, L, n, &post);
 #endif
 }
 

@@ -154,7 +154,7 @@ __device__ __forceinline__ void rl_commit(const RlLds& L, int NP, int D, bool st
 
 // Everything the velocity phase needs, bundled so that the per-item routine can be a template on the item width.
 struct MoveCtx {
-    const RlLds& L; const BatchParams& bp; const double* tape; const Rng& rng; double* gPos; double* gVel;
+    const RlLds& L; const double* pci; const double* tape; const Rng& rng; double* gPos; double* gVel;
     const int* ORDER; const int* NLESS; const int* RANK; int NP, D, G; double lb, ub, vmax; const FastDiv& fg;
 };
 
@@ -315,7 +315,7 @@ __device__ __forceinline__ void rl_move(const MoveCtx& c, int i, int d0, double 
     if (g < c.G) { const double* k = L.COEF + g * 6; cw = k[1]; c1 = k[2]; c2 = k[3]; c3 = k[4]; c4 = k[5]; }
     double ucs[W]; int xrs[W];
     {
-        const double pci = c.bp.pci[i];
+        const double pci = c.pci[i];
         bool need = false;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
     __syncthreads();
 
     // ---- velocity / position update (:179-195).  A work item is W adjacent dimensions of one particle (W = 2 when D is even).
-    const MoveCtx mc{L, bp, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
+    const MoveCtx mc{L, bp.pci, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
     if ((D & 1) == 0) {
         const int HD = D >> 1, NI = NP * HD;
         const FastDiv fh(HD);
@@ -699,36 +699,41 @@ struct RunOut {
 #ifndef MBX_RUN_WAVES
 #define MBX_RUN_WAVES MBX_RL_WAVES
 #endif
-template <int THREADS, int NPC, int DC, int GC>
-__global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParams bp, const float* __restrict__ policy_table, int table_rows,
-                                                                     int n_gens, RunOut out)
+// The body of k_rlepso_run.  KIND != 0: the instance's function kind, known at compile time -- the evaluator (twice in the body: update and re-initialisation) holds that
+// kind's code only.
+// ARGS: a callable that returns (a reference to) the kernel's argument block -- the kernel's own parameters, or, out of line, the kernarg segment behind a pointer
+// that is re-materialised at every use (each field access a fresh scalar load next to its use: what the compiler does with a kernel's parameters by itself, and
+// what it cannot do with values a callee loaded once -- those stay in SGPRs across the whole body or are spilled).
+template <int THREADS, int NPC, int DC, int GC, int KIND, class ARGS>
+__device__ __forceinline__ void rl_run_body(ARGS ar)
 {
+    const int n_gens = ar().n_gens;
     static_assert(NPC > 0 && DC > 0 && GC > 0 && (DC & 1) == 0 && NPC <= THREADS, "k_rlepso_run: compile-time geometry, even D, NP <= THREADS");
     constexpr int NP = NPC, D = DC, G = GC, HD = D / 2, NI = NP * HD, IT = (NI + THREADS - 1) / THREADS, A = 7 * G;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = bp.order[blockIdx.x], tid0 = threadIdx.x, tid = tid0;
-    double* S = bp.state + (int64_t)b * bp.state_stride;
+    const int b = ar().bp.order[blockIdx.x], tid0 = threadIdx.x, tid = tid0;
+    double* S = ar().bp.state + (int64_t)b * ar().bp.state_stride;
     double* sc = S + MBX_RLEPSO_ST_SCALARS(NP, D);
-    const int64_t B = bp.B;
+    const int64_t B = ar().bp.B;
 
     if (sc[MBX_SC_DONE] != 0.) {                                  // finished before the launch: what k_rlepso_step reports for it, n_gens times
-        const double st = sc[MBX_SC_FES] / bp.max_fes;
+        const double st = sc[MBX_SC_FES] / ar().bp.max_fes;
         for (int g = tid; g < n_gens; g += THREADS) {
-            if (out.traj_state) out.traj_state[g * B + b] = st;
-            if (out.traj_reward) out.traj_reward[g * B + b] = 0.;
-            if (out.traj_done) out.traj_done[g * B + b] = 1;
+            if (ar().out.traj_state) ar().out.traj_state[g * B + b] = st;
+            if (ar().out.traj_reward) ar().out.traj_reward[g * B + b] = 0.;
+            if (ar().out.traj_done) ar().out.traj_done[g * B + b] = 1;
         }
         if (tid == 0) {
-            if (out.state_out) out.state_out[b] = st;
-            if (out.reward_out) out.reward_out[b] = 0.;
-            if (out.done_out) out.done_out[b] = 1;
+            if (ar().out.state_out) ar().out.state_out[b] = st;
+            if (ar().out.reward_out) ar().out.reward_out[b] = 0.;
+            if (ar().out.done_out) ar().out.done_out[b] = 1;
         }
         return;
     }
-    ConstProblem& P = *(ConstProblem*)(bp.problems + bp.problem_idx[b]);
+    ConstProblem& P = *(ConstProblem*)(ar().bp.problems + ar().bp.problem_idx[b]);
     const RlLds L = rl_carve(smem, NP, D, rl_maps_in_lds(NPC, DC));
     int gen = (int)sc[MBX_SC_GEN];
-    const uint64_t seed = bp.seeds[b];
+    const uint64_t seed = ar().bp.seeds[b];
     const uint32_t episode = (uint32_t)(int)sc[MBX_SC_EPISODE];
     const double lb = P.lb, ub = P.ub, vmax = 0.1 * (ub - lb);
     double gbest = sc[MBX_SC_GBEST];
@@ -807,11 +812,11 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         // ---- agent.act: the action of this generation from row fes of the actor table (same draws as mbx_gauss_policy)
         if (tid < A) {
             int row = (int)fes;
-            row = row < table_rows ? row : table_rows - 1;
-            const float* ms = policy_table + (int64_t)row * 2 * A;
+            row = row < ar().table_rows ? row : ar().table_rows - 1;
+            const float* ms = ar().policy_table + (int64_t)row * 2 * A;
             const float a = sample_action(rng, tid, ms[tid], ms[A + tid], MBX_POLICY_RLEPSO);
             ACT[tid] = a;
-            if (out.traj_actions) out.traj_actions[((int64_t)g * B + b) * A + tid] = a;
+            if (ar().out.traj_actions) ar().out.traj_actions[((int64_t)g * B + b) * A + tid] = a;
         }
         if (tid < NP) { NLESS[tid] = 0; ORDER[tid] = tid; }
         if (tid == 0) *TIE = 0;
@@ -907,7 +912,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         __syncthreads();
         // ---- velocity / position update (:179-195): new position -> X, new velocity -> register
         {
-            const MoveCtx mc{L, bp, nullptr, rng, nullptr, nullptr, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
+            const MoveCtx mc{L, ar().bp.pci, nullptr, rng, nullptr, nullptr, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 const int it = tid + j * THREADS;
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         }
         __syncthreads();
         // ---- evaluate, update pbest / gbest and the stagnation counters (:198-233)
-        population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+        population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC), KIND>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
         fes += NP;
         commit(true, tid);
         // ---- re-initialisation (:238-239, 134-168)
@@ -949,24 +954,24 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
                 }
             }
             __syncthreads();
-            population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC)>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+            population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC), KIND>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
             fes += n_reinit;
             commit(false, tid);
         }
         // ---- logging, termination, reward (:241-261); every thread keeps the (block-uniform) counters, thread 0 writes the curve
-        if (fes >= (double)log_index * bp.log_interval) { log_index += 1; if (tid == 0) cost[cost_len] = gbest; cost_len += 1; }
-        done = fes >= bp.max_fes;
-        if (!isnan(P.optimum) && bp.early_stop) done = done || gbest <= 1e-8;
+        if (fes >= (double)log_index * ar().bp.log_interval) { log_index += 1; if (tid == 0) cost[cost_len] = gbest; cost_len += 1; }
+        done = fes >= ar().bp.max_fes;
+        if (!isnan(P.optimum) && ar().bp.early_stop) done = done || gbest <= 1e-8;
         if (done) {
-            if (cost_len >= bp.n_logpoint + 1) { if (tid == 0) cost[cost_len - 1] = gbest; }
+            if (cost_len >= ar().bp.n_logpoint + 1) { if (tid == 0) cost[cost_len - 1] = gbest; }
             else { if (tid == 0) cost[cost_len] = gbest; cost_len += 1; }
         }
         const double reward = gbest < pre_gbest ? 1. : -1.;
         ret += reward;
         if (tid == 0) {
-            if (out.traj_state) out.traj_state[g * B + b] = fes / bp.max_fes;
-            if (out.traj_reward) out.traj_reward[g * B + b] = reward;
-            if (out.traj_done) out.traj_done[g * B + b] = done ? 1 : 0;
+            if (ar().out.traj_state) ar().out.traj_state[g * B + b] = fes / ar().bp.max_fes;
+            if (ar().out.traj_reward) ar().out.traj_reward[g * B + b] = reward;
+            if (ar().out.traj_done) ar().out.traj_done[g * B + b] = done ? 1 : 0;
         }
     }
     // ---- store the state block once
@@ -985,19 +990,74 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         S[MBX_RLEPSO_ST_CCOST(NP, D) + tid] = cc;
     }
     if (tid < D) S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid] = L.GB[tid];
-    const double st = fes / bp.max_fes;
+    const double st = fes / ar().bp.max_fes;
     for (int t = g + tid; t < n_gens; t += THREADS) {            // generations after the instance finished
-        if (out.traj_state) out.traj_state[t * B + b] = st;
-        if (out.traj_reward) out.traj_reward[t * B + b] = 0.;
-        if (out.traj_done) out.traj_done[t * B + b] = 1;
+        if (ar().out.traj_state) ar().out.traj_state[t * B + b] = st;
+        if (ar().out.traj_reward) ar().out.traj_reward[t * B + b] = 0.;
+        if (ar().out.traj_done) ar().out.traj_done[t * B + b] = 1;
     }
     if (tid == 0) {
         sc[MBX_SC_GBEST] = gbest; sc[MBX_SC_FES] = fes; sc[MBX_SC_LOG_INDEX] = log_index; sc[MBX_SC_COST_LEN] = cost_len;
         sc[MBX_SC_DONE] = done ? 1. : 0.; sc[MBX_SC_RETURN] += ret; sc[MBX_SC_GEN] = gen;
         sc[MBX_SC_GBEST_IDX] = gbest_idx; sc[MBX_SC_REINIT] = n_reinit > 0 ? 1. : 0.;
-        if (out.state_out) out.state_out[b] = st;
-        if (out.reward_out) out.reward_out[b] = ret;
-        if (out.done_out) out.done_out[b] = done ? 1 : 0;
+        if (ar().out.state_out) ar().out.state_out[b] = st;
+        if (ar().out.reward_out) ar().out.reward_out[b] = ret;
+        if (ar().out.done_out) ar().out.done_out[b] = done ? 1 : 0;
+    }
+}
+
+
+// The kernel's arguments as the kernarg segment lays them out (a callee cannot name the kernel's parameters; it is handed the segment's address)
+struct RlRunArgs {
+    BatchParams bp;
+    const float* policy_table;
+    int32_t table_rows, n_gens;
+    RunOut out;
+};
+
+// rl_run_body out of line, one instantiation per function kind: register-allocated and scheduled without the other kinds' code (a build of the any-kind kernel with every
+// kind but one compiled out of the evaluator ran a one-function batch 8-12 % faster: docs/EXPERIMENTS.md).  In a callee s[8:9] is the IMPLICIT argument pointer, so the
+// address of the kernel's argument block is an argument; every field access goes through that address (see rl_run_body).
+template <int THREADS, int NPC, int DC, int GC, int KIND>
+__device__ __noinline__ void rl_run_body_of_kind(uint32_t karg_lo_, uint32_t karg_hi_)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_lo_), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_hi_);
+    typedef const RlRunArgs __attribute__((address_space(4))) CArgs;
+    auto ar = [&]() -> CArgs& {
+        uintptr_t p = (uintptr_t)(((uint64_t)hi << 32) | lo);
+        asm volatile("" : "+s"(p));
+        return *(CArgs*)p;
+    };
+    rl_run_body<THREADS, NPC, DC, GC, KIND>(ar);
+}
+
+// per-kind bodies for the geometries of configs 1 / 2 (D = 10) and 5 (D = 40): the 24 BBOB kinds (rl_run_kind_ok; the noisy functions share them); the other
+// geometries run the any-kind body inline.  Same-box A/B against the any-kind kernel: D = 10 117.6 -> 113.0 us per generation, D = 40 1.602 -> 1.585 ms.
+__host__ __device__ constexpr bool rl_run_per_kind(int DC) { return DC == 10 || DC == 40; }
+__host__ __device__ constexpr bool rl_run_kind_ok(int kind) { return kind >= 1 && kind <= 24; }
+
+template <int THREADS, int NPC, int DC, int GC>
+__global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParams bp, const float* __restrict__ policy_table, int table_rows,
+                                                                     int n_gens, RunOut out)
+{
+    if constexpr (rl_run_per_kind(DC)) {
+        static_assert(sizeof(RlRunArgs) == sizeof(BatchParams) + 8 + 8 + sizeof(RunOut), "RlRunArgs mirrors the kernel's parameter list");
+        const uint64_t karg = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        const uint32_t klo = (uint32_t)karg, khi = (uint32_t)(karg >> 32);
+        const int kind = __builtin_amdgcn_readfirstlane(bp.problems[bp.problem_idx[bp.order[blockIdx.x]]].kind);
+#define MBX_RL_KIND(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K>(klo, khi); break;
+        switch (kind) {
+        MBX_RL_KIND(1) MBX_RL_KIND(2) MBX_RL_KIND(3) MBX_RL_KIND(4) MBX_RL_KIND(5) MBX_RL_KIND(6) MBX_RL_KIND(7) MBX_RL_KIND(8)
+        MBX_RL_KIND(9) MBX_RL_KIND(10) MBX_RL_KIND(11) MBX_RL_KIND(12) MBX_RL_KIND(13) MBX_RL_KIND(14) MBX_RL_KIND(15) MBX_RL_KIND(16)
+        MBX_RL_KIND(17) MBX_RL_KIND(18) MBX_RL_KIND(19) MBX_RL_KIND(20) MBX_RL_KIND(21) MBX_RL_KIND(22) MBX_RL_KIND(23) MBX_RL_KIND(24)
+        default: __builtin_trap();                                  // (mbx_rlepso_rollout sends batches with any other kind through the per-generation route)
+        }
+#undef MBX_RL_KIND
+    } else {
+        typedef const RlRunArgs __attribute__((address_space(4))) CArgs;
+        rl_run_body<THREADS, NPC, DC, GC, 0>([]() -> CArgs& {
+            return *(CArgs*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        });
     }
 }
 

@@ -11,7 +11,7 @@ from metabox_amd.config import get_config
 from metabox_amd.problem.bbob import BBOB_Dataset
 from metabox_amd.suite import Batch, Suite
 
-ap = argparse.ArgumentParser(); ap.add_argument('--dims', default='10,40'); ap.add_argument('--gens', type=int, default=12)
+ap = argparse.ArgumentParser(); ap.add_argument('--dims', default='10,40'); ap.add_argument('--gens', type=int, default=12); ap.add_argument('--kinds', default='')
 a = ap.parse_args()
 out = {}
 for dim in [int(x) for x in a.dims.split(',')]:
@@ -24,6 +24,7 @@ for dim in [int(x) for x in a.dims.split(',')]:
     actor = agent.actor; h1, h2 = actor.hidden_sizes()
     res = {}
     for k, p in enumerate(ps):
+        if a.kinds and str(p.kind) not in a.kinds.split(','): continue
         b = Batch(s, ALGO_RLEPSO, np.full(B, k), np.arange(B, dtype=np.uint64) + 3, NP, 2000 * dim, 40 * dim, 50, early_stop=False)
         table = b.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
         b.reset(); b.rlepso_rollout(table, 2); torch.cuda.synchronize()
