@@ -1,5 +1,5 @@
 // mbx.hip — libmbx.so: kernels' launch code and the C-ABI of include/mbx.h.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared mbx.hip -o libmbx.so
+// Build: make -C metabox_amd/csrc  (three translation units: this file, mbx_run_rlepso.hip, mbx_run_lde.hip); one file: hipcc ... -DMBX_SINGLE_TU -shared mbx.hip -o libmbx.so
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -14,9 +14,6 @@
 #include "mbx_device.hpp"
 #include "mbx_rlepso.hpp"
 #include "mbx_lde.hpp"
-#ifndef MBX_RUN10_THREADS
-#define MBX_RUN10_THREADS kThreads      // workgroup size of the headline resident kernel k_rlepso_run<., 100, 10, 5> (A/B knob; 128 threads at 3 waves per SIMD, no spills: 158.9 against 117.1 us per generation)
-#endif
 #ifndef MBX_LDE100_STEP_THREADS
 #define MBX_LDE100_STEP_THREADS 512
 #endif
@@ -35,6 +32,12 @@
 #include "mbx_qlpso.hpp"
 #include "mbx_gleet_policy.hpp"
 #include "mbx_classic.hpp"
+// k_rlepso_run / k_lde_run are compiled in translation units of their own (mbx_run_rlepso.hip, mbx_run_lde.hip) and only declared here;
+// -DMBX_SINGLE_TU (instrumented builds: the phase counters are a __device__ array, one copy per translation unit) instantiates them in this file instead
+#ifndef MBX_SINGLE_TU
+#define MBX_RUN_KERNELS_EXTERN
+#endif
+#include "mbx_run_kernels.hpp"
 
 using namespace mbx;
 
@@ -965,7 +968,7 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
         ka.bp = make_params(b);
         {   // the weights may have changed since the last call: rebuild the k-blocked copy the kernel reads (one small launch, ~3 us)
             const LstmPolicy src{net->d_weights, net->in_dim, net->hidden, net->out_dim};
-            hipLaunchKernelGGL(k_lde_repack, dim3(64), dim3(256), 0, (hipStream_t)stream, src, b->d_lstm_pack);
+            hipLaunchKernelGGL(k_lde_repack<0>, dim3(64), dim3(256), 0, (hipStream_t)stream, src, b->d_lstm_pack);
         }
         ka.net = LstmPolicy{b->d_lstm_pack, net->in_dim, net->hidden, net->out_dim};
         ka.state_in = d_state_in; ka.hbuf = d_h; ka.cbuf = d_c; ka.n_gens = n_gens;

@@ -48,6 +48,7 @@ __host__ __device__ inline int64_t lde_run_pack_floats(int IN, int H, int A)
     const int64_t K1 = IN + H, G4 = 4 * H;
     return 4 * ((K1 + 3) / 4) * G4 + G4 + 2 * 4 * (int64_t)((H + 3) / 4) * A + 2 * A;
 }
+template <int UNUSED = 0>
 __global__ void k_lde_repack(LstmPolicy net, float* __restrict__ dst)
 {
     const int IN = net.in_dim, H = net.hidden, A = net.out_dim, K1 = IN + H, G4 = 4 * H, KB1 = (K1 + 3) / 4, KBH = (H + 3) / 4;
@@ -763,8 +764,7 @@ void k_lde_run(LdeRunArgs args_)
 {
     (void)args_;                                                   // read through lde_run_args()
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
-    constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
+    constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, K1 = IN + H, NF = NP + 2 * MBX_LDE_BINS;
     static_assert(D > 16 && D <= 32, "two 16-column tiles");
     const LdeRunLds L = lde_run_carve(smem, NP, D, H);
     int b, gen0, episode, n_gens, kind0;

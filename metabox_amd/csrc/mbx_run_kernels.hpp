@@ -1,0 +1,15 @@
+// mbx_run_kernels.hpp — the resident-rollout kernels that are compiled in translation units of their own (mbx_run_rlepso.hip, mbx_run_lde.hip): mbx.hip sees
+// explicit instantiation DECLARATIONS (no device code, the host-side launch stub is resolved at link time), the other two files hold the definitions.
+#pragma once
+#ifndef MBX_RUN10_THREADS
+#define MBX_RUN10_THREADS 256           // workgroup size of the headline resident kernel k_rlepso_run<., 100, 10, 5> (A/B knob; 128 threads at 3 waves per SIMD, no spills: 158.9 against 117.1 us per generation)
+#endif
+#ifdef MBX_RUN_KERNELS_EXTERN
+namespace mbx {
+extern template __global__ void k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>(BatchParams, const float*, int, int, RunOut);
+extern template __global__ void k_rlepso_run<1024, 128, 40, 5>(BatchParams, const float*, int, int, RunOut);
+extern template __global__ void k_rlepso_run<512, 100, 30, 5>(BatchParams, const float*, int, int, RunOut);
+extern template __global__ void k_lde_run<100, 30>(LdeRunArgs);
+extern template __global__ void k_lde_run<50, 30>(LdeRunArgs);
+}  // namespace mbx
+#endif
