@@ -459,7 +459,7 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     const int n_instances = b->B;
     auto weight = [&](int pi) -> int {
         const int k = s->h_problems[pi].kind;
-        // per-kind weights = ns per instance-generation x 10 of the resident RLEPSO kernel, tools/kbench_costs.py at the round-4 head (the table
+        // per-kind weights = ns per instance-generation x 10 of the resident RLEPSO kernel, tools/kbench_costs.py at the round-4 head, per-kind bodies (the table
         // metabox_amd/distributed.py: COST_NS holds for the inter-rank partition): D = 40 / NP = 128 for the large dimensions, D = 10 / NP = 100 otherwise
         if (b->cfg.algo == MBX_ALGO_LDE && s->dim >= 16 && k != MBX_KIND_PROTEIN) {
             // LDE at D = 30 (k_lde_run, pop 100; tools/exp/lde_run.py --functions, round 4): us per generation of 16 384 instances of that kind / 10.  The cost
@@ -471,20 +471,20 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
         }
         if (s->dim >= 16 && k != MBX_KIND_PROTEIN) {
             switch (k) {
-            case 21: return 3094; case 22: return 2433; case 16: return 2414; case 15: return 2377; case 17: return 2348; case 18: return 2340;
-            case 3: return 2187; case 23: return 2116; case 4: return 2048; case 2: return 1964; case 12: return 1926; case 7: return 1889;
-            case 11: return 1868; case 10: return 1862; case 24: return 1803; case 14: return 1730; case 19: return 1718; case 1: return 1706;
-            case 20: return 1636; case 6: return 1614; case 8: return 1593; case 9: return 1591; case 13: return 1572; case 5: return 1416;
-            default: return 1700;
+            case 21: return 3016; case 22: return 2378; case 16: return 2342; case 15: return 2285; case 18: return 2283; case 17: return 2255;
+            case 3: return 2077; case 23: return 2049; case 4: return 1980; case 7: return 1885; case 12: return 1840; case 2: return 1787;
+            case 11: return 1784; case 10: return 1783; case 24: return 1682; case 14: return 1656; case 19: return 1607; case 1: return 1588;
+            case 6: return 1566; case 8: return 1533; case 9: return 1528; case 20: return 1526; case 13: return 1499; case 5: return 1334;
+            default: return 1886;
             }
         }
         switch (k) {
         case MBX_KIND_PROTEIN: return 30000;
-        case 21: return 399; case 3: return 365; case 16: return 343; case 15: return 338; case 17: return 331; case 4: return 330;
-        case 18: return 328; case 23: return 323; case 2: return 314; case 11: return 293; case 10: return 290; case 12: return 286;
-        case 7: return 285; case 22: return 282; case 6: return 276; case 1: return 271; case 14: return 269; case 19: case 20: return 265;
-        case 5: case 24: return 260; case 8: return 256; case 9: return 251; case 13: return 245;
-        default: return 270;
+        case 21: return 396; case 3: return 329; case 16: return 327; case 23: return 322; case 15: return 315; case 17: return 311;
+        case 18: return 311; case 2: return 296; case 4: return 294; case 22: return 290; case 10: return 270; case 11: return 268;
+        case 12: return 264; case 1: return 260; case 24: return 255; case 7: return 253; case 14: return 250; case 6: return 245;
+        case 19: return 244; case 20: return 243; case 8: return 231; case 9: return 228; case 13: return 223; case 5: return 200;
+        default: return 276;
         }
     };
     b->lde_run_kinds_ok = true;
@@ -493,7 +493,11 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind);
     std::vector<int32_t> order(n_instances);
     for (int i = 0; i < n_instances; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return weight(problem_idx[a]) > weight(problem_idx[c]); });
+    // equal weights: by kind, so that neighbours in the launch order -- the workgroups that share a CU -- run the same per-kind body (k_rlepso_run, k_lde_run)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+        const int wa = weight(problem_idx[a]), wc = weight(problem_idx[c]);
+        return wa != wc ? wa > wc : s->h_problems[problem_idx[a]].kind < s->h_problems[problem_idx[c]].kind;
+    });
     if (!b->d_order) HIP_TRY(hipMalloc(&b->d_order, n_instances * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(b->d_order, order.data(), n_instances * sizeof(int32_t), hipMemcpyHostToDevice));
     return MBX_OK;

@@ -27,13 +27,13 @@ def instance_table(n_problems, runs, sort_by_problem=True):
 
 
 # ns per instance-generation of the RLEPSO generation kernel by BBOB function kind (1..24), measured on one MI355X with tools/kbench_costs.py
-# (a batch that holds one kind only, fixed horizon, resident rollout; re-measured at the round-4 head: gpurun_out/costs.json) at D = 10 / NP = 100, D = 30 / NP = 100 and
+# (a batch that holds one kind only, fixed horizon, resident rollout; re-measured at the round-4 head with the per-kind kernel bodies: profiles/r04e_kind_costs_ns.json; D = 30: before them) at D = 10 / NP = 100, D = 30 / NP = 100 and
 # D = 40 / NP = 128.  Only the RATIOS matter: they weight the inter-rank partition below and -- the same numbers, rounded -- the launch order inside a batch
 # (upload_launch_order in csrc/mbx.hip).  Noisy functions cost what their base kind costs (the noise is O(NP) per generation).
 COST_NS = {
-    10: {1: 27.07, 2: 31.38, 3: 36.52, 4: 32.96, 5: 26.02, 6: 27.64, 7: 28.51, 8: 25.59, 9: 25.12, 10: 28.97, 11: 29.27, 12: 28.57, 13: 24.49, 14: 26.87, 15: 33.82, 16: 34.26, 17: 33.08, 18: 32.85, 19: 26.5, 20: 26.54, 21: 39.9, 22: 28.19, 23: 32.28, 24: 26.03},
+    10: {1: 26.01, 2: 29.65, 3: 32.93, 4: 29.37, 5: 20.05, 6: 24.52, 7: 25.34, 8: 23.1, 9: 22.82, 10: 26.95, 11: 26.83, 12: 26.39, 13: 22.29, 14: 25.01, 15: 31.54, 16: 32.72, 17: 31.07, 18: 31.06, 19: 24.38, 20: 24.31, 21: 39.61, 22: 28.99, 23: 32.19, 24: 25.47},
     30: {1: 84.86, 2: 100.99, 3: 112.79, 4: 102.7, 5: 73.29, 6: 81.22, 7: 90.62, 8: 78.32, 9: 78.39, 10: 91.78, 11: 91.66, 12: 93.63, 13: 76.91, 14: 84.95, 15: 112.8, 16: 118.18, 17: 113.17, 18: 113.63, 19: 83.24, 20: 80.5, 21: 144.75, 22: 97.63, 23: 104.35, 24: 86.63},
-    40: {1: 170.55, 2: 196.38, 3: 218.71, 4: 204.83, 5: 141.62, 6: 161.38, 7: 188.86, 8: 159.29, 9: 159.13, 10: 186.16, 11: 186.83, 12: 192.59, 13: 157.15, 14: 173.03, 15: 237.71, 16: 241.36, 17: 234.78, 18: 233.98, 19: 171.84, 20: 163.6, 21: 309.43, 22: 243.34, 23: 211.59, 24: 180.31},
+    40: {1: 158.85, 2: 178.7, 3: 207.74, 4: 198.05, 5: 133.42, 6: 156.57, 7: 188.54, 8: 153.28, 9: 152.78, 10: 178.33, 11: 178.44, 12: 183.99, 13: 149.94, 14: 165.65, 15: 228.47, 16: 234.17, 17: 225.47, 18: 228.29, 19: 160.72, 20: 152.6, 21: 301.57, 22: 237.76, 23: 204.9, 24: 168.18},
 }
 
 
