@@ -17,14 +17,17 @@ env.reset()
 packed = agent.packed_weights()
 for _ in range(120): env.step(env.batch.ddqn_qnet(packed))          # past the first sweep: the OM_W window is full
 torch.cuda.synchronize()
-ph = (C.c_ulonglong * 16)(); env.batch.lib.mbx_debug_phase_cycles(ph, 16, 1)
+ph = (C.c_ulonglong * 16)()
+try: dbg = env.batch.lib.mbx_debug_phase_cycles            # instrumented builds only
+except AttributeError: dbg = lambda *a: 0
+dbg(ph, 16, 1)
 n = 100
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a = env.batch.ddqn_qnet(packed)
 e0.record()
 for _ in range(n): env.step(a)
 e1.record(); torch.cuda.synchronize()
-env.batch.lib.mbx_debug_phase_cycles(ph, 16, 1)
+dbg(ph, 16, 1)
 v = np.array(list(ph), dtype=np.float64)
 names = ['staging', 'mutation', 'evaluation', 'median', 'window', 'bookkeeping', 'selection', 'features', 'write-back']
 print(json.dumps({'lib': os.path.basename(os.environ.get('MBX_LIB', 'libmbx.so')), 'k_dq_step_us': e0.elapsed_time(e1) / n * 1e3,
