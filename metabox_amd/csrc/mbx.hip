@@ -489,7 +489,7 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     };
     b->lde_run_kinds_ok = true;
     b->rl_run_kinds_ok = true;
-    for (int i = 0; i < n_instances; ++i) b->rl_run_kinds_ok = b->rl_run_kinds_ok && rl_run_kind_ok(s->h_problems[problem_idx[i]].kind);
+    for (int i = 0; i < n_instances; ++i) b->rl_run_kinds_ok = b->rl_run_kinds_ok && rl_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->h_problems[problem_idx[i]].noise_kind);
     for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind);
     std::vector<int32_t> order(n_instances);
     for (int i = 0; i < n_instances; ++i) order[i] = i;

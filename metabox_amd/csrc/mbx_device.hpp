@@ -669,10 +669,11 @@ struct RowPost {
     const Rng* rng; const double* tape_noise; uint32_t siteA, siteB; int n_total;
 };
 
-template <class PT>
+// NOISE: what the caller knows at compile time -- -1 nothing (the problem record decides), 0 a noise-free function (the noise models are compiled out), 1 a noisy one
+template <class PT, int NOISE = -1>
 __device__ __forceinline__ double row_post(const PT& P, const RowPost& rp, int i, double f)
 {
-    if (P.noise_kind != MBX_NOISE_NONE) {
+    if (NOISE != 0 && (NOISE == 1 || P.noise_kind != MBX_NOISE_NONE)) {
         double a, b, c;
         if (rp.tape_noise) { a = rp.tape_noise[i]; b = rp.tape_noise[rp.n_total + i]; c = rp.tape_noise[2 * rp.n_total + i]; }
         else philox_noise(*rp.rng, (uint32_t)i, rp.siteA, rp.siteB, P.noise_kind, a, b, c);
@@ -681,8 +682,8 @@ __device__ __forceinline__ double row_post(const PT& P, const RowPost& rp, int i
     return isnan(P.optimum) ? f : f - P.optimum;
 }
 
-// KIND: the caller knows the function kind at compile time (k_rlepso_run's per-kind generation loops): every other kind's code is compiled out.
-template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0, int KIND = 0>
+// KIND: the caller knows the function kind at compile time (k_rlepso_run's per-kind bodies): every other kind's code is compiled out.  NOISE: see row_post.
+template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0, int KIND = 0, int NOISE = -1>
 __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* post = nullptr)
 {
     if constexpr (KIND == 0) {
@@ -1167,7 +1168,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
         }
         default: f = NAN; break;
         }
-        F[i] = post ? row_post(P, *post, i, f) : f;
+        F[i] = post ? row_post<PT, NOISE>(P, *post, i, f) : f;
     }
     __syncthreads();
 }
@@ -1176,7 +1177,7 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
 // cost_i = problem.eval(x_i) [- optimum] for the n rows staged in L.X (the __get_costs of every optimizer, e.g.
 // rlepso_optimizer.py:68-74): objective, then NoisyProblem's noise with draws from the replay tape ([3, n] rows) or from Philox
 // (sites siteA / siteB, row index = draw index), then the optimum.  Results in L.F; ends with a barrier.  All threads call.
-template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0, int KIND = 0>
+template <int DC = 0, int MD = 0, class PT = DevProblem, int KC = 0, int KIND = 0, int NOISE = -1>
 __device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, int n, const Rng& rng, const double* tape_noise,
                                                  uint32_t siteA, uint32_t siteB)
 {
@@ -1185,7 +1186,7 @@ __device__ __forceinline__ void population_costs(const PT& P, const EvalLds& L, 
     for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, post, i, L.X[i * P.dim] * L.X[i * P.dim] + P.bias);
     __syncthreads();
 #else
-    eval_rows<DC, MD, PT, KC, KIND>(P, L, n, &post);
+    eval_rows<DC, MD, PT, KC, KIND, NOISE>(P, L, n, &post);
 #endif
 }
 

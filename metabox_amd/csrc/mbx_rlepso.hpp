@@ -704,7 +704,7 @@ struct RunOut {
 // ARGS: a callable that returns (a reference to) the kernel's argument block -- the kernel's own parameters, or, out of line, the kernarg segment behind a pointer
 // that is re-materialised at every use (each field access a fresh scalar load next to its use: what the compiler does with a kernel's parameters by itself, and
 // what it cannot do with values a callee loaded once -- those stay in SGPRs across the whole body or are spilled).
-template <int THREADS, int NPC, int DC, int GC, int KIND, class ARGS>
+template <int THREADS, int NPC, int DC, int GC, int KIND, int NOISE, class ARGS>
 __device__ __forceinline__ void rl_run_body(ARGS ar)
 {
     const int n_gens = ar().n_gens;
@@ -926,7 +926,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
         }
         __syncthreads();
         // ---- evaluate, update pbest / gbest and the stagnation counters (:198-233)
-        population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC), KIND>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
+        population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC), KIND, NOISE>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B);
         fes += NP;
         commit(true, tid);
         // ---- re-initialisation (:238-239, 134-168)
@@ -954,7 +954,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
                 }
             }
             __syncthreads();
-            population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC), KIND>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
+            population_costs<eval_dc(DC), eval_md(DC), ConstProblem, rl_run_matvec_chunk(DC), KIND, NOISE>(P, L.eval(), NP, rng, nullptr, MBX_SITE_NOISE1_A, MBX_SITE_NOISE1_B);
             fes += n_reinit;
             commit(false, tid);
         }
@@ -1018,7 +1018,7 @@ struct RlRunArgs {
 // rl_run_body out of line, one instantiation per function kind: register-allocated and scheduled without the other kinds' code (a build of the any-kind kernel with every
 // kind but one compiled out of the evaluator ran a one-function batch 8-12 % faster: docs/EXPERIMENTS.md).  In a callee s[8:9] is the IMPLICIT argument pointer, so the
 // address of the kernel's argument block is an argument; every field access goes through that address (see rl_run_body).
-template <int THREADS, int NPC, int DC, int GC, int KIND>
+template <int THREADS, int NPC, int DC, int GC, int KIND, int NOISE>
 __device__ __noinline__ void rl_run_body_of_kind(uint32_t karg_lo_, uint32_t karg_hi_)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_lo_), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_hi_);
@@ -1028,13 +1028,18 @@ __device__ __noinline__ void rl_run_body_of_kind(uint32_t karg_lo_, uint32_t kar
         asm volatile("" : "+s"(p));
         return *(CArgs*)p;
     };
-    rl_run_body<THREADS, NPC, DC, GC, KIND>(ar);
+    rl_run_body<THREADS, NPC, DC, GC, KIND, NOISE>(ar);
 }
 
-// per-kind bodies for the geometries of configs 1 / 2 (D = 10) and 5 (D = 40): the 24 BBOB kinds (rl_run_kind_ok; the noisy functions share them); the other
-// geometries run the any-kind body inline.  Same-box A/B against the any-kind kernel: D = 10 117.6 -> 113.0 us per generation, D = 40 1.602 -> 1.585 ms.
+// per-kind bodies for the geometries of configs 1 / 2 (D = 10) and 5 (D = 40): the 24 noise-free BBOB kinds with the noise models compiled out (another
+// +2 % on the headline) + the eight kinds of the noisy suite with them (rl_run_kind_ok); the other geometries run the any-kind body inline.  Same-box A/B against the any-kind kernel: D = 10 117.6 -> 113.0 us per generation, D = 40 1.602 -> 1.585 ms.
 __host__ __device__ constexpr bool rl_run_per_kind(int DC) { return DC == 10 || DC == 40; }
-__host__ __device__ constexpr bool rl_run_kind_ok(int kind) { return kind >= 1 && kind <= 24; }
+// a body exists for: the 24 noise-free BBOB kinds; with noise, the eight kinds of the noisy suite (problem/bbob.py: _NOISY)
+__host__ __device__ constexpr bool rl_run_kind_ok(int kind, int noise_kind)
+{
+    return noise_kind == MBX_NOISE_NONE ? (kind >= 1 && kind <= 24)
+                                        : (kind == 1 || kind == 7 || kind == 8 || kind == 10 || kind == 14 || kind == 17 || kind == 19 || kind == 21);
+}
 
 template <int THREADS, int NPC, int DC, int GC>
 __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParams bp, const float* __restrict__ policy_table, int table_rows,
@@ -1044,18 +1049,29 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         static_assert(sizeof(RlRunArgs) == sizeof(BatchParams) + 8 + 8 + sizeof(RunOut), "RlRunArgs mirrors the kernel's parameter list");
         const uint64_t karg = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         const uint32_t klo = (uint32_t)karg, khi = (uint32_t)(karg >> 32);
-        const int kind = __builtin_amdgcn_readfirstlane(bp.problems[bp.problem_idx[bp.order[blockIdx.x]]].kind);
-#define MBX_RL_KIND(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K>(klo, khi); break;
-        switch (kind) {
-        MBX_RL_KIND(1) MBX_RL_KIND(2) MBX_RL_KIND(3) MBX_RL_KIND(4) MBX_RL_KIND(5) MBX_RL_KIND(6) MBX_RL_KIND(7) MBX_RL_KIND(8)
-        MBX_RL_KIND(9) MBX_RL_KIND(10) MBX_RL_KIND(11) MBX_RL_KIND(12) MBX_RL_KIND(13) MBX_RL_KIND(14) MBX_RL_KIND(15) MBX_RL_KIND(16)
-        MBX_RL_KIND(17) MBX_RL_KIND(18) MBX_RL_KIND(19) MBX_RL_KIND(20) MBX_RL_KIND(21) MBX_RL_KIND(22) MBX_RL_KIND(23) MBX_RL_KIND(24)
-        default: __builtin_trap();                                  // (mbx_rlepso_rollout sends batches with any other kind through the per-generation route)
+        const DevProblem* pr = bp.problems + bp.problem_idx[bp.order[blockIdx.x]];
+        const int kind = __builtin_amdgcn_readfirstlane(pr->kind);
+        const bool noisy = __builtin_amdgcn_readfirstlane(pr->noise_kind) != MBX_NOISE_NONE;
+#define MBX_RL_KIND(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K, 0>(klo, khi); break;
+#define MBX_RL_NOISY(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K, 1>(klo, khi); break;
+        if (noisy) {
+            switch (kind) {
+            MBX_RL_NOISY(1) MBX_RL_NOISY(7) MBX_RL_NOISY(8) MBX_RL_NOISY(10) MBX_RL_NOISY(14) MBX_RL_NOISY(17) MBX_RL_NOISY(19) MBX_RL_NOISY(21)
+            default: __builtin_trap();                              // (mbx_rlepso_rollout sends batches with any other function through the per-generation route)
+            }
+        } else {
+            switch (kind) {
+            MBX_RL_KIND(1) MBX_RL_KIND(2) MBX_RL_KIND(3) MBX_RL_KIND(4) MBX_RL_KIND(5) MBX_RL_KIND(6) MBX_RL_KIND(7) MBX_RL_KIND(8)
+            MBX_RL_KIND(9) MBX_RL_KIND(10) MBX_RL_KIND(11) MBX_RL_KIND(12) MBX_RL_KIND(13) MBX_RL_KIND(14) MBX_RL_KIND(15) MBX_RL_KIND(16)
+            MBX_RL_KIND(17) MBX_RL_KIND(18) MBX_RL_KIND(19) MBX_RL_KIND(20) MBX_RL_KIND(21) MBX_RL_KIND(22) MBX_RL_KIND(23) MBX_RL_KIND(24)
+            default: __builtin_trap();
+            }
         }
+#undef MBX_RL_NOISY
 #undef MBX_RL_KIND
     } else {
         typedef const RlRunArgs __attribute__((address_space(4))) CArgs;
-        rl_run_body<THREADS, NPC, DC, GC, 0>([]() -> CArgs& {
+        rl_run_body<THREADS, NPC, DC, GC, 0, -1>([]() -> CArgs& {
             return *(CArgs*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         });
     }
