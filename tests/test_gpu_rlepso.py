@@ -375,10 +375,11 @@ def _rollout_case(suite_name, dim, fids, np_, B, chunks, maxfes=None, resident=T
 
 def test_resident_rollout_equals_one_launch_per_generation():
     """mbx_rlepso_rollout (state on chip across the generations of a launch) == mbx_rlepso_act_step per generation, bit for bit, over
-    whole episodes in uneven chunks: early stops inside a launch, launches that start with finished instances, re-initialisations."""
-    r = _rollout_case('bbob', 10, (1, 3, 5, 16, 21, 24), 100, 96, (1, 7, 60, 3, 140))
+    whole episodes in uneven chunks: early stops inside a launch, launches that start with finished instances, re-initialisations.
+    Every function of both suites, so that every per-kind body of the resident kernel runs whole episodes against the one-generation kernel."""
+    r = _rollout_case('bbob', 10, tuple(range(1, 25)), 100, 96, (1, 7, 60, 3, 140))        # all 24 kinds: k_rlepso_run has one body per kind
     assert (r['steps'] < 199).any() and (r['fes'] >= 20000).any() and (r['fes'] % 100 != 0).any()      # re-initialisations bill odd FEs
-    r = _rollout_case('bbob-noisy', 10, (101, 105, 115, 122, 128, 130), 100, 60, (25, 180))
+    r = _rollout_case('bbob-noisy', 10, tuple(range(101, 131)), 100, 60, (25, 180))          # all 30 noisy functions: the eight bodies that carry the noise models
     assert (r['fes'] >= 20000).any()
 
 
