@@ -70,7 +70,7 @@ def prove_tie(ties, case, g, prev_cc, cur_cc, cur_pni, ledger, who):
         return True
     key = f'{case}/ccost'
     assert key in ties.files, (f'{who}: {case}: bookkeeping differs from the reference at generation {g}, but the fixture holds no reference '
-                               f'c_cost for this episode: add it to EXTRA_TIE_CASES in tools/gen_golden.py and regenerate rlepso_ties')
+                               f'c_cost for this episode: add it to EXTRA_TIE_CASES (rlepso_ties) / HD_EXTRA_TIE_CASES (rlepso_hd) in tools/gen_golden.py and regenerate that section')
     return prove_tie_arrays(ties[key][g], ties[key][g + 1], ref_pni, prev_cc, cur_cc, cur_pni, ledger, who, case, g)
 
 

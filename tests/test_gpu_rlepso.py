@@ -27,9 +27,84 @@ def env():
     return out
 
 
-def test_tape_replay_matches_reference_episodes(env):
+def _tape_replay_group(s, ids, TR, TIES, mine, NP, D, maxfes, ledger):
+    """Replay the reference episodes `mine` (all on suite `s`, one geometry) through mbx_set_tape + mbx_step; returns (episodes whose bookkeeping
+    is identical to the reference's in every generation, worst gbest relative error, launch info)."""
     from metabox_amd.suite import Batch
     from metabox_amd._abi import ALGO_RLEPSO
+    fid_of = lambda c: int(c.split('/')[-3])
+    seed_of = lambda c: int(c.split('/')[-2])
+    pidx = [ids.index(fid_of(c)) for c in mine]
+    B = len(mine)
+    batch = Batch(s, ALGO_RLEPSO, pidx, np.arange(B), NP, maxfes, maxfes // NLOG, NLOG)
+    info = batch.launch_info()
+    feeders = [oracle.NumpyTapeFeeder(seed_of(c), NP, D, s.problems[k].noise[0]) for c, k in zip(mine, pidx)]
+    acts = [TR[f'{c}/actions'] for c in mine]
+    G = max(len(a) for a in acts)
+    tape = np.stack([f.reset_tape() for f in feeders])
+    batch.set_tape(torch.from_numpy(tape).cuda())
+    batch.reset()
+    torch.cuda.synchronize()
+    prev = [oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG) for b in range(B)]
+    for b, c in enumerate(mine):
+        assert close(prev[b]['scalars'][oracle.SC_GBEST], TR[f'{c}/gbest0']), c
+    gb = np.full((B, G), np.nan); fes = np.full((B, G), np.nan); rw = np.zeros((B, G)); dn = np.zeros((B, G), bool)
+    alive = np.ones(B, bool)
+    exact_until = [len(a) for a in acts]          # generations [0, exact_until[b]) have bookkeeping identical to the reference's
+    for g in range(G):
+        a = np.zeros((B, 35), np.float32)
+        for b in range(B):
+            if alive[b]:
+                tape[b] = feeders[b].step_tape()
+                a[b] = acts[b][g]
+        batch.set_tape(torch.from_numpy(tape).cuda())
+        st, r, d = batch.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        r = r.cpu().numpy(); d = d.cpu().numpy()
+        for b in range(B):
+            if not alive[b]:
+                continue
+            cur = oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG)
+            sc = cur['scalars']
+            feeders[b].commit(sc[oracle.SC_REINIT] > 0)
+            gb[b, g] = sc[oracle.SC_GBEST]; fes[b, g] = sc[oracle.SC_FES]; rw[b, g] = r[b]; dn[b, g] = d[b]
+            if exact_until[b] == len(acts[b]) and not prove_tie(TIES, mine[b], g, prev[b]['ccost'], cur['ccost'], cur['pni'], ledger, 'hip'):
+                exact_until[b] = g
+            prev[b] = cur
+            if d[b]:
+                alive[b] = False
+                assert g == len(acts[b]) - 1, (mine[b], 'episode length', g, len(acts[b]))
+    assert not alive.any()
+    res = batch.results()
+    cost = res['cost'].cpu().numpy(); clen = res['cost_len'].cpu().numpy()
+    n_exact, worst = 0, 0.0
+    for b, c in enumerate(mine):
+        n = len(acts[b])
+        ref = TR[f'{c}/gbest']
+        assert close(gb[b, :n], ref), (c, 'gbest trajectory', np.nanmax(np.abs(gb[b, :n] - ref) / np.maximum(np.abs(ref), 1e-300)))
+        ref_cost = TR[f'{c}/cost']
+        assert clen[b] == len(ref_cost), c
+        assert close(cost[b, :clen[b]], ref_cost), c
+        assert np.all(cost[b, clen[b]:] == cost[b, clen[b] - 1])          # 51-padding rule (tester.py:204-205)
+        # integer-valued outputs: EXACT up to the first generation at which the bookkeeping leaves the reference's, and that
+        # generation is a proven near-tie (helpers.prove_tie); no mismatch budget
+        m = exact_until[b]
+        assert np.array_equal(fes[b, :m], TR[f'{c}/fes'][:m]), c
+        assert np.array_equal(rw[b, :m], TR[f'{c}/reward'][:m]), c
+        assert np.array_equal(dn[b, :m], TR[f'{c}/done'][:m]), c
+        if m == n:
+            fin = oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG)
+            assert np.array_equal(fin['pni'], TR[f'{c}/final_pni']), c
+            assert np.abs(fin['pos'].reshape(NP, D) - TR[f'{c}/final_pos']).max() <= 1e-9, c
+            assert close(fin['pbest'], TR[f'{c}/final_pbest'], rtol=1e-9), c
+        n_exact += int(m == n)
+        rel = np.abs(gb[b, :n] - ref) / np.maximum(np.abs(ref), 1e-12)
+        worst = max(worst, float(rel.max()))
+    batch.close()
+    return n_exact, worst, info
+
+
+def test_tape_replay_matches_reference_episodes(env):
     TR = load('rlepso_traces.npz')
     TIES = load('rlepso_ties.npz')
     cases = [str(c) for c in TR['cases']]
@@ -37,68 +112,39 @@ def test_tape_replay_matches_reference_episodes(env):
     for suite in ('bbob', 'bbob-noisy'):
         s, ids = env[suite]
         mine = [c for c in cases if c.split('/')[0] == suite]
-        pidx = [ids.index(int(c.split('/')[1])) for c in mine]
-        B = len(mine)
-        batch = Batch(s, ALGO_RLEPSO, pidx, np.arange(B), NP, MAXFES, LOGI, NLOG)
-        feeders = [oracle.NumpyTapeFeeder(int(c.split('/')[2]), NP, D, s.problems[k].noise[0]) for c, k in zip(mine, pidx)]
-        acts = [TR[f'{c}/actions'] for c in mine]
-        G = max(len(a) for a in acts)
-        tape = np.stack([f.reset_tape() for f in feeders])
-        batch.set_tape(torch.from_numpy(tape).cuda())
-        batch.reset()
-        torch.cuda.synchronize()
-        prev = [oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG) for b in range(B)]
-        for b, c in enumerate(mine):
-            assert close(prev[b]['scalars'][oracle.SC_GBEST], TR[f'{c}/gbest0']), c
-        gb = np.full((B, G), np.nan); fes = np.full((B, G), np.nan); rw = np.zeros((B, G)); dn = np.zeros((B, G), bool)
-        alive = np.ones(B, bool)
-        exact_until = [len(a) for a in acts]          # generations [0, exact_until[b]) have bookkeeping identical to the reference's
-        for g in range(G):
-            a = np.zeros((B, 35), np.float32)
-            for b in range(B):
-                if alive[b]:
-                    tape[b] = feeders[b].step_tape()
-                    a[b] = acts[b][g]
-            batch.set_tape(torch.from_numpy(tape).cuda())
-            st, r, d = batch.step(torch.from_numpy(a).cuda())
-            torch.cuda.synchronize()
-            r = r.cpu().numpy(); d = d.cpu().numpy()
-            for b in range(B):
-                if not alive[b]:
-                    continue
-                cur = oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG)
-                sc = cur['scalars']
-                feeders[b].commit(sc[oracle.SC_REINIT] > 0)
-                gb[b, g] = sc[oracle.SC_GBEST]; fes[b, g] = sc[oracle.SC_FES]; rw[b, g] = r[b]; dn[b, g] = d[b]
-                if exact_until[b] == len(acts[b]) and not prove_tie(TIES, mine[b], g, prev[b]['ccost'], cur['ccost'], cur['pni'], ledger, 'hip'):
-                    exact_until[b] = g
-                prev[b] = cur
-                if d[b]:
-                    alive[b] = False
-                    assert g == len(acts[b]) - 1, (mine[b], 'episode length', g, len(acts[b]))
-        assert not alive.any()
-        res = batch.results()
-        cost = res['cost'].cpu().numpy(); clen = res['cost_len'].cpu().numpy()
-        for b, c in enumerate(mine):
-            n = len(acts[b])
-            ref = TR[f'{c}/gbest']
-            assert close(gb[b, :n], ref), (c, 'gbest trajectory', np.nanmax(np.abs(gb[b, :n] - ref) / np.maximum(np.abs(ref), 1e-300)))
-            ref_cost = TR[f'{c}/cost']
-            assert clen[b] == len(ref_cost), c
-            assert close(cost[b, :clen[b]], ref_cost), c
-            assert np.all(cost[b, clen[b]:] == cost[b, clen[b] - 1])          # 51-padding rule (tester.py:204-205)
-            # integer-valued outputs: EXACT up to the first generation at which the bookkeeping leaves the reference's, and that
-            # generation is a proven near-tie (helpers.prove_tie); no mismatch budget
-            m = exact_until[b]
-            assert np.array_equal(fes[b, :m], TR[f'{c}/fes'][:m]), c
-            assert np.array_equal(rw[b, :m], TR[f'{c}/reward'][:m]), c
-            assert np.array_equal(dn[b, :m], TR[f'{c}/done'][:m]), c
-            n_exact += int(m == n)
-            rel = np.abs(gb[b, :n] - ref) / np.maximum(np.abs(ref), 1e-12)
-            worst = max(worst, float(rel.max()))
-        batch.close()
+        ne, w, info = _tape_replay_group(s, ids, TR, TIES, mine, NP, D, MAXFES, ledger)
+        assert info['fixed_geometry'] == 1, info
+        n_exact += ne; worst = max(worst, w)
     print(f'tape replay: {n_exact}/{len(cases)} episodes with bookkeeping identical to the reference in every generation; worst gbest rel err '
           f'{worst:.2e}; {len(ledger)} episodes leave it at a proven near-tie:')
+    print_ledger(ledger)
+
+
+# (dim, NP) -> the compile-time-geometry instantiation mbx_step must take: 7 = k_rlepso_step<512, 100, 30, 5> (bbob --dim 30, the geometry config 3's
+# suite runs RLEPSO at), 2 = k_rlepso_step<1024, 128, 40, 5> (BASELINE config 5), 0 = the run-time-geometry kernel (NP 100 at D 40: the reference as shipped)
+HD_GEOMETRIES = {(30, 100): 7, (40, 100): 0, (40, 128): 2}
+
+
+@pytest.mark.parametrize('dim,np_', sorted(HD_GEOMETRIES))
+def test_tape_replay_matches_reference_episodes_at_dim_30_and_40(dim, np_):
+    """Whole REFERENCE episodes at the geometries of BASELINE configs 3 / 5 (tools/gen_golden.py rlepso_hd: --dim 30 / 40 as shipped, and NP = 128 with
+    the reference's one population constant patched in the generator), replayed through mbx_set_tape + mbx_step: 12 / 11 / 13 episodes on 24 functions incl.
+    F16 / F21 / F24, all three noise models, the Gallagher noisy kinds, 'uniform'-action episodes and F5 / F7 where __reinit fires in > 100 generations.
+    src/optimizer/rlepso_optimizer.py:39-65, 173-263."""
+    from metabox_amd.suite import Suite
+    HD = load('rlepso_traces_hd.npz')
+    cases = [str(c) for c in HD['cases'] if int(c.split('/')[1]) == dim and int(c.split('/')[2]) == np_]
+    assert len(cases) >= 11
+    ledger, worst, n_exact = [], 0.0, 0
+    for suite in ('bbob', 'bbob-noisy'):
+        ps = problems(suite, dim)
+        ids = sorted(ps)
+        mine = [c for c in cases if c.split('/')[0] == suite]
+        ne, w, info = _tape_replay_group(Suite([ps[i] for i in ids]), ids, HD, HD, mine, np_, dim, 2000 * dim, ledger)
+        assert info['fixed_geometry'] == HD_GEOMETRIES[(dim, np_)], info
+        n_exact += ne; worst = max(worst, w)
+    print(f'tape replay D = {dim}, NP = {np_}: {n_exact}/{len(cases)} episodes with bookkeeping identical to the reference in every generation; worst '
+          f'gbest rel err {worst:.2e}; {len(ledger)} episodes leave it at a proven near-tie:')
     print_ledger(ledger)
 
 
@@ -381,6 +427,18 @@ def test_resident_rollout_equals_one_launch_per_generation():
     assert (r['steps'] < 199).any() and (r['fes'] >= 20000).any() and (r['fes'] % 100 != 0).any()      # re-initialisations bill odd FEs
     r = _rollout_case('bbob-noisy', 10, tuple(range(101, 131)), 100, 60, (25, 180))          # all 30 noisy functions: the eight bodies that carry the noise models
     assert (r['fes'] >= 20000).any()
+
+
+@pytest.mark.parametrize('dim,np_,chunks', [(40, 128, (1, 90, 233, 300)), (30, 100, (250, 350))])
+def test_resident_rollout_equals_one_launch_per_generation_whole_episodes_config_5_and_3_geometries(dim, np_, chunks):
+    """The same bit-for-bit identity over WHOLE episodes at the geometries of BASELINE config 5 (k_rlepso_run<1024, 128, 40, 5>: one out-of-line body per
+    function kind) and of bbob --dim 30 (k_rlepso_run<512, 100, 30, 5>), every function of both suites.  Together with the reference episodes replayed
+    through the one-generation kernels of these geometries (test_tape_replay_matches_reference_episodes_at_dim_30_and_40) this ties the resident
+    kernels config 5 is timed on to the reference run, not only to the oracle."""
+    r = _rollout_case('bbob', dim, tuple(range(1, 25)), np_, 24, chunks)
+    assert (r['fes'] >= 2000 * dim).any()
+    r = _rollout_case('bbob-noisy', dim, tuple(range(101, 131)), np_, 30, chunks)
+    assert (r['fes'] >= 2000 * dim).any()
 
 
 def test_resident_ranking_orders_equal_costs_like_the_one_generation_kernel():

@@ -13,24 +13,36 @@ from oracle import oracle
 TR = load('rlepso_traces.npz')
 TIES = load('rlepso_ties.npz')
 CASES = [str(c) for c in TR['cases']]
+# whole reference episodes at the geometries of BASELINE configs 3 / 5: --dim 30 / 40 at NP = 100, D = 40 at NP = 128 (tools/gen_golden.py rlepso_hd;
+# keys suite/dim/NP/fid/seed/mode; the fixture carries its own per-generation per_no_improve / c_cost)
+HD = load('rlepso_traces_hd.npz')
+HD_CASES = [str(c) for c in HD['cases']]
 LEDGER = []
 
 
-def replay(case):
-    suite, fid, seed, _ = case.split('/')
-    p = problems(suite, 10)[int(fid)]
-    cfg = oracle.make_cfg(1, 100, 10, 20000, 400, 50)
+def geometry(case):
+    """(suite, dim, NP, fid, seed, maxFEs) of a case key of either fixture."""
+    k = case.split('/')
+    if len(k) == 4:
+        return k[0], 10, 100, int(k[1]), int(k[2]), 20000
+    return k[0], int(k[1]), int(k[2]), int(k[3]), int(k[4]), 2000 * int(k[1])
+
+
+def replay(case, TR=TR, TIES=TIES):
+    suite, D, NP, fid, seed, maxfes = geometry(case)
+    p = problems(suite, D)[fid]
+    cfg = oracle.make_cfg(1, NP, D, maxfes, maxfes // 50, 50)
     o = oracle.RlepsoOracle(p.desc(), p.bias, cfg)
-    fd = oracle.NumpyTapeFeeder(int(seed), 100, 10, p.noise[0])
+    fd = oracle.NumpyTapeFeeder(seed, NP, D, p.noise[0])
     o.reset(fd.reset_tape())
-    g0 = oracle.split_rlepso_state(o.state(), 100, 10, 50)['scalars'][oracle.SC_GBEST]
+    g0 = oracle.split_rlepso_state(o.state(), NP, D, 50)['scalars'][oracle.SC_GBEST]
     acts = TR[f'{case}/actions']
     rows = []
     exact_until = len(acts)                      # generations [0, exact_until) have bookkeeping identical to the reference's
-    prev = oracle.split_rlepso_state(o.state(), 100, 10, 50)
+    prev = oracle.split_rlepso_state(o.state(), NP, D, 50)
     for g, a in enumerate(acts):
         s, r, d = o.step(a, fd.step_tape())
-        cur = oracle.split_rlepso_state(o.state(), 100, 10, 50)
+        cur = oracle.split_rlepso_state(o.state(), NP, D, 50)
         sc = cur['scalars']
         fd.commit(sc[oracle.SC_REINIT] > 0)
         rows.append((sc[oracle.SC_GBEST], sc[oracle.SC_FES], r, d))
@@ -40,9 +52,11 @@ def replay(case):
     return g0, np.array(rows), prev, exact_until
 
 
-@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('case', CASES + HD_CASES)
 def test_oracle_replays_reference_episode(case):
-    g0, rows, st, m = replay(case)
+    TR, TIES = (globals()['TR'], globals()['TIES']) if case in CASES else (HD, HD)
+    suite, D, NP, fid, seed, maxfes = geometry(case)
+    g0, rows, st, m = replay(case, TR, TIES)
     assert close(g0, TR[f'{case}/gbest0'], rtol=1e-9)
     assert close(rows[:, 0], TR[f'{case}/gbest'], rtol=1e-9), 'gbest trajectory'
     n = int(st['scalars'][oracle.SC_COST_LEN])
@@ -58,19 +72,34 @@ def test_oracle_replays_reference_episode(case):
         assert np.array_equal(st['pni'], TR[f'{case}/final_pni'])
         # positions after 199 generations: the matvec is an fma chain here and BLAS (its own blocking) in the reference, 1e-16 apart per
         # evaluation; a PSO amplifies that (bbob/15/2, two maps per evaluation: 2.7e-11 with every branch still identical to the reference's)
-        assert np.abs(st['pos'].reshape(100, 10) - TR[f'{case}/final_pos']).max() <= 1e-9
+        assert np.abs(st['pos'].reshape(NP, D) - TR[f'{case}/final_pos']).max() <= 1e-9
         assert close(st['pbest'], TR[f'{case}/final_pbest'], rtol=1e-9)
 
 
 def test_every_branch_divergence_is_a_proven_near_tie():
     """Runs after the parametrised replays (file order): the ledger lists every episode in which the oracle's bookkeeping leaves the
     reference's, each with the proof that the deciding comparison is closer than the implementations agree."""
-    for case in CASES:
-        if not any(c == case for _, c, _, _ in LEDGER) and int(TIES[f'{case}/oracle_first_divergence']) >= 0:
-            replay(case)                           # (running this test alone)
-    print(f'{len(LEDGER)} of {len(CASES)} episodes leave the reference bookkeeping at a proven near-tie:')
+    first = {c: int(TIES[f'{c}/oracle_first_divergence']) for c in CASES}
+    first.update({c: int(HD[f'{c}/oracle_first_divergence']) for c in HD_CASES})
+    for case in CASES + HD_CASES:
+        if not any(c == case for _, c, _, _ in LEDGER) and first[case] >= 0:
+            replay(case, *((TR, TIES) if case in CASES else (HD, HD)))        # (running this test alone)
+    print(f'{len(LEDGER)} of {len(CASES) + len(HD_CASES)} episodes leave the reference bookkeeping at a proven near-tie:')
     print_ledger(LEDGER)
-    assert {c for _, c, _, _ in LEDGER} == {c for c in CASES if int(TIES[f'{c}/oracle_first_divergence']) >= 0}
+    assert {c for _, c, _, _ in LEDGER} == {c for c in first if first[c] >= 0}
+
+
+def test_np128_fixture_carries_the_reference_pci():
+    """The NP = 128 episodes come from the reference with its one population constant patched in the generator (rlepso_optimizer.py:11); the fixture
+    keeps the pci curve the reference derived from it (:24-25).  libm's exp -- what the oracle and libmbx's host side evaluate the curve with -- must
+    reproduce numpy's (its own SIMD exp) closely: `rand > pci` (:79) is a branch.  Measured: 3 of 100 / 1 of 128 entries differ, by <= 2 ulp, i.e. a
+    53-bit uniform lands between the two values with probability ~2e-16 per draw -- never in any recorded episode."""
+    import math
+    for case in HD_CASES:
+        NP = geometry(case)[2]
+        ref = HD[f'{case}/pci']
+        mine = np.array([0.05 + 0.45 * math.exp(10. * i / (NP - 1)) / (math.exp(10.) - 1) for i in range(NP)])
+        assert ref.shape == (NP,) and np.all(np.abs(mine - ref) <= 2 * np.spacing(ref)), case
 
 
 def test_philox_mode_is_deterministic_and_seed_dependent():

@@ -917,6 +917,132 @@ def gen_rlepso_ties():
 
 
 
+# ---------------------------------------------------------------------------------------------------- rlepso_hd
+# Whole RLEPSO reference episodes at the geometries of BASELINE configs 3 / 5: `--dim 30` and `--dim 40` with the reference's own
+# NP = 100, and D = 40 with NP = 128.  NP is the literal `config.NP = 100` of src/optimizer/rlepso_optimizer.py:11; for NP = 128 that ONE constant is
+# patched here, in the generator: the reference module's text is read from /root/reference, the literal replaced, and the result compiled in memory
+# (never written anywhere) -- every derived quantity (pci :24-25, per_no_improve :30, the NP // n_group slices of __get_coe :117-126 that leave
+# particles 125-127 with zero coefficients, all draw shapes) is then computed by the reference's own code.
+# Per episode: actions, gbest / fes / reward / done per generation, per_no_improve per generation (uint16), final arrays, the generation at which the C
+# oracle's bookkeeping first leaves the reference's (-1: never) and, for those episodes and HD_EXTRA_TIE_CASES, the reference's c_cost per generation.
+HD_EXTRA_TIE_CASES = set()
+HD_CASES = (
+    # (suite, dim, NP, function ids, seed, action mode)
+    ('bbob', 30, 100, (1, 7, 15, 16, 21, 24), 0, 'actor'),
+    ('bbob-noisy', 30, 100, (103, 115, 124, 128), 1, 'actor'),
+    ('bbob', 30, 100, (8,), 3, 'uniform'),
+    ('bbob-noisy', 30, 100, (108,), 4, 'uniform'),
+    ('bbob', 40, 100, (3, 5, 16, 20, 21, 24), 0, 'actor'),
+    ('bbob-noisy', 40, 100, (102, 119, 126, 130), 1, 'actor'),
+    ('bbob', 40, 100, (9,), 3, 'uniform'),
+    ('bbob', 40, 128, (1, 6, 12, 16, 21, 23, 24), 2, 'actor'),
+    ('bbob-noisy', 40, 128, (101, 117, 121, 129), 2, 'actor'),
+    ('bbob', 40, 128, (2,), 5, 'uniform'),
+    ('bbob-noisy', 40, 128, (113,), 5, 'uniform'),
+)
+
+
+def rlepso_class_with_np(np_):
+    """RLEPSO_Optimizer of the reference with its hard-coded population size replaced (see above); np_ == 100 returns the class as shipped."""
+    from optimizer import RLEPSO_Optimizer
+    if np_ == 100:
+        return RLEPSO_Optimizer
+    path = os.path.join(ref_import.REF_SRC, 'optimizer', 'rlepso_optimizer.py')
+    with open(path) as f:
+        text = f.read()
+    assert text.count('config.NP = 100') == 1
+    ns = {'__name__': f'optimizer.rlepso_optimizer_np{np_}'}
+    exec(compile(text.replace('config.NP = 100', f'config.NP = {np_}'), path, 'exec'), ns)
+    return ns['RLEPSO_Optimizer']
+
+
+def _hd_worker(job):
+    import copy as _copy
+    from environment import PBO_Env
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from oracle import oracle
+    torch.set_num_threads(1)
+    suite, dim, np_, fid, seed, mode = job
+    case = f'{suite}/{dim}/{np_}/{fid}/{seed}/{mode}'
+    scratch = tempfile.mkdtemp()
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/RLEPSO_Agent.pkl'))
+    config = ref_import.ref_config(['--problem', suite, '--dim', str(dim)], scratch)
+    tr, te, _ = all_problems(suite, dim)
+    p = {fid_of(q): q for q in tr + te}[fid]
+    p.reset()
+    cls = rlepso_class_with_np(np_)
+    opt = cls(_copy.deepcopy(config))
+    priv = lambda name: getattr(opt, '_RLEPSO_Optimizer__' + name)
+    assert priv('NP') == np_ and len(priv('pci')) == np_
+    env = PBO_Env(p, opt)
+    actor = agent._RLEPSO_Agent__actor
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ars = np.random.RandomState(10_000 + seed)
+    state = env.reset()
+    part = priv('particles')
+    gb0 = float(part['gbest_val'])
+    cc, pni = [part['c_cost'].copy()], [np.array(priv('per_no_improve')).copy()]
+    acts, gbest, fes, reward, done_l = [], [], [], [], []
+    done = False
+    while not done:
+        if mode == 'actor':
+            with torch.no_grad():
+                a = actor(torch.FloatTensor(state))[0].cpu().numpy()
+        else:
+            a = ars.uniform(0, 1, size=35).astype(np.float32)
+        state, r, done = env.step(a)
+        part = priv('particles')
+        acts.append(a.astype(np.float32))
+        gbest.append(float(part['gbest_val'])); fes.append(float(opt.fes)); reward.append(float(r)); done_l.append(bool(done))
+        cc.append(part['c_cost'].copy())
+        pni.append(np.array(priv('per_no_improve')).copy())
+    cc, pni = np.stack(cc), np.stack(pni)
+    rec = dict(actions=np.stack(acts), gbest=np.array(gbest), fes=np.array(fes), reward=np.array(reward), done=np.array(done_l),
+               cost=np.array(opt.cost, dtype=np.float64), gbest0=np.float64(gb0), final_pos=np.array(part['current_position']),
+               final_pbest=np.array(part['pbest']), final_pni=np.array(priv('per_no_improve')), pni=pni.astype(np.uint16),
+               pci=np.array(priv('pci'), dtype=np.float64))
+    # the C oracle on the same tape: the first generation at which its bookkeeping leaves the reference's
+    from metabox_amd.problem.bbob import BBOB_Dataset
+    mtr, mte = BBOB_Dataset.get_datasets(suite, dim, 5.0)
+    mp_ = {q.func_id: q for q in mtr.data + mte.data}[fid]
+    maxfes = int(config.maxFEs)
+    cfg = oracle.make_cfg(1, np_, dim, maxfes, maxfes // 50, 50)
+    o = oracle.RlepsoOracle(mp_.desc(), mp_.bias, cfg)
+    fd = oracle.NumpyTapeFeeder(seed, np_, dim, mp_.noise[0])
+    o.reset(fd.reset_tape())
+    first = -1
+    for g, a in enumerate(acts):
+        o.step(a, fd.step_tape())
+        st = oracle.split_rlepso_state(o.state(), np_, dim, 50)
+        fd.commit(st['scalars'][oracle.SC_REINIT] > 0)
+        if not np.array_equal(st['pni'], pni[g + 1]):
+            first = g
+            break
+    rec['oracle_first_divergence'] = np.int32(first)
+    if first >= 0 or case in HD_EXTRA_TIE_CASES:
+        rec['ccost'] = cc
+    return case, rec
+
+
+def gen_rlepso_hd():
+    import multiprocessing as mp
+    jobs = [(suite, dim, np_, fid, seed, mode) for suite, dim, np_, fids, seed, mode in HD_CASES for fid in fids]
+    data, cases = {}, []
+    with mp.get_context('fork').Pool(7) as pool:
+        for case, rec in pool.imap(_hd_worker, jobs):
+            cases.append(case)
+            for k, v in rec.items():
+                data[f'{case}/{k}'] = v
+            np_ = int(case.split('/')[2])
+            n_re = int(np.sum(np.diff(np.concatenate([[float(np_)], rec['fes']])) != np_))
+            print(f'{case}: gens={len(rec["gbest"])} fes={rec["fes"][-1]:.0f} final={rec["gbest"][-1]:.6g} reinit_steps={n_re} '
+                  f'oracle_first_divergence={int(rec["oracle_first_divergence"])}', flush=True)
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'rlepso_traces_hd.npz'), **data)
+    print('rlepso_hd:', len(cases), 'episodes')
+
+
 
 # ---------------------------------------------------------------------------------------------------- train
 # One training update of each reference agent on a SCRIPTED environment (states / rewards / done are fixed sequences, so nothing but the
@@ -1090,7 +1216,7 @@ def gen_train():
 
 
 
-SECTIONS = {'train': gen_train, 'rlepso_ties': gen_rlepso_ties, 'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+SECTIONS = {'train': gen_train, 'rlepso_hd': gen_rlepso_hd, 'rlepso_ties': gen_rlepso_ties, 'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
