@@ -235,14 +235,12 @@ def _final_r(calls, NP):
     return r[0].numpy().astype(np.uint8)
 
 
-def run_lde_episode(problem, seed, agent, config, action_mode):
-    from optimizer import LDE_Optimizer
+def run_lde_episode(problem, seed, agent, config, action_mode, NP=50, keep_actions=True):
     from environment import PBO_Env
     import copy
-    opt = LDE_Optimizer(copy.deepcopy(config))
+    opt = lde_class_with_np(NP)(copy.deepcopy(config))
     env = PBO_Env(problem, opt)
-    net = agent._LDE_Agent__net
-    NP = 50
+    net = agent._LDE_Agent__net if agent is not None else None
     np.random.seed(seed)
     torch.manual_seed(seed)
     ars = np.random.RandomState(20_000 + seed)
@@ -254,6 +252,7 @@ def run_lde_episode(problem, seed, agent, config, action_mode):
     rec = dict(actions=[], r=[], gbest=[], fes=[], reward=[], done=[], states=[])
     done = False
     g = 0
+    first_tie = -1
     while not done:
         if action_mode == 'actor':
             with torch.no_grad():
@@ -262,6 +261,8 @@ def run_lde_episode(problem, seed, agent, config, action_mode):
         else:
             action = ars.uniform(0, 1, size=(1, 2 * NP)).astype(np.float32)
         calls = []
+        if first_tie < 0 and len(np.unique(opt._LDE_Optimizer__fit[0])) < NP:
+            first_tie = g          # two individuals with exactly the same fitness enter update() number g: np.argsort's order of them is unspecified
 
         def spy(*a_, **k_):
             out = real_randint(*a_, **k_)
@@ -282,7 +283,11 @@ def run_lde_episode(problem, seed, agent, config, action_mode):
             rec['states'].append(np.concatenate([[g], np.asarray(state[0], dtype=np.float64)]))
         g += 1
     out = {k: np.stack(v) if k in ('actions', 'r', 'states') else np.array(v) for k, v in rec.items()}
+    if not keep_actions:
+        assert action_mode == 'uniform'           # regenerated by the tests: RandomState(20_000 + seed).uniform(0, 1, (1, 2 NP)).astype(float32) per generation
+        del out['actions']
     out['cost'] = np.array(opt.cost, dtype=np.float64)
+    out['first_tie_gen'] = np.int32(first_tie)
     out['state0'] = state0
     out['final_fit'] = np.array(opt._LDE_Optimizer__fit[0])
     out['final_pop'] = np.array(opt._LDE_Optimizer__pop[0])
@@ -1043,6 +1048,70 @@ def gen_rlepso_hd():
     print('rlepso_hd:', len(cases), 'episodes')
 
 
+# ---------------------------------------------------------------------------------------------------- lde_hd
+# Whole LDE reference episodes at the geometry of BASELINE config 3 (bbob-noisy, D = 30): the reference's own NP = 50 -- one function per noise model,
+# two Gallaghers, two noise-free functions -- and NP = 100 ("pop=100" as config 3 is written), for which the ONE literal `self.__config.NP = 50` of
+# src/optimizer/lde_optimizer.py:10 is patched here, in the generator (module text read from /root/reference, literal replaced, compiled in memory; P_MIN :14,
+# the histogram prior :139 and every draw shape then follow from the reference's own code).  The shipped PolicyNet is NP = 50 only, so the NP = 100 episodes
+# (and most NP = 50 ones, to keep the fixture small) are driven by seeded uniform actions, which the tests regenerate instead of loading.
+LDE_HD_CASES = (
+    # (suite, dim, NP, fid, seed, mode)
+    ('bbob-noisy', 30, 50, 115, 3, 'actor'),          # Cauchy noise, step ellipsoid
+    ('bbob-noisy', 30, 50, 128, 4, 'actor'),          # Gauss noise, Gallagher 101 peaks
+    ('bbob-noisy', 30, 50, 104, 5, 'uniform'),        # Gauss, Rosenbrock
+    ('bbob-noisy', 30, 50, 120, 6, 'uniform'),        # uniform noise, different powers
+    ('bbob-noisy', 30, 50, 124, 7, 'uniform'),        # Cauchy, Schaffers
+    ('bbob-noisy', 30, 50, 130, 8, 'uniform'),        # Cauchy, Gallagher
+    ('bbob', 30, 50, 16, 9, 'uniform'),
+    ('bbob', 30, 50, 21, 10, 'uniform'),
+    ('bbob-noisy', 30, 100, 101, 11, 'uniform'),      # NP = 100: Gauss
+    ('bbob-noisy', 30, 100, 109, 12, 'uniform'),      # Cauchy (severe)
+    ('bbob-noisy', 30, 100, 117, 13, 'uniform'),      # uniform noise, ellipsoid
+    ('bbob-noisy', 30, 100, 129, 14, 'uniform'),      # uniform noise, Gallagher
+    ('bbob-noisy', 30, 100, 126, 15, 'uniform'),      # uniform noise, Griewank-Rosenbrock
+)
+
+
+def lde_class_with_np(np_):
+    from optimizer import LDE_Optimizer
+    if np_ == 50:
+        return LDE_Optimizer
+    path = os.path.join(ref_import.REF_SRC, 'optimizer', 'lde_optimizer.py')
+    with open(path) as f:
+        text = f.read()
+    assert text.count('self.__config.NP = 50') == 1
+    ns = {'__name__': f'optimizer.lde_optimizer_np{np_}'}
+    exec(compile(text.replace('self.__config.NP = 50', f'self.__config.NP = {np_}'), path, 'exec'), ns)
+    return ns['LDE_Optimizer']
+
+
+def _lde_hd_worker(job):
+    torch.set_num_threads(1)
+    suite, dim, np_, fid, seed, mode = job
+    scratch = tempfile.mkdtemp()
+    agent = load_shipped(os.path.join(ref_import.REF_SRC, 'agent_model/test/bbob_easy/LDE_Agent.pkl')) if mode == 'actor' else None
+    config = ref_import.ref_config(['--problem', suite, '--dim', str(dim)], scratch)
+    tr, te, _ = all_problems(suite, dim)
+    p = {fid_of(q): q for q in tr + te}[fid]
+    p.reset()
+    rec = run_lde_episode(p, seed, agent, config, mode, NP=np_, keep_actions=(mode == 'actor'))
+    return f'{suite}/{dim}/{np_}/{fid}/{seed}/{mode}', rec
+
+
+def gen_lde_hd():
+    import multiprocessing as mp
+    data, cases = {}, []
+    with mp.get_context('fork').Pool(7) as pool:
+        for case, rec in pool.imap(_lde_hd_worker, LDE_HD_CASES):
+            cases.append(case)
+            for k, v in rec.items():
+                data[f'{case}/{k}'] = v
+            print(f'{case}: gens={len(rec["gbest"])} fes={rec["fes"][-1]:.0f} final={rec["gbest"][-1]:.6g} first_tie_gen={int(rec["first_tie_gen"])}', flush=True)
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, 'lde_traces_hd.npz'), **data)
+    print('lde_hd:', len(cases), 'episodes')
+
+
 
 # ---------------------------------------------------------------------------------------------------- train
 # One training update of each reference agent on a SCRIPTED environment (states / rewards / done are fixed sequences, so nothing but the
@@ -1216,7 +1285,7 @@ def gen_train():
 
 
 
-SECTIONS = {'train': gen_train, 'rlepso_hd': gen_rlepso_hd, 'rlepso_ties': gen_rlepso_ties, 'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
+SECTIONS = {'train': gen_train, 'lde_hd': gen_lde_hd, 'rlepso_hd': gen_rlepso_hd, 'rlepso_ties': gen_rlepso_ties, 'qlpso': gen_qlpso, 'gleet_policy': gen_gleet_policy, 'gleet': gen_gleet, 'rlpso': gen_rlpso, 'mte': gen_mte, 'lde_stats': gen_lde_stats, 'stats': gen_stats, 'harness': gen_harness, 'ddqn': gen_ddqn, 'protein': gen_protein, 'lde': gen_lde, 'instances': gen_instances, 'kat': gen_kat, 'noise': gen_noise, 'policy': gen_policy,
             'rlepso': gen_rlepso}
 
 if __name__ == '__main__':
