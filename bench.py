@@ -443,7 +443,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    # a process group whenever the line is launched through torch.distributed.run -- also at --nproc-per-node 1, where the same collectives then run
+    # through a one-rank RCCL communicator (tests/test_gpu_shards.py: the first RCCL call this code makes is not the 8-GPU run's)
+    if world > 1 or ('TORCHELASTIC_RUN_ID' in os.environ and 'MASTER_PORT' in os.environ):
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -179,6 +179,10 @@ int mbx_read_public(mbx_batch* b, int instance, double* host_out /* [MBX_NSCALAR
  * RLEPSO layout: see MBX_RLEPSO_* offsets in include/mbx_layout.h. */
 int64_t mbx_instance_state_doubles(const mbx_batch* b);
 int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out);
+/* The inverse: overwrite one instance's state block from the host (host_in: mbx_instance_state_doubles doubles, same layout).  What a caller of the
+ * reference does with `copy.deepcopy(env)` / a pickled optimizer (src/tester.py, src/agent/utils.py:44-48 save_class): snapshot an instance and
+ * resume it later -- and what the tests use to hand the generation kernels a crafted swarm (tests/test_fdr_ties.py).  Synchronises the device. */
+int mbx_debug_write_state(mbx_batch* b, int instance, const double* host_in);
 
 /* The RLEPSO / RL-PSO actor as ONE kernel launch per step (src/agent/rlepso_agent.py:9-47 Actor.forward without
  * fixed_action; src/agent/rl_pso_agent.py:9-47 PolicyNetwork.forward): two MLPs in_dim -> h1 -> h2 -> out_dim (ReLU, ReLU, none) sharing their input,

@@ -26,6 +26,11 @@ def _q_layers(n_in, n_out, width=100, depth=4):
 
 
 class DE_DDQN_Agent(Basic_Agent):
+    # Under torch.distributed the only training path Trainer drives is train_batch, whose gradients are synchronised over ranks: every rank holds the
+    # same parameters, so rank 0 alone writes the checkpoints -- including the `checkpoint0` of __init__ / update_setting (agent/utils.save_class).
+    # A class attribute: true before the first train_batch call and not part of the pickled instance state.
+    _mbx_replicated = True
+
     def __init__(self, config):
         super().__init__(config)
         for key, value in _HYPER.items():               # the agent publishes its hyper-parameters on the shared config
@@ -190,7 +195,6 @@ class DE_DDQN_Agent(Basic_Agent):
         the target network, refreshed every update_target_steps updates) follow -- the reference's loop (de_ddqn_agent.py:70-106)
         with a batch axis.  By construction the data : update ratio is B times the reference's.  Gradients are averaged across ranks.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'})."""
-        self._mbx_replicated = True                        # gradients are averaged over ranks (the replay buffers are per-rank working state, not checkpointed separately)
         from ..distributed import all_ranks_any
         cfg, dev = self.__config, env.batch.device
         net, tgt = self.__pred_func, self.__target_func

@@ -177,6 +177,11 @@ _HYPER = dict(embedding_dim=16, encoder_head_num=4, decoder_head_num=4, n_encode
 
 
 class GLEET_Agent(Basic_Agent):
+    # Under torch.distributed the only training path Trainer drives is train_batch, whose gradients are synchronised over ranks: every rank holds the
+    # same parameters, so rank 0 alone writes the checkpoints -- including the `checkpoint0` of __init__ / update_setting (agent/utils.save_class).
+    # A class attribute: true before the first train_batch call and not part of the pickled instance state.
+    _mbx_replicated = True
+
     def __init__(self, config):
         super().__init__(config)
         for k, v in _HYPER.items():                       # the agent publishes its hyper-parameters on the shared config (:31-53)
@@ -293,7 +298,6 @@ class GLEET_Agent(Basic_Agent):
         averaged across ranks when torch.distributed is initialised.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps'}) with per-batch means."""
         from ..distributed import all_ranks_any, average_gradients
-        self._mbx_replicated = True                        # gradient-synchronised over ranks: rank 0 writes the checkpoints (agent/utils.save_class)
         c = self.__config
         actor, critic = self.actor, self.critic
         params = list(actor.parameters()) + list(critic.parameters())
@@ -356,7 +360,7 @@ class GLEET_Agent(Basic_Agent):
                     value_loss = (torch.max((val - returns) ** 2, (v_clip - returns) ** 2) * M).sum() / n_live
                 self.optimizer.zero_grad()
                 (value_loss + policy_loss).backward()
-                average_gradients(params)
+                average_gradients(params, weight=M.sum())
                 for group in self.optimizer.param_groups:
                     torch.nn.utils.clip_grad_norm_(group['params'], c.max_grad_norm if c.max_grad_norm > 0 else math.inf, norm_type=2)
                 self.optimizer.step()

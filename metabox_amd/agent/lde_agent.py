@@ -55,6 +55,11 @@ _REF_KEYS = {'net/_PolicyNet__lstm.': 'lstm.', 'net/_PolicyNet__mu.': 'mu.', 'ne
 
 
 class LDE_Agent(Basic_Agent):
+    # Under torch.distributed the only training path Trainer drives is train_batch, whose gradients are synchronised over ranks: every rank holds the
+    # same parameters, so rank 0 alone writes the checkpoints -- including the `checkpoint0` of __init__ / update_setting (agent/utils.save_class).
+    # A class attribute: true before the first train_batch call and not part of the pickled instance state.
+    _mbx_replicated = True
+
     def __init__(self, config):
         super().__init__(config)
         self.__config = config
@@ -245,7 +250,6 @@ class LDE_Agent(Basic_Agent):
         (log-probability of action + 1e-8, discounted returns, back-propagation through the collection-phase LSTM steps) is the one
         tests/test_training_parity.py pins against the reference for train_episode."""
         from ..distributed import all_ranks_any, average_gradients
-        self._mbx_replicated = True                        # gradient-synchronised over ranks: rank 0 writes the checkpoints (agent/utils.save_class)
         c = self.__config
         dev = env.batch.device
         state = env.reset().to(torch.float32).clone()
@@ -281,7 +285,7 @@ class LDE_Agent(Basic_Agent):
             logp = torch.distributions.Normal(mean[0], std[0]).log_prob(torch.stack(A).view(T * B, -1) + 1e-8).sum(1).view(T, B)
             loss = -(logp * G * M).sum() / M.sum().clamp_min(1.)
             loss.backward()
-            average_gradients(list(self.__net.parameters()))
+            average_gradients(list(self.__net.parameters()), weight=M.sum())
             self.__optimizer.step()
             self.__after_update()
             updates += 1

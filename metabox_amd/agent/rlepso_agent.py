@@ -140,6 +140,11 @@ _REF_PREFIX = {'actor/_Actor__mu_net.': 'mu_net.', 'actor/_Actor__sigma_net.': '
 
 
 class RLEPSO_Agent(Basic_Agent):
+    # Under torch.distributed the only training path Trainer drives is train_batch, whose gradients are synchronised over ranks: every rank holds the
+    # same parameters, so rank 0 alone writes the checkpoints -- including the `checkpoint0` of __init__ / update_setting (agent/utils.save_class).
+    # A class attribute: true before the first train_batch call and not part of the pickled instance state.
+    _mbx_replicated = True
+
     def __init__(self, config):
         super().__init__(config)
         # the agent writes its hyper-parameters into the shared config like the reference (rlepso_agent.py:69-78)
@@ -309,7 +314,6 @@ class RLEPSO_Agent(Basic_Agent):
                  BatchedPBO_Env on the GPU and no actions are forced, else 'step'.
         Returns (exceed_max_learning_step, {'normalizer', 'gbest', 'return', 'learn_steps', 'last_losses'})."""
         from ..distributed import all_ranks_any, average_gradients
-        self._mbx_replicated = True                        # gradient-synchronised over ranks: rank 0 writes the checkpoints (agent/utils.save_class)
         config = self.__config
         gamma, n_step, K_epochs, eps_clip = config.gamma, config.n_step, config.K_epochs, config.eps_clip
         actor, critic = self.__actor, self.__critic
@@ -391,7 +395,7 @@ class RLEPSO_Agent(Basic_Agent):
                 self.__optimizer_actor.zero_grad()
                 self.__optimizer_critic.zero_grad()
                 (baseline_loss + reinforce_loss).backward()
-                average_gradients(params)
+                average_gradients(params, weight=M.sum())          # weight = live (step, instance) pairs: the global mean loss for any world size
                 self.__optimizer_actor.step()
                 self.__optimizer_critic.step()
                 self.__dict__['_tables'] = {}

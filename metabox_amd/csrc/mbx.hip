@@ -820,8 +820,8 @@ extern "C" int mbx_gauss_policy(mbx_batch* b, const mbx_gauss_mlp* net, const do
     return MBX_OK;
 }
 
-extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state, float* d_h, float* d_c, float* d_actions,
-                              float* d_mu_sigma, void* stream)
+static int lde_policy_launch(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state, float* d_h, float* d_c, float* d_actions,
+                             float* d_mu_sigma, void* stream, int skip_done)
 {
     if (!b || !net || !net->d_weights || !d_state || !d_h || !d_c) return fail(MBX_E_ARG, "mbx_lde_policy: bad arguments");
     if (b->cfg.algo != MBX_ALGO_LDE) return fail(MBX_E_UNSUPPORTED, "mbx_lde_policy: the batch is not an LDE batch");
@@ -836,7 +836,7 @@ extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const do
         do {                                                                                                                                          \
             HIP_TRY(hipFuncSetAttribute((const void*)k_lstm_policy<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
             hipLaunchKernelGGL((k_lstm_policy<__VA_ARGS__>), dim3((b->B + kLstmTile - 1) / kLstmTile), dim3(kThreads), lds, (hipStream_t)stream,      \
-                               make_params(b), g, d_state, d_h, d_c, d_actions, d_mu_sigma);                                                          \
+                               make_params(b), g, d_state, d_h, d_c, d_actions, d_mu_sigma, skip_done);                                               \
         } while (0)
         // the reference's PolicyNet (lde_agent.py:8-29: LSTM NP + 10 -> 50, heads 50 -> 2 NP) at config 3's two populations: compile-time dimensions
         if (net->in_dim == 60 && net->hidden == 50 && net->out_dim == 100) MBX_LSTM_LAUNCH(kLstmTile, 60, 50, 100);
@@ -846,6 +846,12 @@ extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const do
     }
     HIP_TRY(hipGetLastError());
     return MBX_OK;
+}
+
+extern "C" int mbx_lde_policy(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state, float* d_h, float* d_c, float* d_actions,
+                              float* d_mu_sigma, void* stream)
+{
+    return lde_policy_launch(b, net, d_state, d_h, d_c, d_actions, d_mu_sigma, stream, 0);
 }
 
 extern "C" int mbx_ddqn_qnet(mbx_batch* b, const mbx_qnet* net, const double* d_state, int32_t* d_actions, float* d_q, void* stream)
@@ -907,6 +913,26 @@ __global__ void k_sum_rewards(double* __restrict__ acc, const double* __restrict
     if (i < n) acc[i] = first ? r[i] : acc[i] + r[i];
 }
 
+// The ONE launch site of k_rlepso_run.  The D = 10 / D = 40 instantiations dispatch to one out-of-line body per function kind and trap on a kind without a
+// body (csrc/mbx_rlepso.hpp), which would take the whole GPU context down: the check that keeps such batches away lives here, next to the launch, not only in
+// the mbx_rlepso_rollout_resident query.
+static int launch_rlepso_run(mbx_batch* b, const float* d_table, int rows, int n_gens, const RunOut& out, hipStream_t stream)
+{
+    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !b->rl_run_kinds_ok)
+        return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: the batch holds a function kind the resident kernel has no body for");
+    if (b->fixed_geometry == 1)
+        hipLaunchKernelGGL((k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>), dim3(b->B), dim3(MBX_RUN10_THREADS), b->lds_bytes, stream,
+                           make_params(b), d_table, rows, n_gens, out);
+    else if (b->fixed_geometry == 7)
+        hipLaunchKernelGGL((k_rlepso_run<512, 100, 30, 5>), dim3(b->B), dim3(512), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
+    else if (b->fixed_geometry == 2)
+        hipLaunchKernelGGL((k_rlepso_run<1024, 128, 40, 5>), dim3(b->B), dim3(1024), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
+    else
+        return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: no instantiation for this geometry");
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
 extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_traj_actions, double* d_traj_state,
                                   double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out, double* d_reward_out,
                                   uint8_t* d_done_out, void* stream)
@@ -916,20 +942,9 @@ extern "C" int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens
     if (n_gens < 1) return fail(MBX_E_ARG, "mbx_rlepso_rollout: n_gens must be >= 1");
     if (b->d_tape) return fail(MBX_E_ARG, "mbx_rlepso_rollout: a replay tape holds one generation and no policy draws; use mbx_step with recorded actions");
     const int rows = mbx_rlepso_policy_table_rows(b);
-    if (mbx_rlepso_rollout_resident(b) == 1) {
-        const RunOut out{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
-        if (b->fixed_geometry == 1)
-            hipLaunchKernelGGL((k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>), dim3(b->B), dim3(MBX_RUN10_THREADS), b->lds_bytes, (hipStream_t)stream,
-                               make_params(b), d_table, rows, n_gens, out);
-        else if (b->fixed_geometry == 7)
-            hipLaunchKernelGGL((k_rlepso_run<512, 100, 30, 5>), dim3(b->B), dim3(512), b->lds_bytes, (hipStream_t)stream,
-                               make_params(b), d_table, rows, n_gens, out);
-        else
-            hipLaunchKernelGGL((k_rlepso_run<1024, 128, 40, 5>), dim3(b->B), dim3(1024), b->lds_bytes, (hipStream_t)stream,
-                               make_params(b), d_table, rows, n_gens, out);
-        HIP_TRY(hipGetLastError());
-        return MBX_OK;
-    }
+    if (mbx_rlepso_rollout_resident(b) == 1)
+        return launch_rlepso_run(b, d_table, rows, n_gens, RunOut{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out},
+                                 (hipStream_t)stream);
     // run-time geometries: one k_rlepso_step launch per generation, same outputs
     const int64_t B = b->B, A = b->action_dim;
     for (int g = 0; g < n_gens; ++g) {
@@ -968,6 +983,7 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
                     net->in_dim, net->hidden, net->out_dim, b->state_dim, b->action_dim);
     const int64_t B = b->B, A = b->action_dim, NF = b->state_dim;
     if (mbx_lde_rollout_resident(b) == 1 && net->hidden == 50) {
+        if (!b->lde_run_kinds_ok) return fail(MBX_E_UNSUPPORTED, "k_lde_run: the batch holds an objective kind the resident kernel does not build");   // (its row-sum default yields NaN)
         LdeRunArgs ka{};
         ka.bp = make_params(b);
         {   // the weights may have changed since the last call: rebuild the k-blocked copy the kernel reads (one small launch, ~3 us)
@@ -993,7 +1009,8 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
     float* a_scratch = (float*)(b->d_scratch + B);
     for (int g = 0; g < n_gens; ++g) {
         float* acts = d_traj_actions ? d_traj_actions + g * B * A : a_scratch;
-        if (const int rc = mbx_lde_policy(b, net, d_state_out, d_h, d_c, acts, nullptr, stream)) return rc;
+        // (h, c) and the action rows of instances that are already done stay untouched, as in the resident kernel (include/mbx.h)
+        if (const int rc = lde_policy_launch(b, net, d_state_out, d_h, d_c, acts, nullptr, stream, 1)) return rc;
         double* r = d_traj_reward ? d_traj_reward + g * B : (d_reward_out ? r_scratch : nullptr);
         uint8_t* dn = d_traj_done ? d_traj_done + g * B : d_done_out;
         if (const int rc = mbx_step(b, acts, d_state_out, r, dn, stream)) return rc;
@@ -1150,6 +1167,15 @@ extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out
     double* sc = host_out + b->sc_off;
     const int len = (int)sc[MBX_SC_COST_LEN];
     for (int k = len; k <= b->cfg.n_logpoint && len > 0; ++k) sc[MBX_NSCALAR + k] = sc[MBX_NSCALAR + len - 1];
+    return MBX_OK;
+}
+
+extern "C" int mbx_debug_write_state(mbx_batch* b, int instance, const double* host_in)
+{
+    if (!b || instance < 0 || instance >= b->B || !host_in) return fail(MBX_E_ARG, "mbx_debug_write_state: bad arguments");
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t n = mbx_instance_state_doubles(b);
+    HIP_TRY(hipMemcpy(b->d_state + (int64_t)instance * b->state_stride, host_in, n * sizeof(double), hipMemcpyHostToDevice));
     return MBX_OK;
 }
 

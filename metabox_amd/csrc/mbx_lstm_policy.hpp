@@ -40,7 +40,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // loaded before its MFMA chain starts (one L2 round trip per tile instead of one per k-step, as in mbx_qnet.hpp); config 3's two networks get instantiations.
 template <int TI, int INC = 0, int HC = 0, int AC = 0>
 __global__ __launch_bounds__(kThreads) void k_lstm_policy(BatchParams bp, LstmPolicy net, const double* __restrict__ state, float* __restrict__ hbuf,
-                                                          float* __restrict__ cbuf, float* __restrict__ actions, float* __restrict__ mu_sigma)
+                                                          float* __restrict__ cbuf, float* __restrict__ actions, float* __restrict__ mu_sigma, int skip_done)
 {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     constexpr int RT = TI / 16;                                   // 16-instance row tiles per workgroup
@@ -125,8 +125,12 @@ __global__ __launch_bounds__(kThreads) void k_lstm_policy(BatchParams bp, LstmPo
             const float gg = tanhf(GT[(2 * H + j) * TI + i]), go = sigmoidf_(GT[(3 * H + j) * TI + i]);
             const float cn = gf * cbuf[(int64_t)(b0 + i) * H + j] + gi * gg;
             const float hn = go * tanhf(cn);
-            cbuf[(int64_t)(b0 + i) * H + j] = cn;
-            hbuf[(int64_t)(b0 + i) * H + j] = hn;
+            // skip_done (mbx_lde_rollout's per-generation route): an instance that has terminated keeps its (h, c) -- the agent stops calling its
+            // policy once env.step returned done (lde_agent.py:147-163)
+            if (!(skip_done && bp.state[(int64_t)(b0 + i) * bp.state_stride + bp.sc_off + MBX_SC_DONE] != 0.)) {
+                cbuf[(int64_t)(b0 + i) * H + j] = cn;
+                hbuf[(int64_t)(b0 + i) * H + j] = hn;
+            }
             HN[j * TI + i] = hn;
         } else HN[j * TI + i] = 0.f;
     }
@@ -184,8 +188,8 @@ __global__ __launch_bounds__(kThreads) void k_lstm_policy(BatchParams bp, LstmPo
                             const int b = b0 + i;
                             const float mu = am[rt][r], sigma = sigmoidf_(as[rt][r]);
                             if (mu_sigma) { mu_sigma[((int64_t)b * 2) * A + j] = mu; mu_sigma[((int64_t)b * 2 + 1) * A + j] = sigma; }
-                            if (actions) {
-                                const double* sc = bp.state + (int64_t)b * bp.state_stride + bp.sc_off;
+                            const double* sc = bp.state + (int64_t)b * bp.state_stride + bp.sc_off;
+                            if (actions && !(skip_done && sc[MBX_SC_DONE] != 0.)) {
                                 const uint64_t seed = bp.seeds[b];
                                 // the action drawn here drives generation gen + 1 of the current episode
                                 const Rng rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)((int)sc[MBX_SC_GEN] + 1), (uint32_t)(int)sc[MBX_SC_EPISODE]};

@@ -7,8 +7,20 @@ number of ranks.  The only communication is one all-gather of the per-instance r
 ([n_local, n_logpoint+1 + 3] float64: cost curve, fes, return, steps) at the end of an epoch — RCCL over xGMI when
 the process group is "nccl", gloo in the CPU tests.
 """
+import os
+
 import numpy as np
 import torch
+
+
+def _single_process(group=None):
+    """True when there is nothing to communicate with: no process group, or a group of ONE rank -- unless MBX_FORCE_COLLECTIVES=1 asks for the
+    collectives to be issued anyway (tests/test_gpu_shards.py pushes real result rows and gradients through a world-size-1 RCCL group, so that the
+    first RCCL call this code ever makes is not the 8-GPU run's)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get('MBX_FORCE_COLLECTIVES', '0') != '1'
 
 
 def shard_range(n_total, rank, world):
@@ -99,7 +111,7 @@ def gather_rows(rows, n_total, group=None, bounds=None):
     order because shards are contiguous).  Shards differ in size (by one row for the equal-count split, by the cost ratio for
     `bounds` = cost_partition(...)): rows are padded to the maximum."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single_process(group):
         return rows
     world = dist.get_world_size(group)
     if bounds is not None:
@@ -115,18 +127,30 @@ def gather_rows(rows, n_total, group=None, bounds=None):
     return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
 
 
-def average_gradients(params, group=None):
-    """Data-parallel training: average the gradients of `params` over all ranks (one flat all-reduce; the RLEPSO actor +
-    critic are 6.9 k parameters, the LDE LSTM 32.6 k — latency-bound on xGMI, nothing to bucket)."""
+def average_gradients(params, group=None, weight=None):
+    """Data-parallel training: combine the gradients of `params` over all ranks with ONE flat all-reduce (the RLEPSO actor + critic are 6.9 k
+    parameters, the LDE LSTM 32.6 k -- latency-bound on xGMI, nothing to bucket).
+
+    weight: the number of samples the rank's loss was a MEAN over (live (step, instance) pairs for PPO / REINFORCE; may be 0 for a rank whose shard
+    has finished).  Shards are cost-weighted (`cost_partition`), so ranks own different numbers of instances; the synchronised gradient is then
+    sum_r weight_r grad_r / sum_r weight_r = the gradient of the mean loss over ALL ranks' samples, i.e. the same objective for any world size
+    (the unweighted mean of per-rank means gave instances of expensive functions up to ~2x the weight of cheap ones).  The weight travels
+    as one extra element of the same all-reduce.  weight=None: plain mean over ranks (equal-size mini-batches, e.g. DE-DDQN's replay samples)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single_process(group):
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat /= dist.get_world_size(group)
+    if weight is None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= dist.get_world_size(group)
+    else:
+        w = torch.as_tensor(weight, dtype=flat.dtype, device=flat.device).reshape(1)
+        flat = torch.cat([flat * w, w])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat = flat[:-1] / flat[-1].clamp_min(torch.finfo(flat.dtype).tiny)
     o = 0
     for g in grads:
         n = g.numel()
@@ -139,7 +163,7 @@ def all_ranks_any(flag, device=None, group=None):
     initialised).  The batched training loops use it so that every rank issues the same number of gradient all-reduces even though
     shards finish their episodes at different generations."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single_process(group):
         return bool(flag)
     dev = device if (device is not None and dist.get_backend(group) == 'nccl') else torch.device('cpu')
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)

@@ -348,6 +348,13 @@ class Batch:
         _abi.check(self.lib.mbx_debug_read_state(self._h, int(instance), out.ctypes.data_as(_abi.c_double_p)))
         return out
 
+    def write_state(self, instance, block):
+        """Overwrite one instance's state block (the layout read_state returns): snapshot / resume, crafted swarms in tests."""
+        n = int(self.lib.mbx_instance_state_doubles(self._h))
+        block = np.ascontiguousarray(block, dtype=np.float64)
+        assert block.shape == (n,)
+        _abi.check(self.lib.mbx_debug_write_state(self._h, int(instance), block.ctypes.data_as(_abi.c_double_p)))
+
     def launch_info(self):
         """How the generation kernel is launched: threads per workgroup, LDS bytes, compile-time-geometry id, state stride in doubles."""
         import ctypes as C

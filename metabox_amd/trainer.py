@@ -44,7 +44,7 @@ class Trainer(object):
         src/trainer.py:159-161).  Instances are sharded over ranks when torch.distributed is initialised and gradients are
         averaged, so every rank holds the same policy."""
         import numpy as np
-        from .distributed import instance_table, partition_bounds, philox_seed
+        from .distributed import instance_table, partition_bounds, philox_seed, shard_range
         from .environment import BatchedPBO_Env
         from .suite import Suite
         from .tester import _world
@@ -56,12 +56,16 @@ class Trainer(object):
             pidx, run = instance_table(len(problems), self.config.train_batch_size)
             # cost-weighted contiguous split like Tester's run_pairs (distributed.cost_partition): an epoch of lock-step training ends with the
             # slowest rank, and the table is function-sorted, so equal counts would leave the Gallagher / Weierstrass rank ~2x the work
-            bounds = partition_bounds(problems, pidx, world)
-            lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-            seeds = philox_seed(run, np.arange(len(pidx)), epoch_salt=epoch + 1)
-            if len(pidx) < world or bool(np.any(np.diff(bounds) <= 0)):              # decided from global quantities only: EVERY rank raises, none is left waiting in an all-reduce
+            if len(pidx) < world:                                                    # decided from global quantities only: EVERY rank raises, none is left waiting in an all-reduce
                 raise ValueError(f'train_batched: {world} ranks but only {len(pidx)} instances in the epoch, a rank would own none: '
                                  f'raise --train_batch_size or use fewer ranks')
+            bounds = partition_bounds(problems, pidx, world)
+            if bool(np.any(np.diff(bounds) <= 0)):
+                # few instances per rank and cost ratios up to ~2x: the cost midpoints can leave a rank empty although there are enough instances;
+                # such epochs train with the equal-count split (every rank owns at least one instance)
+                bounds = np.array([shard_range(len(pidx), r, world)[0] for r in range(world)] + [len(pidx)], dtype=np.int64)
+            lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+            seeds = philox_seed(run, np.arange(len(pidx)), epoch_salt=epoch + 1)
             env = BatchedPBO_Env(problems, self.optimizer, pidx[lo:hi], seeds[lo:hi], suite=suite)
             exceed, info = self.agent.train_batch(env)
             env.close()

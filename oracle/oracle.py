@@ -42,6 +42,7 @@ def lib():
         L.orc_rlepso_reset.argtypes = [C.c_void_p, _dp]
         L.orc_rlepso_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), _dp, _dp]
         L.orc_rlepso_state.argtypes = [C.c_void_p, _dp]
+        L.orc_rlepso_set_state.argtypes = [C.c_void_p, _dp]
         _lib = L
     return _lib
 
@@ -118,6 +119,11 @@ class RlepsoOracle:
         out = np.empty(rlepso_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint))
         lib().orc_rlepso_state(self._h, _p(out))
         return out
+
+    def set_state(self, block):
+        block = np.ascontiguousarray(block, dtype=np.float64)
+        assert block.shape == (rlepso_state_doubles(self.cfg.np, self.cfg.dim, self.cfg.n_logpoint),)
+        lib().orc_rlepso_set_state(self._h, _p(block))
 
 
 # scalar slots (include/mbx_layout.h)

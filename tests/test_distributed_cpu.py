@@ -142,6 +142,85 @@ def test_batched_training_with_unequal_episode_lengths_world2():
     assert np.array_equal(outs[0][2], outs[1][2])
 
 
+class _ScriptedInstances:
+    """Lock-step environment over the instances `ids` of a global table: per instance a fixed episode length (4 .. 12 steps) and reward sequence that
+    depend on the GLOBAL id only, so any partition of the table replays the same instances."""
+
+    def __init__(self, ids):
+        self.ids, self.B, self.t = list(ids), len(ids), 0
+        self.T = np.array([4 + (3 * i) % 9 for i in self.ids])
+        self.rw = np.stack([np.random.RandomState(1000 + i).choice([-1., 1.], size=16) for i in self.ids])
+
+    def reset(self):
+        self.t = 0
+        return torch.full((self.B, 1), 0.005, dtype=torch.float64)
+
+    def step(self, actions):
+        self.t += 1
+        state = 0.005 + 0.005 * np.minimum(self.t, self.T)           # a finished instance keeps reporting its terminal state, like the kernels
+        return (torch.as_tensor(state[:, None].copy()), torch.as_tensor(self.rw[:, self.t - 1].copy()), torch.as_tensor((self.t >= self.T).astype(np.uint8)))
+
+    def results(self):
+        return {'cost': torch.tensor([[1.0, 0.5]] * self.B, dtype=torch.float64)}
+
+
+def _forced_actions(ids):
+    return torch.as_tensor(np.stack([np.random.RandomState(2000 + i).uniform(0, 1, size=(16, 35)) for i in ids], 1).astype(np.float32))     # [T, B, 35]
+
+
+def _first_ppo_gradient(ids):
+    """The gradient RLEPSO_Agent.train_batch hands its optimizers at the first step of a batch over instances `ids` (after average_gradients)."""
+    from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
+    from metabox_amd.config import get_config
+    cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cpu', '--max_learning_step', '1000'])
+    cfg.agent_save_dir = None
+    cfg.save_interval = 10 ** 9
+    torch.manual_seed(0)
+    agent = RLEPSO_Agent(cfg)
+    params = list(agent.actor.parameters()) + list(agent.critic.parameters())
+    seen = []
+    opt = agent._RLEPSO_Agent__optimizer_actor
+    orig = opt.step
+
+    def step(*a, **k):
+        seen.append(torch.cat([p.grad.detach().reshape(-1).clone() for p in params]))
+        return orig(*a, **k)
+    opt.step = step
+    agent.train_batch(_ScriptedInstances(ids), max_updates=1, forced_actions=_forced_actions(ids))
+    return seen[0].numpy()
+
+
+def _weighted_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    q.put((rank, _first_ppo_gradient([0, 1] if rank == 0 else [2, 3, 4, 5, 6])))         # unequal shards, as cost_partition cuts them
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_of_unequal_shards_equals_the_single_rank_gradient_world2():
+    """shards are cost-weighted, so ranks own different numbers of instances and each normalises its loss by its OWN live count.  The
+    all-reduce weights every rank's gradient by that count (distributed.average_gradients(weight=...)): two ranks owning 2 and 5 instances must hand
+    their optimizers the gradient one rank owning all 7 computes -- the objective does not depend on the world size."""
+    want = _first_ppo_gradient(range(7))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 38500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_weighted_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(2)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert np.array_equal(outs[0][1], outs[1][1])
+    scale = np.abs(want).max()
+    assert np.abs(outs[0][1] - want).max() <= 2e-6 * scale, np.abs(outs[0][1] - want).max() / scale
+    # (the unweighted mean of the two per-rank means is a different vector: the test would fail by ~1e-1 of the gradient's scale)
+
+
 def _c5_table():
     """BASELINE config 5's instance table: 24 bbob + 30 noisy functions at D = 40, function-sorted, 65 536 instances (problem-major)."""
     from metabox_amd.problem.bbob import BBOB_Dataset
@@ -251,6 +330,60 @@ def test_train_batched_shards_by_predicted_cost(monkeypatch, tmp_path):
     per = np.array([cost[seen[r][0]].sum() for r in range(world)])
     eq = np.array([cost[pidx[slice(*shard_range(len(pidx), r, world))]].sum() for r in range(world)])
     assert per.max() / per.mean() < 1.05 < eq.max() / eq.mean()
+
+
+def test_train_batched_falls_back_to_equal_counts_when_a_cost_shard_would_be_empty(monkeypatch, tmp_path):
+    """with few instances per rank the cost midpoints can leave a rank without instances although len(table) >= world; such epochs
+    used to abort with a misleading message, now they are cut in equal counts.  Fewer instances than ranks still raises, on every rank."""
+    import types
+    import metabox_amd.environment as env_mod
+    import metabox_amd.suite as suite_mod
+    import metabox_amd.tester as tester_mod
+    import metabox_amd.trainer as trainer_mod
+    from metabox_amd.trainer import Trainer
+    ps, _ = _c5_table()
+    ps = ps[:3]
+    seen = {}
+
+    class _Env:
+        def __init__(self, problems, optimizer, pidx, seeds, suite=None):
+            self.pidx = np.asarray(pidx)
+
+        def close(self):
+            pass
+
+    class _Agent:
+        def train_batch(self, env):
+            seen[self.rank] = env.pidx
+            return True, {'learn_steps': 1, 'return': 0.0}
+
+    monkeypatch.setattr(env_mod, 'BatchedPBO_Env', _Env)
+    monkeypatch.setattr(suite_mod, 'Suite', lambda problems: None)
+    monkeypatch.setattr(trainer_mod, 'partition_bounds', lambda problems, pidx, world: np.array([0, 0, 2, len(pidx)]), raising=False)
+
+    def run(world, runs):
+        for rank in range(world):
+            monkeypatch.setattr(tester_mod, '_world', lambda rank=rank: (rank, world))
+            t = Trainer.__new__(Trainer)
+            t.config = types.SimpleNamespace(train_batch_size=runs, log_dir=str(tmp_path), run_time='t')
+            t.optimizer, t.agent = None, _Agent()
+            t.agent.rank = rank
+            t.train_set = types.SimpleNamespace(data=ps)
+            t.train_batched(max_epochs=1)
+    import metabox_amd.distributed as dmod
+    monkeypatch.setattr(dmod, 'partition_bounds', lambda problems, pidx, world: np.array([0, 0, 2, len(pidx)]))
+    run(3, 2)                                                   # 6 instances, a partition whose first shard is empty -> equal counts 2 / 2 / 2
+    assert [len(seen[r]) for r in range(3)] == [2, 2, 2]
+    with pytest.raises(ValueError, match='only 3 instances'):
+        run(4, 1)
+
+
+def test_batched_agents_declare_replication_on_the_class():
+    """the flag save_class reads must be true before the first train_batch call (checkpoint0 is written in __init__) and must not travel
+    in the pickled instance state."""
+    from metabox_amd.agent import DE_DDQN_Agent, GLEET_Agent, LDE_Agent, RLEPSO_Agent
+    for cls in (RLEPSO_Agent, LDE_Agent, GLEET_Agent, DE_DDQN_Agent):
+        assert cls.__dict__.get('_mbx_replicated') is True, cls
 
 
 def _save_worker(rank, world, port, out_dir):

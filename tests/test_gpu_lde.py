@@ -331,6 +331,10 @@ def test_lde_rollout_host_loop_route(monkeypatch):
     """Behind the same entry point: objective kinds the resident kernel does not build (F3, F15, F24: two arrays in the row sums / the candidate
     itself), another geometry (D = 10), and MBX_ROLLOUT_PER_GENERATION=1 take mbx_lde_policy + mbx_step per generation -- same records."""
     _lde_rollout_case('bbob', (1, 3, 15, 24), 50, 8, (2, 5), resident=False)
+    # whole short episodes on this route: instances terminate inside the second call and the third call starts with every instance done -- their
+    # (h, c) and action rows must stay untouched, as include/mbx.h promises for both routes (ADVICE r04)
+    r = _lde_rollout_case('bbob', (1, 3, 15, 24), 50, 8, (4, 9, 30), resident=False, maxfes=50 * 12)
+    assert np.all(r['steps'] == 11)
     monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')
     _lde_rollout_case('bbob-noisy', (101, 128), 100, 8, (3, 4), resident=False)
 

@@ -113,3 +113,86 @@ def test_two_ranks_on_one_gpu_gather_the_unsharded_table(n_total):
         assert full.shape == want.shape
         assert np.array_equal(full, want, equal_nan=True), (rank, 'gathered table differs from the unsharded batch')
     assert want[:, -1].min() == GENS or want[:, -1].min() > 0          # every instance stepped
+
+
+# ------------------------------------------------------------------------------------------------------------ RCCL, one rank
+def _nccl1_worker(port, q):
+    """world size 1, backend nccl (= RCCL) on cuda:0, collectives forced (MBX_FORCE_COLLECTIVES=1): real result rows through gather_rows, real
+    gradients through average_gradients, the loop-control flag through all_ranks_any -- the device-tensor branch of every collective this
+    framework issues."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ['MBX_FORCE_COLLECTIVES'] = '1'
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import torch.distributed as dist
+        from metabox_amd.distributed import all_ranks_any, average_gradients, gather_rows
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        n = 48
+        pidx, seeds = _table(n)
+        rows = _run_rows(pidx, seeds, 12)
+        assert rows.is_cuda
+        full = gather_rows(rows, n, bounds=np.array([0, n]))                       # all_gather over RCCL (padded shard, cost-weighted bounds form)
+        full_eq = gather_rows(rows, n)                                             # ... and the equal-count form
+        torch.manual_seed(0)
+        net = torch.nn.Linear(35, 7).to(dev)
+        net(torch.rand(5, 35, device=dev)).sum().backward()
+        before = [p.grad.clone() for p in net.parameters()]
+        average_gradients(list(net.parameters()), weight=torch.tensor(5., device=dev))   # weighted flat all-reduce over RCCL
+        after_w = [p.grad.clone() for p in net.parameters()]
+        average_gradients(list(net.parameters()))                                  # plain mean
+        flags = (all_ranks_any(True, dev), all_ranks_any(False, dev))              # scalar MAX all-reduce on a device tensor
+        t = torch.arange(8, dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        q.put(('ok', dist.get_backend(), torch.equal(full, rows) and torch.equal(full_eq, rows),
+               all(torch.allclose(a, b, rtol=1e-6, atol=0) for a, b in zip(before, after_w)) and
+               all(torch.allclose(a, p.grad, rtol=1e-6, atol=0) for a, p in zip(before, net.parameters())),
+               flags, t.cpu().tolist()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:
+        import traceback
+        q.put(('error', repr(exc), traceback.format_exc()))
+
+
+def test_rccl_world_size_one_runs_every_collective_of_the_framework():
+    """no test or bench had ever executed an `nccl` process group (two ranks on one device fall back to gloo above), so the first RCCL
+    call of this code would have been the driver's 8-GPU run.  One rank, backend nccl, on cuda:0: result rows, gradients and the loop-control flag go
+    through RCCL's all_gather / all_reduce on device tensors."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl1_worker, args=(39500 + os.getpid() % 2000, q))
+    p.start()
+    try:
+        out = q.get(timeout=300)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert out[0] == 'ok', out
+    _, backend, rows_ok, grads_ok, flags, summed = out
+    print(f'world-size-1 process group, backend = {backend}')
+    assert backend == 'nccl' and rows_ok and grads_ok and flags == (True, False) and summed == list(map(float, range(8)))
+
+
+def test_bench_under_torchrun_one_rank_nccl():
+    """The driver's launch line at N = 1 through torch.distributed.run with the RCCL backend: bench.py builds the process group, the max-over-ranks /
+    sum-over-ranks reductions and the per-rank diagnostics run through RCCL on device tensors (over_ranks), and the line says `"backend": "nccl"`."""
+    import json
+    import subprocess
+    port = 41500 + os.getpid() % 2000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '12', '--warmup', '3',
+                          '--dist-backend', 'nccl', '--no-cpu-baseline', '--no-other-configs', '--no-pmc', '--repeats', '3'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-400:]
+    d = json.loads(lines[0])
+    assert d['backend'] == 'nccl' and d['n_gpus'] == 1 and d['ranks_seen'] == [{'rank': 0, 'device': 0}]
+    assert d['value'] > 1e6 and len(d['per_rank']['ms_per_step']) == 1

@@ -9,8 +9,13 @@ optimizer step, the weights afterwards.
 The same data is replayed through THIS framework's update code -- `train_batch` at B = 1 (which `train_episode` is), with the recorded
 actions forced -- and the gradients at every optimizer step and the final weights must agree.
 
-Tolerances (float32 networks, CPU): gradients 2e-5 relative to the largest entry of the tensor (+1e-9); weight change after the updates
+Tolerances (float32 networks): gradients 2e-5 relative to the largest entry of the tensor (+1e-9); weight change after the updates
 within 2 % of the learning rate per step taken (Adam's first steps move every weight by ~lr, so the DELTA is what carries information).
+
+Every parity test runs on the CPU (`-m "not gpu"`) and, gpu-marked, with networks, optimizer state and the whole update on cuda:0 -- the device the
+framework trains on.  test_rlepso_ppo_update_from_resident_segments_reproduces_the_reference additionally feeds the reference's
+recorded transitions through the RESIDENT collection path (train_batch(collect='resident'): one mbx_rlepso_rollout trajectory block per segment, log-probabilities
+and values evaluated over the whole [n_step, B] block): same gradients as the reference's step-by-step loop.
 """
 import types
 
@@ -23,9 +28,12 @@ from helpers import load
 G = load('train_updates.npz')
 
 
-def _cfg(problem='bbob', dim=10):
+DEVICES = ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)]
+
+
+def _cfg(problem='bbob', dim=10, device='cpu'):
     from metabox_amd.config import get_config
-    cfg = get_config(['--problem', problem, '--dim', str(dim), '--device', 'cpu', '--max_learning_step', '1000'])
+    cfg = get_config(['--problem', problem, '--dim', str(dim), '--device', device, '--max_learning_step', '1000'])
     cfg.agent_save_dir = None
     cfg.save_interval = 10 ** 9
     return cfg
@@ -46,7 +54,7 @@ def _hook(opt, named, sink, tag):
     orig = opt.step
 
     def step(*a, **k):
-        sink.append((tag, {n: p.grad.detach().clone().numpy() for n, p in named}))
+        sink.append((tag, {n: p.grad.detach().cpu().clone().numpy() for n, p in named}))
         return orig(*a, **k)
     opt.step = step
 
@@ -70,39 +78,82 @@ def _ours(name):
 class _ScriptedBatch:
     """B = 1 lock-step environment that replays the fixture's states / rewards and ends after T steps."""
 
-    def __init__(self, tag):
+    def __init__(self, tag, device='cpu'):
         self.states, self.rewards, self.B, self.t = G[f'{tag}/states'], G[f'{tag}/rewards'], 1, 0
-        self.seen = []
+        self.actions = G[f'{tag}/actions'] if f'{tag}/actions' in G.files else None
+        self.seen, self.dev = [], torch.device(device)
+        self.batch = self                                   # the resident collection path talks to env.batch (suite.Batch protocol)
 
     def reset(self):
         self.t = 0
-        return torch.as_tensor(self.states[0].reshape(1, 1))
+        return torch.as_tensor(self.states[0].reshape(1, 1)).to(self.dev)
 
     def step(self, actions):
-        self.seen.append(actions.detach().numpy().copy())
+        self.seen.append(actions.detach().cpu().numpy().copy())
         self.t += 1
         done = self.t >= len(self.rewards)
-        return (torch.as_tensor(self.states[self.t].reshape(1, 1)), torch.tensor([self.rewards[self.t - 1]], dtype=torch.float64),
-                torch.tensor([1 if done else 0], dtype=torch.uint8))
+        return (torch.as_tensor(self.states[self.t].reshape(1, 1)).to(self.dev), torch.tensor([self.rewards[self.t - 1]], dtype=torch.float64, device=self.dev),
+                torch.tensor([1 if done else 0], dtype=torch.uint8, device=self.dev))
 
     def results(self):
-        return {'cost': torch.tensor([[1.0, 0.5]], dtype=torch.float64)}
+        return {'cost': torch.tensor([[1.0, 0.5]], dtype=torch.float64, device=self.dev)}
+
+    # ---- what collect_segment_resident asks of a suite.Batch: the (mu, sigma) table and one trajectory block per segment.  The block replays the
+    # reference's recorded transitions in mbx_rlepso_rollout's format ([n, B, .] records; after the episode's end: reward 0, done 1, state frozen).
+    def policy_table(self, *net):
+        return None
+
+    def rlepso_rollout(self, table, n, trajectory=False):
+        T = len(self.rewards)
+        acts = np.zeros((n, 1, 35), np.float32); st = np.zeros((n, 1)); rw = np.zeros((n, 1)); dn = np.ones((n, 1), np.uint8)
+        for g in range(n):
+            t = self.t + g
+            if t < T:
+                acts[g, 0] = self.actions[t]; st[g, 0] = np.ravel(self.states[t + 1])[0]; rw[g, 0] = np.ravel(self.rewards[t])[0]; dn[g, 0] = 1 if t + 1 >= T else 0
+            else:
+                st[g, 0] = np.ravel(self.states[T])[0]
+        self.t = min(self.t + n, T)
+        traj = {'actions': torch.as_tensor(acts), 'state': torch.as_tensor(st), 'reward': torch.as_tensor(rw), 'done': torch.as_tensor(dn)}
+        return None, None, None, {k: v.to(self.dev) for k, v in traj.items()}
 
 
-@pytest.mark.parametrize('tag', ['ppo10', 'ppo7', 'ppo13'])
-def test_rlepso_ppo_update_reproduces_the_reference(tag):
+def _ppo_agent(tag, device):
     from metabox_amd.agent.rlepso_agent import RLEPSO_Agent
-    agent = RLEPSO_Agent(_cfg()).load_exported_weights(_Sub(f'{tag}/init/'))
-    actor, critic = agent.actor, agent.critic
+    agent = RLEPSO_Agent(_cfg(device=device)).load_exported_weights(_Sub(f'{tag}/init/')).to(device)
     sink = []
-    _hook(agent._RLEPSO_Agent__optimizer_actor, list(actor.named_parameters()), sink, 'actor')
-    _hook(agent._RLEPSO_Agent__optimizer_critic, list(critic.named_parameters()), sink, 'critic')
-    env = _ScriptedBatch(tag)
+    _hook(agent._RLEPSO_Agent__optimizer_actor, list(agent.actor.named_parameters()), sink, 'actor')
+    _hook(agent._RLEPSO_Agent__optimizer_critic, list(agent.critic.named_parameters()), sink, 'critic')
+    assert all(p.device.type == device for p in agent.actor.parameters())
+    return agent, sink
+
+
+@pytest.mark.parametrize('device', DEVICES)
+@pytest.mark.parametrize('tag', ['ppo10', 'ppo7', 'ppo13'])
+def test_rlepso_ppo_update_reproduces_the_reference(tag, device):
+    agent, sink = _ppo_agent(tag, device)
+    env = _ScriptedBatch(tag, device)
     forced = torch.as_tensor(G[f'{tag}/actions'])[:, None, :]                  # [T, 1, 35]
     exceed, info = agent.train_batch(env, forced_actions=forced)
     n_upd = int(G[f'{tag}/n_updates'])
-    assert not exceed and info['learn_steps'] == n_upd and len(sink) == 2 * n_upd
     assert np.array_equal(np.concatenate(env.seen), G[f'{tag}/actions'])
+    _check_ppo(agent, sink, tag, exceed, info, n_upd)
+
+
+@pytest.mark.parametrize('device', DEVICES)
+@pytest.mark.parametrize('tag', ['ppo10', 'ppo7', 'ppo13'])
+def test_rlepso_ppo_update_from_resident_segments_reproduces_the_reference(tag, device):
+    """train_batch(collect='resident'): the segment arrives as ONE trajectory block in mbx_rlepso_rollout's format (here: the reference's recorded
+    transitions, padded past the episode's end the way the kernel reports finished instances) and log-probabilities / values are evaluated over the
+    whole block at once; gradients and weights must still be the reference's (rlepso_agent.py:192-276)."""
+    agent, sink = _ppo_agent(tag, device)
+    env = _ScriptedBatch(tag, device)
+    exceed, info = agent.train_batch(env, collect='resident')
+    _check_ppo(agent, sink, tag, exceed, info, int(G[f'{tag}/n_updates']))
+
+
+def _check_ppo(agent, sink, tag, exceed, info, n_upd):
+    actor, critic = agent.actor, agent.critic
+    assert not exceed and info['learn_steps'] == n_upd and len(sink) == 2 * n_upd
     assert info['return'] == pytest.approx(float(G[f'{tag}/rewards'].sum()))
     ref_keys = [k for k in G.files if k.startswith(f'{tag}/grad0/')]
     assert len(ref_keys) == 18                                                  # 12 actor + 6 critic tensors
@@ -117,7 +168,7 @@ def test_rlepso_ppo_update_reproduces_the_reference(tag):
         for k in [k for k in G.files if k.startswith(f'{tag}/post/{which}/')]:
             name = _ours(k.split('/', 3)[3])
             init = G[k.replace('/post/', '/init/')]
-            d_ref, d_got = G[k] - init, sd[name].numpy() - init
+            d_ref, d_got = G[k] - init, sd[name].cpu().numpy() - init
             assert np.abs(d_ref).max() > 0.5 * lr                               # the update did move the weights
             assert np.abs(d_got - d_ref).max() <= 0.02 * lr * n_upd, (tag, which, name, np.abs(d_got - d_ref).max())
 
@@ -179,10 +230,12 @@ def test_every_rollout_policy_sees_the_weights_after_an_update():
 
 
 # ------------------------------------------------------------------------------------------------------------- LDE / REINFORCE
+@pytest.mark.parametrize('device', DEVICES)
 @pytest.mark.parametrize('tag', ['lde_equal', 'lde_ragged'])
-def test_lde_reinforce_update_reproduces_the_reference(tag):
+def test_lde_reinforce_update_reproduces_the_reference(tag, device):
     from metabox_amd.agent.lde_agent import LDE_Agent
-    agent = LDE_Agent(_cfg()).load_exported_weights(_Sub(f'{tag}/init/'))
+    agent = LDE_Agent(_cfg(device=device)).load_exported_weights(_Sub(f'{tag}/init/')).to(device)
+    assert all(p.device.type == device for p in agent.net.parameters())
     net = agent.net
     sink = []
     _hook(agent._LDE_Agent__optimizer, list(net.named_parameters()), sink, 'net')
@@ -220,18 +273,20 @@ def test_lde_reinforce_update_reproduces_the_reference(tag):
     for k in [k for k in G.files if k.startswith(f'{tag}/post/net/')]:
         name = k.split('/', 3)[3].replace(strip, '')
         init = G[k.replace('/post/', '/init/')]
-        assert np.abs((sd[name].numpy() - init) - (G[k] - init)).max() <= 0.02 * lr, (tag, name)
+        assert np.abs((sd[name].cpu().numpy() - init) - (G[k] - init)).max() <= 0.02 * lr, (tag, name)
 
 
 # ------------------------------------------------------------------------------------------------------------- DE-DDQN
-def test_ddqn_updates_reproduce_the_reference():
+@pytest.mark.parametrize('device', DEVICES)
+def test_ddqn_updates_reproduce_the_reference(device):
     from metabox_amd.agent.de_ddqn_agent import DE_DDQN_Agent
-    agent = DE_DDQN_Agent(_cfg('protein', 12)).load_exported_weights(_Sub('ddqn/init/'))
+    agent = DE_DDQN_Agent(_cfg('protein', 12, device)).load_exported_weights(_Sub('ddqn/init/')).to(device)
+    assert all(p.device.type == device for p in agent.q_net.parameters())
     net = agent.q_net
     sink = []
     _hook(agent._DE_DDQN_Agent__optimizer, list(net.named_parameters()), sink, 'net')
     for u in range(3):
-        b = {n: torch.as_tensor(G[f'ddqn/batch{u}/{n}']) for n in ('obs', 'act', 'rew', 'nxt', 'done')}
+        b = {n: torch.as_tensor(G[f'ddqn/batch{u}/{n}']).to(device) for n in ('obs', 'act', 'rew', 'nxt', 'done')}
         agent.learn_from_batch(b['obs'], b['act'], b['rew'], b['nxt'], b['done'])
         for k in [k for k in G.files if k.startswith(f'ddqn/grad{u}/net/')]:
             _close_grad(sink[u][1][k.split('/', 3)[3]], G[k], ('ddqn', u, k))
@@ -240,4 +295,4 @@ def test_ddqn_updates_reproduce_the_reference():
     for k in [k for k in G.files if k.startswith('ddqn/post/net/')]:
         name = k.split('/', 3)[3]
         init = G[k.replace('/post/', '/init/')]
-        assert np.abs((sd[name].numpy() - init) - (G[k] - init)).max() <= 0.02 * lr * 3, name
+        assert np.abs((sd[name].cpu().numpy() - init) - (G[k] - init)).max() <= 0.02 * lr * 3, name
