@@ -529,6 +529,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 10) b->fixed_geometry = 1;
             if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
             if (b->threads == 512 && cfg->np == 100 && cfg->dim == 30) b->fixed_geometry = 7;
+            if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 12) b->fixed_geometry = 8;     // protein docking: resident rollout only, the one-generation kernel stays the run-time-geometry one
         }
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
@@ -570,6 +571,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<256, 100, 12, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -904,7 +906,7 @@ extern "C" int mbx_rlepso_rollout_resident(const mbx_batch* b)
     if (!b) return fail(MBX_E_ARG, "mbx_rlepso_rollout_resident: null batch");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return 0;
     if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !b->rl_run_kinds_ok) return 0;
-    return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7) && !b->rollout_per_generation ? 1 : 0;
+    return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7 || b->fixed_geometry == 8) && !b->rollout_per_generation ? 1 : 0;
 }
 
 __global__ void k_sum_rewards(double* __restrict__ acc, const double* __restrict__ r, int n, int first)
@@ -927,6 +929,8 @@ static int launch_rlepso_run(mbx_batch* b, const float* d_table, int rows, int n
         hipLaunchKernelGGL((k_rlepso_run<512, 100, 30, 5>), dim3(b->B), dim3(512), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
     else if (b->fixed_geometry == 2)
         hipLaunchKernelGGL((k_rlepso_run<1024, 128, 40, 5>), dim3(b->B), dim3(1024), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
+    else if (b->fixed_geometry == 8)
+        hipLaunchKernelGGL((k_rlepso_run<256, 100, 12, 5>), dim3(b->B), dim3(256), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
     else
         return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: no instantiation for this geometry");
     HIP_TRY(hipGetLastError());

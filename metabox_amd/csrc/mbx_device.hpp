@@ -6,6 +6,7 @@
 // Arithmetic is float64 and the translation unit is built with -ffp-contract=off so that element-wise
 // expressions round like numpy's (no implicit FMA).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -688,7 +689,9 @@ __device__ void eval_rows(const PT& P, const EvalLds& L, int n, const RowPost* p
 {
     if constexpr (KIND == 0) {
         if (P.kind == MBX_KIND_PROTEIN) {
-            eval_rows_protein<DC, PT, protein_prefetch(DC)>(P, L, n);
+            // (four pairs in flight only where the caller has the registers: k_dq_step's DevProblem route; the RLEPSO / LDE generation kernels hand a
+            //  ConstProblem and run under a 96-register cap next to their resident state -- the plain loop, same sums)
+            eval_rows_protein<DC, PT, (std::is_same<PT, DevProblem>::value ? protein_prefetch(DC) : 1)>(P, L, n);
             if (post) { for (int i = threadIdx.x; i < n; i += MBX_NT) L.F[i] = row_post(P, *post, i, L.F[i]); __syncthreads(); }
             return;
         }

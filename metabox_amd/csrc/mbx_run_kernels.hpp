@@ -9,6 +9,7 @@ namespace mbx {
 extern template __global__ void k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>(BatchParams, const float*, int, int, RunOut);
 extern template __global__ void k_rlepso_run<1024, 128, 40, 5>(BatchParams, const float*, int, int, RunOut);
 extern template __global__ void k_rlepso_run<512, 100, 30, 5>(BatchParams, const float*, int, int, RunOut);
+extern template __global__ void k_rlepso_run<256, 100, 12, 5>(BatchParams, const float*, int, int, RunOut);
 extern template __global__ void k_lde_run<100, 30>(LdeRunArgs);
 extern template __global__ void k_lde_run<50, 30>(LdeRunArgs);
 }  // namespace mbx

@@ -9,4 +9,5 @@ namespace mbx {
 template __global__ void k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>(BatchParams, const float*, int, int, RunOut);
 template __global__ void k_rlepso_run<1024, 128, 40, 5>(BatchParams, const float*, int, int, RunOut);
 template __global__ void k_rlepso_run<512, 100, 30, 5>(BatchParams, const float*, int, int, RunOut);
+template __global__ void k_rlepso_run<256, 100, 12, 5>(BatchParams, const float*, int, int, RunOut);      // protein docking (src/config.py:86-90: dim 12), any-kind body
 }  // namespace mbx

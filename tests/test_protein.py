@@ -172,3 +172,59 @@ def test_hip_rlepso_and_lde_on_protein_replay_reference():
         assert n == len(TR[f'{c}/cost']) and close(res['cost'][0, :n].cpu().numpy(), TR[f'{c}/cost']), c
         assert res['cost'].shape[1] == 6
         b.close()
+
+
+@pytest.mark.gpu
+def test_protein_rlepso_resident_rollout_equals_per_generation_and_matches_the_oracle():
+    """RLEPSO on protein docking (src/config.py:86-90: dim 12, maxFEs 1000, 5 log points; the setting of the published T2 row) takes the resident route:
+    k_rlepso_run<256, 100, 12, 5> keeps the swarm on chip across the nine generations of an episode.  Whole episodes in uneven chunks, bit for bit
+    against mbx_rlepso_act_step per generation (the run-time-geometry kernel), and against the C oracle on the actions the kernel drew."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    byid, tr, te, _ = protein()
+    pids = [tr[0], tr[7], te[0], '1AVX_1', '7CEI_3', te[-1]]
+    ps = [byid[p] for p in pids]
+    s = Suite(ps)
+    B = 12
+    pidx, seeds = np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) * 7919 + 3
+    a = Batch(s, ALGO_RLEPSO, pidx, seeds, 100, 1000, 200, 5)
+    b = Batch(s, ALGO_RLEPSO, pidx, seeds, 100, 1000, 200, 5)
+    assert a.rollout_is_resident() and a.launch_info()['fixed_geometry'] == 8, a.launch_info()
+    table = torch.rand(1000 + 200 + 1, 2, 35, generator=torch.Generator().manual_seed(9)).cuda()
+    table[:, 1] = 0.05 + 0.3 * table[:, 1]
+    table = table.contiguous()
+    a.reset(); b.reset()
+    acts_all = []
+    for n in (4, 3, 4):                                   # the episode ends inside the third launch (9 generations), which then idles
+        st, rw, dn, traj = a.rlepso_rollout(table, n, trajectory=True)
+        st, rw, dn = st.clone(), rw.clone(), dn.clone()
+        acts_all.append(traj['actions'].cpu().numpy().copy())
+        rsum = torch.zeros(B, dtype=torch.float64, device='cuda')
+        for g in range(n):
+            live = (b.done == 0).clone()
+            sb, rb, db, acts = b.act_step(table, want_actions=True)
+            assert torch.equal(traj['state'][g], sb[:, 0]) and torch.equal(traj['reward'][g], rb) and torch.equal(traj['done'][g], db), g
+            assert torch.equal(traj['actions'][g][live], acts[live]), g
+            rsum += rb
+        assert torch.equal(st[:, 0], sb[:, 0]) and torch.equal(dn, db) and torch.equal(rw, rsum)
+        torch.cuda.synchronize()
+        for k in range(B):
+            assert np.array_equal(a.read_state(k), b.read_state(k), equal_nan=True), k
+    ra, rb_ = a.results(), b.results()
+    for key in ra:
+        assert torch.equal(ra[key], rb_[key]), key
+    assert torch.all(ra['steps'] == 9) and torch.all(ra['fes'] >= 1000)
+    acts_all = np.concatenate(acts_all)[:9]
+    cfg = oracle.make_cfg(1, 100, 12, 1000, 200, 5)
+    for k in range(B):
+        o = oracle.RlepsoOracle(ps[pidx[k]].desc(), None, cfg, seed=int(seeds[k]))
+        o.reset()
+        for g in range(9):
+            _, _, d = o.step(acts_all[g, k])
+        assert d
+        want = oracle.split_rlepso_state(o.state(), 100, 12, 5)
+        got = oracle.split_rlepso_state(a.read_state(k), 100, 12, 5)
+        assert close(got['scalars'][oracle.SC_GBEST], want['scalars'][oracle.SC_GBEST]) and got['scalars'][oracle.SC_FES] == want['scalars'][oracle.SC_FES], k
+        assert close(got['pbest'], want['pbest']) and close(got['cost'], want['cost']), k
+    a.close(); b.close()
