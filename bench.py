@@ -4,8 +4,10 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-A *step* is one lock-step generation of the whole instance batch: one batched policy forward (PyTorch-ROCm) and
-one fused RLEPSO generation kernel (mbx_step).  An episode is 199 generations (maxFEs = 20 000, pop 100); when it
+A *step* is one lock-step generation of the whole instance batch: agent.act (the actor's (mu, sigma) looked up in the per-state table that ONE
+mbx_rlepso_policy_table launch builds per weight set, sampled inside the generation kernel) + RLEPSO_Optimizer.update + problem.eval, i.e. one
+generation of the resident kernel k_rlepso_run (mbx_rlepso_rollout, --gens-per-launch generations per launch; --policy selects the older routes: a
+PyTorch / HIP policy forward + mbx_step per generation).  An episode is 199 generations (maxFEs = 20 000, pop 100); when it
 ends the batch is re-initialised (mbx_reset, a new Philox episode) and stepping continues, so K steps may span
 several episodes.  value = env-steps/s = sum over the K timed steps of the number of instances that were not yet
 done (reference stop rule gbest <= 1e-8 kept) / wall time, aggregated over all ranks (weak scaling: 4096
@@ -15,8 +17,9 @@ timed region.
 Also reported on the same JSON line:
   roofline     — fused generation kernel: algorithmic bytes (54.0 KB per env-step) x live instances
                  per launch / average kernel duration measured with HIP events on the launch stream, vs 8 TB/s.
-  roofline.valu — the kernel is VALU-issue bound, not bandwidth bound: wave-instructions per launch and the issue bound they imply,
-                 from the committed PMC profile (profiles/r*_pmc_hbm_traffic.json, `valu_issue_bound`), beside the measured time.
+  roofline.valu — the kernel is VALU-issue bound, not bandwidth bound: wave-instructions per generation (one rocprofv3 --pmc child pass) priced at 4 cycles each
+                 against the SIMD cycles of the TIMED window, whose shader clock is sampled by a probe wave beside the kernel, no profiler attached
+                 (frac_timed_window; useful_f64_frac = that x float64 share x active lanes / 64); the profiled launch's own ratio stays as frac_profiled_launch.
   other_configs — one GPU's share of BASELINE.json configs 3 (LDE, NP = 50 and NP = 100), 4 (DE-DDQN on protein docking) and
                  5 (RLEPSO D = 40, NP = 128): ms per lock-step step, env-steps/s, algorithmic bytes and roofline fraction (N = 1 only).
   cpu_baseline — the C oracle (a float64 port of the reference path, oracle/mbx_oracle.c) on all host cores (one
@@ -600,6 +603,53 @@ def main():
             live += steps_sum() - base
         return elapsed, live, launches, marks, mark_step, reset_steps
 
+    def window_clock():
+        """Shader clock during the timed window, no profiler attached: the window once more (reset, W warm-up generations, the same K generations in the same
+        launches) with a one-wave probe kernel on a side stream sampling s_memtime (shader cycles) and s_memrealtime (100 MHz) beside it
+        (mbx_debug_clock_probe), bracketed on the launch stream by two mbx_debug_clock_mark.  -> dict or None."""
+        if not resident:
+            return None
+        import ctypes as C
+        lib = env.batch.lib
+        n_s = 2048
+        est_s = max(K * 0.12e-3, 1e-3)                                   # ~0.11 ms per generation
+        sleep_units = max(127, int(est_s * 1.6 / n_s * 2.1e9 / 64))
+        buf = torch.zeros(n_s, 2, dtype=torch.int64, device=dev)
+        marks = torch.zeros(2, 2, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream()
+        main_s = torch.cuda.current_stream()
+        with torch.no_grad():
+            env.reset()
+            it = 0
+            while it < W:
+                n = min(max(1, args.gens_per_launch), EPISODE_GENS, W - it)
+                env.batch.rlepso_rollout(fused_table, n)
+                it += n
+            torch.cuda.synchronize()
+            if lib.mbx_debug_clock_probe(C.c_void_p(buf.data_ptr()), n_s, sleep_units, C.c_void_p(side.cuda_stream)) != 0:
+                return None
+            lib.mbx_debug_clock_mark(C.c_void_p(marks[0].data_ptr()), C.c_void_p(main_s.cuda_stream))
+            it, gen_in_ep = 0, W % EPISODE_GENS
+            while it < K:
+                n = min(max(1, args.gens_per_launch), EPISODE_GENS - gen_in_ep, K - it)
+                if n <= 0:
+                    break                                                  # (an episode restart inside the window: the clock of the first part is enough)
+                env.batch.rlepso_rollout(fused_table, n)
+                it += n; gen_in_ep += n
+            lib.mbx_debug_clock_mark(C.c_void_p(marks[1].data_ptr()), C.c_void_p(main_s.cuda_stream))
+            torch.cuda.synchronize()
+        b, m = buf.cpu().numpy(), marks.cpu().numpy()
+        inside = (b[:, 1] >= m[0, 1]) & (b[:, 1] <= m[1, 1])
+        if inside.sum() < 8:
+            return None
+        t, r = b[inside, 0].astype(np.float64), b[inside, 1].astype(np.float64)
+        ticks = (t[-1] - t[0]) / (r[-1] - r[0])                            # shader-counter ticks per 10 ns
+        per = np.diff(t) / np.diff(r)
+        return {'clock_ghz': ticks * 0.1, 'clock_ghz_min_max_over_samples': [float(per.min() * 0.1), float(per.max() * 0.1)], 'samples_in_window': int(inside.sum()),
+                'window_us_realtime_counter': float((m[1, 1] - m[0, 1]) * 0.01), 'generations': int(it),
+                'method': 'one probe wave on a side stream beside the timed launches, no profiler: delta s_memtime / delta s_memrealtime (100 MHz) over the samples between two marks '
+                          'on the launch stream (mbx_debug_clock_probe / mbx_debug_clock_mark)'}
+
     red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
 
     def over_ranks(elapsed, live):
@@ -688,6 +738,30 @@ def main():
             if per_step is not None:
                 traffic, traffic_in_run = per_step * live_per_launch, True
         first_gen = W % EPISODE_GENS + 1
+        if valu_in_run is not None:
+            # the PMC child ran under the profiler (lower clock, longer launch): its ratio is the profiled launch's.  The wave-instruction COUNT is the same work in
+            # the timed window; price it against the timed window's SIMD cycles at the clock sampled there.
+            valu_in_run['frac_profiled_launch'] = valu_in_run.pop('frac')
+            valu_in_run['clock_ghz_profiled_launch'] = valu_in_run.pop('clock_ghz')
+            try:
+                wc = window_clock() if world == 1 else None
+            except Exception as exc:
+                wc = {'error': repr(exc)}
+            valu_in_run['timed_window_clock'] = wc
+            if wc and wc.get('clock_ghz') and 1.0 < wc['clock_ghz'] < 3.0:
+                # per LIVE instance-generation, so that windows with finished instances are priced right
+                wi = valu_in_run['wave_instructions_per_env_step'] * live_per_gen
+                valu_in_run['clock_ghz'] = wc['clock_ghz']
+                valu_in_run['frac'] = wi * 4. / (1024. * wc['clock_ghz'] * 1e9 * avg_gen_s)
+                valu_in_run['frac_is'] = ('vector wave-instructions per generation (profiled child, same work) x 4 issue cycles / (1024 SIMDs x the TIMED window\'s clock x its '
+                                          'average generation time by HIP events)')
+            else:
+                valu_in_run['frac'] = valu_in_run['frac_profiled_launch']
+                valu_in_run['clock_ghz'] = valu_in_run['clock_ghz_profiled_launch']
+                valu_in_run['frac_is'] = 'the profiled launch\'s own ratio (no usable clock sample of the timed window)'
+            if valu_in_run.get('f64_share') and valu_in_run.get('active_lanes_per_instruction'):
+                # issue slots are not useful work: the share of float64 arithmetic among the vector instructions x the lanes that are switched on
+                valu_in_run['useful_f64_frac'] = valu_in_run['frac'] * valu_in_run['f64_share'] * valu_in_run['active_lanes_per_instruction'] / 64.
         out = {
             'metric': 'env-steps/sec (instances x gens/s), RLEPSO bbob-easy d=10', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed_max / K * 1e3, 'higher_is_better': True,
@@ -719,6 +793,11 @@ def main():
                                         (f'one HIP event every {stride} generations on the launch stream; consecutive events bracket {stride} back-to-back '
                                          f'generation kernels (all of them are covered), minus the cost of an empty event pair ({pair_ms * 1e3:.1f} us)'),
                        'policy_table_build_us': table_build_us,
+                       # the policy work north_star puts on the step path, memoised: the actor is a function of ONE scalar state (fes / maxFEs), so it is evaluated once
+                       # per weight set at every reachable fes (one mbx_rlepso_policy_table launch) and every generation of every instance looks its row up
+                       'policy_table_amortisation': (f'one build per weight set = per {EPISODE_GENS} generations x {B} instances ({EPISODE_GENS * B} env-steps) in a rollout: '
+                                                     f'{(table_build_us or 0.) / EPISODE_GENS:.2f} us per generation if charged to the step path, outside the timed window; '
+                                                     f'training rebuilds it after every optimizer step (n_step = 10 generations)'),
                        'timed_window': f'{K} consecutive lock-step generations starting at generation {first_gen} of an episode of {EPISODE_GENS} '
                                        f'(episodes restart with mbx_reset inside the window when it is longer)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -340,6 +340,14 @@ int mbx_debug_rlepso_draws(uint64_t seed, int gen, int episode, int np, int dim,
  * between the state blocks of consecutive instances (>= mbx_instance_state_doubles).  Host-only, no device work. */
 int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4]);
 
+/* Measurement: the shader clock DURING somebody else's kernel.  One wave takes `n_samples` samples, `sleep_units` x 64 clocks apart (s_sleep), of the
+ * shader's cycle counter (s_memtime) and of the constant 100 MHz real-time counter (s_memrealtime): d_out [n_samples, 2] uint64.  Launched on a side stream
+ * next to a timed window, the ratio of the two differences is the clock the chip ran at in that window WITHOUT a profiler attached (bench.py:
+ * roofline.valu.clock_ghz; rocprofv3's counter passes lower the clock).  mbx_debug_clock_mark writes one (s_memtime, s_memrealtime) pair: two marks around a
+ * launch on its own stream bracket it in the same time base. */
+int mbx_debug_clock_probe(uint64_t* d_out, int n_samples, int sleep_units, void* stream);
+int mbx_debug_clock_mark(uint64_t* d_out2, void* stream);
+
 const char* mbx_last_error(void);
 /* "metabox_amd libmbx <major.minor> (gfx950; Philox stream layout <n>: ...)".  The stream layout number changes whenever the assignment of Philox
  * counters to draws changes (include/mbx_layout.h section 3): trajectories, tapes and golden files made under another layout number do not

@@ -1136,6 +1136,37 @@ extern "C" int mbx_debug_rlepso_draws(uint64_t seed, int gen, int episode, int n
     return MBX_OK;
 }
 
+__global__ void k_clock_probe(uint64_t* __restrict__ out, int n, int sleep_units)
+{
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+        out[2 * i] = t; out[2 * i + 1] = r;
+        for (int k = 0; k < sleep_units; k += 127) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks per instruction
+    }
+}
+
+__global__ void k_clock_mark(uint64_t* __restrict__ out)
+{
+    if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime(); out[1] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+extern "C" int mbx_debug_clock_probe(uint64_t* d_out, int n_samples, int sleep_units, void* stream)
+{
+    if (!d_out || n_samples < 2 || sleep_units < 1) return fail(MBX_E_ARG, "mbx_debug_clock_probe: bad arguments");
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out, n_samples, sleep_units);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_debug_clock_mark(uint64_t* d_out2, void* stream)
+{
+    if (!d_out2) return fail(MBX_E_ARG, "mbx_debug_clock_mark: bad arguments");
+    hipLaunchKernelGGL(k_clock_mark, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out2);
+    HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
 extern "C" int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4])
 {
     if (!b || !out) return fail(MBX_E_ARG, "mbx_batch_launch_info: bad arguments");

@@ -16,3 +16,17 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _grad_mode_is_per_test():
+    """torch's grad mode is process-global and several harness tests switch it (the reference's main() runs under torch.set_grad_enabled(False) and
+    enables it around training): every test starts with gradients ENABLED and whatever it sets is undone afterwards."""
+    import torch
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)
+    yield
+    torch.set_grad_enabled(prev)
