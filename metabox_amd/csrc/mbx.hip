@@ -490,7 +490,7 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     b->lde_run_kinds_ok = true;
     b->rl_run_kinds_ok = true;
     for (int i = 0; i < n_instances; ++i) b->rl_run_kinds_ok = b->rl_run_kinds_ok && rl_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->h_problems[problem_idx[i]].noise_kind);
-    for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind);
+    for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->dim);
     std::vector<int32_t> order(n_instances);
     for (int i = 0; i < n_instances; ++i) order[i] = i;
     // equal weights: by kind, so that neighbours in the launch order -- the workgroups that share a CU -- run the same per-kind body (k_rlepso_run, k_lde_run)
@@ -534,6 +534,8 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 100 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 6;
+        // the reference's own LDE setting (lde_optimizer.py:10 NP = 50, bbob --dim 10): resident rollout only, the one-generation kernel stays the run-time-geometry one
+        if (cfg->algo == MBX_ALGO_LDE && b->threads == kThreads && cfg->np == 50 && cfg->dim == 10 && !(g && g[0] == '1')) b->fixed_geometry = 9;
         if (cfg->algo == MBX_ALGO_DEDDQN && cfg->np == 100 && cfg->dim == 12 && !(g && g[0] == '1')) b->fixed_geometry = 4;
         if (cfg->algo == MBX_ALGO_GLEET && cfg->np == 100 && cfg->dim == 10 && !(g && g[0] == '1')) b->fixed_geometry = 5;
     }
@@ -585,6 +587,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
             HIP_TRY(hipMalloc(&b->d_lstm_pack, (size_t)lde_run_pack_floats(g.state_dim, 64, g.action_dim) * sizeof(float)));      // hidden <= 64
             HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(100, 30, 50) * sizeof(double))));
             HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50) * sizeof(double))));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 10, 50) * sizeof(double))));
         }
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -971,7 +974,7 @@ extern "C" int mbx_lde_rollout_resident(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "mbx_lde_rollout_resident: null batch");
     if (b->cfg.algo != MBX_ALGO_LDE) return 0;
-    return (b->fixed_geometry == 3 || b->fixed_geometry == 6) && b->lde_run_kinds_ok && !b->rollout_per_generation ? 1 : 0;
+    return (b->fixed_geometry == 3 || b->fixed_geometry == 6 || b->fixed_geometry == 9) && b->lde_run_kinds_ok && !b->rollout_per_generation ? 1 : 0;
 }
 
 extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state_in, float* d_h, float* d_c, int n_gens,
@@ -999,6 +1002,9 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
         ka.out = LdeRunOut{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
         if (b->fixed_geometry == 6)
             hipLaunchKernelGGL((k_lde_run<100, 30>), dim3(b->B), dim3(lde_run_threads(100)), (size_t)lde_run_lds_doubles(100, 30, 50) * sizeof(double),
+                               (hipStream_t)stream, ka);
+        else if (b->fixed_geometry == 9)
+            hipLaunchKernelGGL((k_lde_run<50, 10>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 10, 50) * sizeof(double),
                                (hipStream_t)stream, ka);
         else
             hipLaunchKernelGGL((k_lde_run<50, 30>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 30, 50) * sizeof(double),

@@ -21,8 +21,10 @@
 //
 // Objectives: the element-wise part runs in the accumulator layout, so it is written per function kind here (same expressions, same
 // out-of-line math routines, same summation order as eval_rows).  Kinds that need the candidate itself or two arrays in the row sums
-// (3, 4, 5, 15, 20, 24) are not built: mbx_lde_rollout steps batches that contain them with one launch per generation.  The boundary
-// penalty of every kind is exactly +0 here (the midpoint repair keeps a trial inside [lb, ub]) and is added as the literal it is.
+// (3, 4, 5, 15, 20, 24) are built where a SECOND tile array fits the LDS budget -- D <= 16, i.e. k_lde_run<50, 10>, the reference's own LDE setting
+// (bbob --dim 10, the shipped LDE_Agent.pkl); at D = 30 (config 3: the noisy suite has none of them) mbx_lde_rollout steps batches that contain them with
+// one launch per generation.  The boundary penalty of every kind is exactly +0 here (the midpoint repair keeps a trial inside [lb, ub]) and is added as
+// the literal it is.
 #pragma once
 #include "mbx_lde.hpp"
 #include "mbx_lstm_policy.hpp"
@@ -95,16 +97,19 @@ __device__ __forceinline__ LdeRunCArgs& lde_run_args()
     return *(LdeRunCArgs*)p;
 }
 
-__host__ __device__ constexpr bool lde_run_kind_ok(int kind)
+// one column tile (D <= 16): a second tile array TB2 exists and with it the six kinds whose row sums read two arrays / the candidate
+__host__ __device__ constexpr bool lde_run_two_arrays(int D) { return D <= 16; }
+__host__ __device__ constexpr bool lde_run_kind_ok(int kind, int D)
 {
-    return kind == 1 || kind == 2 || (kind >= 6 && kind <= 14) || (kind >= 16 && kind <= 19) || (kind >= 21 && kind <= 23);
+    return lde_run_two_arrays(D) ? (kind >= 1 && kind <= 24)
+                                 : (kind == 1 || kind == 2 || (kind >= 6 && kind <= 14) || (kind >= 16 && kind <= 19) || (kind >= 21 && kind <= 23));
 }
 
 __host__ __device__ constexpr int lde_run_tiles(int NP) { return (NP + 15) / 16; }
 __host__ __device__ constexpr int lde_run_threads(int NP) { return 64 * lde_run_tiles(NP); }
 
 struct LdeRunLds {
-    double *P, *TB, *FIT, *A1, *A2, *FEAT, *HS, *RED, *SCAL, *DSH;
+    double *P, *TB, *TB2, *FIT, *A1, *A2, *FEAT, *HS, *RED, *SCAL, *DSH;
     float *ACT, *HC;
     uint8_t *RK, *ORDER;         // rank of a physical row / row at a rank (NP <= 255)
     int *ACC, *HIST, *FLAG;      // ACC: the ranking's per-row counters
@@ -114,7 +119,7 @@ struct LdeRunLds {
 __host__ __device__ inline int64_t lde_run_lds_doubles(int NP, int D, int H)
 {
     const int64_t NE = align2((int64_t)NP * D), P = align2(NP);
-    return 2 * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + align2((P + 1) / 2) + 2 * align2((P + 7) / 8) + 4 + align2(D);
+    return (lde_run_two_arrays(D) ? 3 : 2) * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + align2((P + 1) / 2) + 2 * align2((P + 7) / 8) + 4 + align2(D);
 }
 
 __device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, int H)
@@ -123,6 +128,8 @@ __device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, 
     LdeRunLds L;
     double* p = base;
     L.P = p; p += NE;  L.TB = p; p += NE;
+    L.TB2 = nullptr;
+    if (lde_run_two_arrays(D)) { L.TB2 = p; p += NE; }           // second tile array (kinds 3, 4, 5, 15, 20, 24)
     L.FIT = p; p += P;
     L.A1 = p; p += P;            // SORTED (from the ranking to the next row sums) | Gallagher: best key per row
     L.FEAT = p; L.A2 = p; p += align2(NP + 2 * MBX_LDE_BINS);   // features; dead between the policy's input staging and the next feature phase, where
@@ -181,7 +188,7 @@ __device__ MBX_LDE_GALL_ATTR void lde_gallagher_search(double* TB_, unsigned lon
             const kptr py = (kptr)P.pyr, pcc = (kptr)P.pc, plw = (kptr)P.plogw;
             const int npk = P.n_peaks, nw = __builtin_amdgcn_readfirstlane(MBX_NW);
             const double cexp = -0.5 / D;
-            constexpr int PB = 4, GC = 6;
+            constexpr int PB = 4, GC = D % 6 == 0 ? 6 : 5;
             static_assert(D % GC == 0, "whole chunks only");
             const int mine = wave < npk ? (npk - wave + nw - 1) / nw : 0;
             double bkey[2] = {-INFINITY, -INFINITY};
@@ -237,23 +244,29 @@ template <int NP, int D, class TWP>
 __device__ __forceinline__ void lde_map_tile(const double* __restrict__ M, const double (&a)[(D + 3) / 4], TWP TW, int wave, int c, int q)
 {
     constexpr int KS = (D + 3) / 4;
+    constexpr bool TWO_TILES = D > 16;
+    const int c0 = c < D ? c : D - 1;                              // (D < 16: the columns past the dimension are clamped and masked)
     const int c1 = 16 + c < D ? 16 + c : D - 1;                    // second column tile, clamped
     f64x4 y0 = {0., 0., 0., 0.}, y1 = {0., 0., 0., 0.};
-    double bm0[KS], bm1[KS];
+    double bm0[KS], bm1[TWO_TILES ? KS : 1];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bm0[s] = M[c * D + (4 * s + q < D ? 4 * s + q : D - 1)];
+    for (int s = 0; s < KS; ++s) bm0[s] = M[c0 * D + (4 * s + q < D ? 4 * s + q : D - 1)];
+    if constexpr (TWO_TILES) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bm1[s] = M[c1 * D + (4 * s + q < D ? 4 * s + q : D - 1)];
+        for (int s = 0; s < KS; ++s) bm1[s] = M[c1 * D + (4 * s + q < D ? 4 * s + q : D - 1)];
+    }
 #pragma unroll
-    for (int s = 0; s < KS; ++s) y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], 4 * s + q < D ? bm0[s] : 0., y0, 0, 0, 0);
+    for (int s = 0; s < KS; ++s) y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], (4 * s + q < D && c < D) ? bm0[s] : 0., y0, 0, 0, 0);
+    if constexpr (TWO_TILES) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], (4 * s + q < D && 16 + c < D) ? bm1[s] : 0., y1, 0, 0, 0);
+        for (int s = 0; s < KS; ++s) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], (4 * s + q < D && 16 + c < D) ? bm1[s] : 0., y1, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int lr = q + 4 * r;
         if (16 * wave + lr < NP) {
-            TW[lr * D + c] = y0[r];
-            if (16 + c < D) TW[lr * D + 16 + c] = y1[r];
+            if (c < D) TW[lr * D + c] = y0[r];
+            if constexpr (TWO_TILES) { if (16 + c < D) TW[lr * D + 16 + c] = y1[r]; }
         }
     }
 }
@@ -262,12 +275,15 @@ __device__ __forceinline__ void lde_map_tile(const double* __restrict__ M, const
 // time.  Out of line like the Gallagher search: the generation body (policy, mutation, ranking) is register-allocated without it, and the kinds that have
 // nothing element-wise never call it.
 template <int NP, int D, int KIND = 0>
-__device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, ConstProblem* Pp, int kind_)
+__device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, ConstProblem* Pp, int kind_, double* TW2_ = nullptr)
 {
     typedef __attribute__((address_space(3))) double lds_f64;
     lds_f64* TW = (lds_f64*)TW_;
     lds_f64* A2 = (lds_f64*)A2_;
+    lds_f64* TW2 = (lds_f64*)TW2_;                                  // the wave's slice of the second tile array (D <= 16 only)
     constexpr int KS = (D + 3) / 4;
+    constexpr bool TWO = lde_run_two_arrays(D) && KIND == 0;       // kinds 3, 4, 5, 15, 20, 24 live in the any-kind loop of the one-tile geometries
+    constexpr int MM = D > 16 ? 8 : 4;                             // elements per lane: 4 rows x one or two column tiles
     const uint64_t pu_ = (uint64_t)(uintptr_t)Pp;
     const uint64_t pu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pu_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pu_ >> 32)) << 32);
     ConstProblem& P = *(ConstProblem*)(uintptr_t)pu;
@@ -288,12 +304,24 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
             const double s0 = P.s[0];
             const double kats_exp = kind == 23 ? 10 / m_pow((double)D, 1.2) : 0.;
 #pragma unroll 1
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < ((TWO && kind == 20) ? 0 : MM); ++m) {       // (Schwefel has its own two passes below)
                 int lr, d;
                 if (!elem(m, lr, d)) continue;
                 lds_f64* pz = TW + lr * D + d;
                 const double z = *pz;
                 double t;
+                if constexpr (TWO) {
+                    if (kind == 3 || kind == 4) {                  // Rastrigin / Bueche-Rastrigin (eval_rows phase E1): z stays, cos(2 pi z) goes to the second array
+                        double zz;
+                        if (kind == 3) zz = P.v0[d] * asy1(osc1(z), P.v1[d]);
+                        else { double o = osc1(z); if ((d & 1) == 0 && o > 0.) o *= 10.; zz = o * P.v0[d]; }
+                        *pz = zz;
+                        TW2[lr * D + d] = m_cos(kTwoPi * zz);
+                        continue;
+                    }
+                    if (kind == 15) { *pz = asy1(osc1(z), P.v1[d]); continue; }
+                    if (kind == 24) { *pz = m_cos(kTwoPi * z); continue; }      // (the slice holds M1 (x_hat - mu0): phase E2)
+                }
                 switch (kind) {
                 case 2: case 10: { const double o = osc1(z); t = P.v0[d] * (o * o); break; }
                 case 6: { double zi = z; if (zi * P.dshift[d] > 0.) zi *= 100.; t = zi * zi; break; }
@@ -319,16 +347,49 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
                 *pz = t;
             }
         }
-        if ((kind == 7 || kind == 12 || (kind >= 16 && kind <= 18))) {    // second linear map (F7, F16-F18: M2; F12: M1 again) of the tile just written
+        if constexpr (TWO) {
+            if (kind == 20) {                                      // Schwefel (bbob.py:754-756; eval_rows phases E1 / E2): T0 = v2 x is in the second array
+                wave_lds_fence();
+#pragma unroll 1
+                for (int m = 0; m < MM; ++m) {
+                    int lr, d;
+                    if (!elem(m, lr, d)) continue;
+                    double zi = TW2[lr * D + d];
+                    if (d > 0) zi += 0.25 * (TW2[lr * D + d - 1] - P.v1[d - 1]);
+                    TW[lr * D + d] = 100. * (P.v0[d] * (zi - P.v1[d]) + P.v1[d]);
+                }
+                wave_lds_fence();                                  // every T0 has been read: the second array takes the penalty terms
+#pragma unroll 1
+                for (int m = 0; m < MM; ++m) {
+                    int lr, d;
+                    if (!elem(m, lr, d)) continue;
+                    const double z = TW[lr * D + d];
+                    const double qq = fmax(0., fabs(z / 100) - P.ub);
+                    TW2[lr * D + d] = qq * qq;
+                    TW[lr * D + d] = z * m_sin(sqrt(fabs(z)));
+                }
+            }
+        }
+        if ((kind == 7 || kind == 12 || (TWO && kind == 15) || (kind >= 16 && kind <= 18))) {    // second linear map (F7, F15-F18: M2; F12: M1 again) of the tile just written
             wave_lds_fence();
             double av2[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) { const double v = TW[(rvalid ? c : 0) * D + kq[s]]; av2[s] = (rvalid && 4 * s + q < D) ? v : 0.; }
             wave_lds_fence();                                      // every lane holds its A fragment: the slice can take the product
             lde_map_tile<NP, D>(kind == 12 ? P.m1 : P.m2, av2, TW, wave, c, q);
+            if constexpr (TWO) {
+                if (kind == 15) {                                  // Rastrigin F15: z = M2 (...) stays, cos(2 pi z) goes to the second array
+#pragma unroll 1
+                    for (int m = 0; m < MM; ++m) {
+                        int lr, d;
+                        if (!elem(m, lr, d)) continue;
+                        TW2[lr * D + d] = m_cos(kTwoPi * TW[lr * D + d]);
+                    }
+                }
+            }
             if (kind == 16) {                                      // Weierstrass series by angle tripling (eval_rows, phase E2)
 #pragma unroll 1
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < MM; ++m) {
                     int lr, d;
                     if (!elem(m, lr, d)) continue;
                     lds_f64* pz = TW + lr * D + d;
@@ -350,7 +411,7 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
             // element (row, d) needs (row, d + 1), which another lane owns and overwrites with ITS term: the wave walks m in step -- all lanes read,
             // then all lanes write -- and in ascending m, so the one neighbour that belongs to a later step (d = 15 -> 16) is still untouched
 #pragma unroll 1
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < MM; ++m) {
                 int lr, d;
                 const bool ok = elem(m, lr, d) && d < D - 1;       // coordinate D - 1 has no term
                 wave_lds_fence();
@@ -399,6 +460,10 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
     constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
+    constexpr bool TWO = lde_run_two_arrays(D) && KIND == 0;       // the six two-array kinds: any-kind loop of the one-tile geometries
+    // crossover uniforms of a row: D consecutive elements of the sorted population starting at offset (i D) & 3 in {0, 2} (D even) -> GPR Philox groups
+    constexpr int GPR = (D + 2 + 3) / 4, ROWW = 4 * GPR;
+    static_assert(D % 2 == 0 && 16 * ROWW * 4 <= 16 * D * 8, "the uniforms of a tile fit the wave's slice");
     static_assert(4 * ((K1 + 3) / 4) - IN <= 64, "the hidden state is staged by one wave");
     const LdeRunLds L = lde_run_carve(smem, NP, D, H);
     const int b = __builtin_amdgcn_readfirstlane(b_), gen0 = __builtin_amdgcn_readfirstlane(gen0_), episode = __builtin_amdgcn_readfirstlane(episode_);
@@ -523,6 +588,7 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
         const bool rvalid = jrow < NP;
         const int jr_c = rvalid ? jrow : NP - 1;                   // clamped: lanes past the last row compute on a copy of it, nothing of theirs is stored
         double* TW = L.TB + 16 * wave * D;                         // this wave's slice of the tile array: rows 16 wave .. (row-major, D per row)
+        double* TW2 = TWO ? L.TB2 + 16 * wave * D : nullptr;       // ... and of the second one
         // the trial vector is parked in the instance's own population block in HBM (free until the end of the launch: the parents live in LDS) and read
         // back by the lanes of the rows that survive -- 16 registers less across the transforms than holding it, and no compiler-placed spill chain
         double* park = ar.bp.state + (int64_t)b * ar.bp.state_stride + MBX_LDE_ST_POP(NP, D);
@@ -537,12 +603,12 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
             // index e >> 2), like k_lde_step; a row touches 8 groups, lane m of the wave makes the calls of (row m >> 3, group m & 7)
             uint32_t* UW = (uint32_t*)TW;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int m = lane + 64 * h2, rr = m >> 3, g = m & 7, jr_ = 16 * wave + rr;
+            for (int h2 = 0; h2 < (16 * GPR + 63) / 64; ++h2) {
+                const int m = lane + 64 * h2, rr = m / GPR, g = m - rr * GPR, jr_ = 16 * wave + rr;      // (GPR = 8 at D = 30: m >> 3, m & 7)
                 const int ii = RKa[jr_ < NP ? jr_ : NP - 1];
                 const int t = ((ii * D) >> 2) + g;
                 const U4 w = (MBX_LDE_ABL & 4) ? U4{(uint32_t)t * 2654435761u, (uint32_t)t * 40503u + 7u, (uint32_t)t ^ 0x9E3779B9u, (uint32_t)t * 69069u} : rng.draw((uint32_t)t, MBX_SITE_LDE_ELEM);
-                if (jr_ < NP && 4 * t < NE) *(uint4*)(UW + rr * 32 + 4 * g) = make_uint4(w.x, w.y, w.z, w.w);
+                if (rr < 16 && jr_ < NP && 4 * t < NE) *(uint4*)(UW + rr * ROWW + 4 * g) = make_uint4(w.x, w.y, w.z, w.w);
             }
             // ---- per-individual draws (:101-105, 88-99)
             const U4 w = (MBX_LDE_ABL & 4) ? U4{(uint32_t)i * 2654435761u, (uint32_t)i * 40503u + 7u, (uint32_t)i ^ 0x9E3779B9u, (uint32_t)i * 69069u} : rng.draw((uint32_t)i, MBX_SITE_LDE_PART);
@@ -557,7 +623,7 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
             const double* row0 = L.P + L.ORDER[r0] * D;
             const double* row1 = L.P + L.ORDER[r1] * D;
             const double* rowI = L.P + jr_c * D;
-            const uint32_t* urow = UW + (jr_c - 16 * wave) * 32 + ((i * D) & 3);   // (the clamped lanes read the uniforms of the row they are clamped to)
+            const uint32_t* urow = UW + (jr_c - 16 * wave) * ROWW + ((i * D) & 3);   // (the clamped lanes read the uniforms of the row they are clamped to)
             double* pk = park + jr_c * D;
             const bool self = pidx == i;
             wave_lds_fence();
@@ -567,11 +633,13 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
                 uint32_t uw[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (s0 + j >= KS) break;                      // (KS is odd at D = 10)
                     const int d = kq[s0 + j];
                     xi[j] = rowI[d]; xp[j] = rowP[d]; x0[j] = row0[d]; x1[j] = row1[d]; uw[j] = urow[d]; sh[j] = L.DSH[d];
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (s0 + j >= KS) break;
                     const int s = s0 + j, d = kq[s];
                     const double u = d == jr ? 0. : u32d(uw[j]);
                     // :88-99: x_i + F (x_pbest - x_i) + F (x_r0 - x_r1), written like the reference's tensor arithmetic: the two orders of the first sum
@@ -583,7 +651,22 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
                     const double rl = (xi[j] + lb) / 2., ru = (xi[j] + ub) / 2.;
                     cval = cval < lb ? rl : (cval > ub ? ru : cval);
                     pk[d] = cval;                                  // unconditional: a lane in the padding computes the element it is clamped to, bit for bit what its owner stores
-                    av[s] = (rvalid && 4 * s + q < D) ? cval - sh[j] : 0.;
+                    double aop = cval - sh[j];
+                    if constexpr (TWO) {
+                        // the kinds without a first map read the candidate itself (eval_rows phase E1): their first array goes straight to the SECOND slice (the first
+                        // still holds the uniforms), in [row][coordinate] order
+                        if (kind == 24) aop = P.v0[d] * cval - P.s[0];      // x_hat - mu0: the operand of the M1 map (phase C)
+                        if (rvalid && 4 * s + q < D && (kind == 5 || kind == 20 || kind == 24)) {
+                            double tv = cval;                                  // F24: the row sums need x itself
+                            if (kind == 5) {
+                                double zi = cval;
+                                if (cval * sh[j] > ub * ub) zi = (zi > 0. ? 1. : (zi < 0. ? -1. : 0.)) * ub;
+                                tv = P.v1[d] - zi * P.v0[d];
+                            } else if (kind == 20) tv = P.v2[d] * cval;
+                            TW2[(jrow - 16 * wave) * D + d] = tv;
+                        }
+                    }
+                    av[s] = (rvalid && 4 * s + q < D) ? aop : 0.;
                 }
             }
             wave_lds_fence();                                      // the uniforms are consumed: the slice is free for the transforms' output
@@ -593,9 +676,9 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
         // The result goes straight to the wave's slice (C / D layout: lane (c, q) holds rows q + 4 r, coordinates c and 16 + c); everything
         // element-wise then happens IN PLACE there, one element per lane at a time (loops that are not unrolled: the transforms are out-of-line
         // calls, and the fewer values are alive across a call the fewer are spilled around it).
-        lde_map_tile<NP, D>(P.m1, av, TW, wave, c, q);
+        if (!(TWO && (kind == 5 || kind == 20))) lde_map_tile<NP, D>(P.m1, av, TW, wave, c, q);      // (linear slope, Schwefel: no map)
         MBX_PHASE(8);                                              // (first linear map of wave 0)
-        if (!(kind == 1 || kind == 13 || gall)) lde_tile_transforms<NP, D, KIND>(TW, L.A2, &P, kind);      // (Sphere-like kinds and Gallagher: nothing element-wise)
+        if (!(kind == 1 || kind == 13 || gall || (TWO && kind == 5))) lde_tile_transforms<NP, D, KIND>(TW, L.A2, &P, kind, TW2);      // (Sphere-like kinds and Gallagher: nothing element-wise)
         __syncthreads();
         MBX_PHASE(2);                                              // mutation, linear maps, transforms (wave-local)
 
@@ -666,7 +749,34 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
                 f = res * tmp - tmp + bh + bias;
                 break;
             }
-            default: f = NAN; break;
+            default:
+                f = NAN;
+                if constexpr (TWO) {                               // the two-array kinds (eval_rows' row phase, same order of the sums)
+                    const double* t2 = L.TB2 + j * D;
+                    if (kind == 3 || kind == 15 || kind == 4) {
+                        double sc = 0., sq = 0.;
+                        for (int d = 0; d < D; ++d) { sc += t2[d]; sq += z[d] * z[d]; }
+                        f = kind == 4 ? 10. * (D - sc) + sq + 100 * bh + bias : 10. * (D - sc) + sq + bias;
+                    } else if (kind == 5) {
+                        double s = 0.; for (int d = 0; d < D; ++d) s += t2[d];
+                        f = s + bias;
+                    } else if (kind == 20) {
+                        double acc = 0., pen = 0.;
+                        for (int d = 0; d < D; ++d) { acc += z[d]; pen += t2[d]; }
+                        f = 4.189828872724339 - 0.01 * (acc / D) + 100 * pen + bias;
+                    } else if (kind == 24) {
+                        const double mu0 = P.s[0], sc_ = P.s[1], mu1 = P.s[2];
+                        double a = 0., bq = 0., sc = 0.;
+                        for (int d = 0; d < D; ++d) {
+                            const double xh = P.v0[d] * t2[d];      // t2 = the candidate
+                            a += (xh - mu0) * (xh - mu0);
+                            bq += (xh - mu1) * (xh - mu1);
+                            sc += t[d];
+                        }
+                        f = fmin(a, D + sc_ * bq) + 10. * (D - sc) + 1e4 * bh + bias;
+                    }
+                }
+                break;
             }
             const RowPost post{&rng, nullptr, MBX_SITE_NOISE0_A, MBX_SITE_NOISE0_B, NP};
             const double nc = (MBX_LDE_ABL & 16) ? f - P.optimum : row_post(P, post, RKa[j], f);        // the noise draw of an individual is indexed by its position in the order
@@ -765,7 +875,7 @@ void k_lde_run(LdeRunArgs args_)
     (void)args_;                                                   // read through lde_run_args()
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, K1 = IN + H, NF = NP + 2 * MBX_LDE_BINS;
-    static_assert(D > 16 && D <= 32, "two 16-column tiles");
+    static_assert(D <= 32 && D % 2 == 0, "one or two 16-column tiles, coordinate pairs");
     const LdeRunLds L = lde_run_carve(smem, NP, D, H);
     int b, gen0, episode, n_gens, kind0;
     uint32_t seed_lo, seed_hi;

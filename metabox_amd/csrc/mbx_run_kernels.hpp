@@ -12,5 +12,6 @@ extern template __global__ void k_rlepso_run<512, 100, 30, 5>(BatchParams, const
 extern template __global__ void k_rlepso_run<256, 100, 12, 5>(BatchParams, const float*, int, int, RunOut);
 extern template __global__ void k_lde_run<100, 30>(LdeRunArgs);
 extern template __global__ void k_lde_run<50, 30>(LdeRunArgs);
+extern template __global__ void k_lde_run<50, 10>(LdeRunArgs);
 }  // namespace mbx
 #endif

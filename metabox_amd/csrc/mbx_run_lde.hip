@@ -11,4 +11,5 @@
 namespace mbx {
 template __global__ void k_lde_run<100, 30>(LdeRunArgs);
 template __global__ void k_lde_run<50, 30>(LdeRunArgs);
+template __global__ void k_lde_run<50, 10>(LdeRunArgs);        // the reference's own LDE setting (NP = 50, bbob --dim 10): all 24 kinds
 }  // namespace mbx

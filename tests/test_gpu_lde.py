@@ -269,12 +269,12 @@ def _lde_net(NP, seed=3):
     return agent.to('cuda').net
 
 
-def _lde_rollout_case(suite_name, fids, NP, B, chunks, resident=True, maxfes=60000, early_stop=True):
+def _lde_rollout_case(suite_name, fids, NP, B, chunks, resident=True, maxfes=None, early_stop=True, dim=30):
     """One mbx_lde_rollout launch per chunk against mbx_lde_policy + mbx_step per generation on a twin batch: per-generation actions, features,
     rewards, done flags, the LSTM's (h, c), whole state blocks and result tables must agree bit for bit."""
     from metabox_amd.suite import Batch, Suite
     from metabox_amd._abi import ALGO_LDE
-    dim = 30
+    maxfes = maxfes or 2000 * dim
     ps = [problems(suite_name, dim)[f] for f in fids]
     s = Suite(ps)
     net = _lde_net(NP)
@@ -327,9 +327,20 @@ def test_lde_resident_rollout_equals_policy_plus_step(NP):
     assert np.all(r['fes'] >= NP * 12) and np.all(r['steps'] == 11)          # every instance terminated inside the second launch
 
 
+def test_lde_resident_rollout_reference_setting_dim10_all_24_kinds():
+    """The reference's own LDE setting -- NP = 50 (lde_optimizer.py:10), bbob / bbob-noisy --dim 10, the shipped LDE_Agent.pkl -- takes the resident route
+    (VERDICT r04 item 6): k_lde_run<50, 10> (one column tile; a second tile array carries the kinds whose row sums read two arrays or the candidate itself:
+    F3, F4, F5, F15, F20, F24, src/problem/bbob.py:229-287, 585-602, 740-759, 869-890).  All 24 bbob functions and all 30 noisy ones, bit for bit against
+    k_lstm_policy + k_lde_step per generation, in uneven chunks; then whole short episodes with terminations inside a launch."""
+    _lde_rollout_case('bbob', tuple(range(1, 25)), 50, 48, (1, 6, 13, 2), dim=10)
+    _lde_rollout_case('bbob-noisy', tuple(range(101, 131)), 50, 60, (5, 11), dim=10)
+    r = _lde_rollout_case('bbob', (1, 3, 4, 5, 15, 20, 24, 21), 50, 16, (4, 9, 30), maxfes=50 * 12, dim=10)
+    assert np.all(r['fes'] >= 50 * 12) and np.all(r['steps'] == 11)
+
+
 def test_lde_rollout_host_loop_route(monkeypatch):
-    """Behind the same entry point: objective kinds the resident kernel does not build (F3, F15, F24: two arrays in the row sums / the candidate
-    itself), another geometry (D = 10), and MBX_ROLLOUT_PER_GENERATION=1 take mbx_lde_policy + mbx_step per generation -- same records."""
+    """Behind the same entry point: objective kinds the D = 30 resident kernels do not build (F3, F15, F24: two arrays in the row sums / the candidate
+    itself; the second tile array exists at D <= 16 only), and MBX_ROLLOUT_PER_GENERATION=1 take mbx_lde_policy + mbx_step per generation -- same records."""
     _lde_rollout_case('bbob', (1, 3, 15, 24), 50, 8, (2, 5), resident=False)
     # whole short episodes on this route: instances terminate inside the second call and the third call starts with every instance done -- their
     # (h, c) and action rows must stay untouched, as include/mbx.h promises for both routes (ADVICE r04)
@@ -339,15 +350,15 @@ def test_lde_rollout_host_loop_route(monkeypatch):
     _lde_rollout_case('bbob-noisy', (101, 128), 100, 8, (3, 4), resident=False)
 
 
-@pytest.mark.parametrize('NP', [50, 100])
-def test_lde_resident_rollout_matches_the_oracle(NP):
+@pytest.mark.parametrize('NP,suite,dim', [(50, 'bbob-noisy', 30), (100, 'bbob-noisy', 30), (50, 'bbob', 10), (50, 'bbob-noisy', 10)])
+def test_lde_resident_rollout_matches_the_oracle(NP, suite, dim):
     """The resident kernel against the C oracle directly: 10 generations of all 30 noisy functions in ONE launch; the oracle, on the same Philox
     seeds, replays the actions the in-kernel PolicyNet drew and must see the same features / rewards after every generation and the same
     population at the end."""
     from metabox_amd.suite import Batch
     from metabox_amd._abi import ALGO_LDE
-    s, ids = _suite('bbob-noisy', 30)
-    B, G, dim, maxfes = len(ids), 10, 30, 60000
+    s, ids = _suite(suite, dim)
+    B, G, maxfes = len(ids), 10, 2000 * dim
     net = _lde_net(NP)
     w, H = net.packed_weights(), net.lstm.hidden_size
     seeds = np.arange(B, dtype=np.uint64) * 104729 + 3

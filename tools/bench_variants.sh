@@ -9,11 +9,11 @@ OUT=$ROOT/gpurun_out/${TAG}_variants.jsonl
 mkdir -p "$ROOT/gpurun_out"; : > "$OUT"
 cd "$ROOT"
 for fn in all24 train18; do
-    python bench.py --no-cpu-baseline --functions $fn >> "$OUT" 2>> "$OUT.err"
-    python bench.py --no-cpu-baseline --functions $fn --fixed-horizon >> "$OUT" 2>> "$OUT.err"
+    python bench.py --no-cpu-baseline --no-pmc --no-other-configs --functions $fn >> "$OUT" 2>> "$OUT.err"
+    python bench.py --no-cpu-baseline --no-pmc --no-other-configs --functions $fn --fixed-horizon >> "$OUT" 2>> "$OUT.err"
 done
 for f in $(seq 1 24); do
-    python bench.py --no-cpu-baseline --functions $f --fixed-horizon --steps 199 --warmup 10 >> "$OUT" 2>> "$OUT.err"
+    python bench.py --no-cpu-baseline --no-pmc --no-other-configs --functions $f --fixed-horizon --steps 199 --warmup 10 >> "$OUT" 2>> "$OUT.err"
 done
 python - "$OUT" <<'PY'
 import json, sys
@@ -21,5 +21,5 @@ for line in open(sys.argv[1]):
     d = json.loads(line)
     w = d['config']['workload']
     print(f"{w[w.index('(') + 1:w.index(' round-robin')]:45s} {'fixed' if 'fixed horizon' in w else 'stop-rule':9s} "
-          f"value {d['value']:.3e}  kernel {d['roofline']['avg_kernel_us']:.1f} us  live/launch {d['roofline']['live_instances_per_launch']:.0f}")
+          f"value {d['value']:.3e}  {d['roofline'].get('avg_generation_us', d['roofline']['avg_kernel_us']):.1f} us per generation  live instances per generation {d['roofline'].get('live_instances_per_generation', float('nan')):.0f}")
 PY
