@@ -191,7 +191,9 @@ def pmc_traffic_in_run(instances, timeout_s=150):
                 if counter is sq_pass:
                     break                                       # the traffic figure stands without the VALU pass
                 return None, f'rocprofv3 --pmc {first} pass failed (rc {r.returncode})', None
-            big = max(rows, key=lambda d: d[first])             # the 20-generation launch (the other dispatch is the 2-generation warm-up)
+            # the 20-generation launch (the other dispatch is the 2-generation warm-up): the LONGEST dispatch (GRBM_GUI_ACTIVE of a process's first dispatch can
+            # exceed a later, longer one's: round 5 saw the warm-up picked by counter value)
+            big = max(rows, key=lambda d: (d.get('t1', 0.) - d.get('t0', 0.), d.get('SQ_INSTS_VALU', 0.), d[first]))
             if counter is not sq_pass:
                 got[counter] = big[counter]
                 continue
@@ -603,12 +605,14 @@ def main():
             live += steps_sum() - base
         return elapsed, live, launches, marks, mark_step, reset_steps
 
-    def window_clock():
+    def window_clock(prime=6):
         """Shader clock during a timed window, no profiler attached: the window once more (reset, W warm-up generations, the same K generations in the same
         launches) with a one-wave kernel on a side stream that samples s_memtime (shader cycles of ITS XCD; the counters of different XCDs are offset against
         each other, so one wave takes all samples) and s_memrealtime (100 MHz) beside the launches (mbx_debug_clock_probe); two mbx_debug_clock_mark launches on
-        the launch stream bracket the K generations in the real-time base.  Must run BEFORE the rocprofv3 child passes: a counter-collection session leaves the
-        chip in a lower, fixed clock state (the PMC children and any window after them run the same kernel ~15 % slower).  -> dict or None."""
+        the launch stream bracket the K generations in the real-time base.
+        The chip has two regimes (tools/exp/clock_windows.py, round 5): after >= ~10 ms of back-to-back work the kernel runs at ~2.3 GHz (108 us per generation, what
+        the 30-200 back-to-back repeats of the headline measure); a short window after >= 50 ms without work runs at 2.0-2.1 GHz (122-131 us per generation: a
+        process's first window, e.g. the rocprofv3 children).  The probed window is therefore preceded by `prime` plain windows, back to back.  -> dict or None."""
         if not resident:
             return None
         import ctypes as C
@@ -622,12 +626,15 @@ def main():
         side = torch.cuda.Stream()
         main_s = torch.cuda.current_stream()
         with torch.no_grad():
-            env.reset()
-            it = 0
-            while it < W:
-                n = min(max(1, args.gens_per_launch), EPISODE_GENS, W - it)
-                env.batch.rlepso_rollout(fused_table, n)
-                it += n
+            for _ in range(prime + 1):                                      # `prime` plain windows, then the probed one: no host work in between
+                env.reset()
+                it = 0
+                while it < W:
+                    n = min(max(1, args.gens_per_launch), EPISODE_GENS, W - it)
+                    env.batch.rlepso_rollout(fused_table, n)
+                    it += n
+                if _ < prime:
+                    env.batch.rlepso_rollout(fused_table, Kc)
             barrier()
             if lib.mbx_debug_clock_probe(C.c_void_p(buf.data_ptr()), n_s, sleep_units, C.c_void_p(side.cuda_stream)) != 0:
                 return None
@@ -737,15 +744,22 @@ def main():
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         wc = None
         if resident and world == 1 and not args.no_pmc and not os.environ.get('MBX_BENCH_CHILD'):
-            try:                                               # BEFORE the rocprofv3 children: they leave the chip at a lower clock (see window_clock)
+            try:
                 wcs = sorted([w for w in (window_clock() for _ in range(3)) if w], key=lambda w: w['kernel_us_per_generation_by_events'])
                 if wcs:
                     wc = dict(wcs[len(wcs) // 2])
                     wc['all_windows'] = [{k: w[k] for k in ('clock_ghz', 'kernel_us_per_generation_by_events')} for w in wcs]
                     wc['method'] = ('a one-wave kernel on a side stream samples s_memtime (shader cycles) and s_memrealtime (100 MHz) beside the K timed generations, no profiler '
-                                    'attached, before any rocprofv3 child of this run (mbx_debug_clock_probe / mbx_debug_clock_mark); median of three such windows')
+                                    'attached, after six plain windows back to back like the timed repeats (mbx_debug_clock_probe / mbx_debug_clock_mark); median of three such windows')
             except Exception as exc:
                 wc = {'error': repr(exc)}
+        # the side legs are timed legs: they run right behind the headline's repeats, before the (slow, idle-heavy) profiler children
+        side_legs = None
+        if world == 1 and not args.no_other_configs:
+            try:
+                side_legs = {'plugin_view': plugin_view_cost(), 'other_configs': other_configs()}
+            except Exception as exc:                       # the headline line must survive a failure of the side legs
+                side_legs = {'other_configs': {'error': repr(exc)}}
         traffic, traffic_src = pmc_traffic_per_launch(live_per_launch, resident)
         traffic_in_run, traffic_note, valu_in_run = False, None, None
         if resident and world == 1 and not args.no_pmc and not os.environ.get('MBX_BENCH_CHILD'):
@@ -754,19 +768,25 @@ def main():
                 traffic, traffic_in_run = per_step * live_per_launch, True
         first_gen = W % EPISODE_GENS + 1
         if valu_in_run is not None:
-            # the PMC child ran in the profiler's fixed lower clock state (longer launch): its ratio is the profiled launch's.  The wave-instruction COUNT is the same
-            # work in the timed window; price it against the timed window's SIMD cycles at the clock sampled there.
+            # the PMC child is a process's FIRST short window: the chip's low-clock regime (window_clock), a longer launch: its ratio is that launch's.  The
+            # wave-instruction COUNT is the same work in the timed windows; price it against the SIMD cycles of a window in the repeats' regime at the clock sampled there.
             valu_in_run['frac_profiled_launch'] = valu_in_run.pop('frac')
             valu_in_run['clock_ghz_profiled_launch'] = valu_in_run.pop('clock_ghz')
             valu_in_run['timed_window_clock'] = wc
             if wc and wc.get('clock_ghz') and 1.0 < wc['clock_ghz'] < 3.0:
-                # priced on the clock-marked window itself: its own wave-instructions (the profiled child's count per env-step x this window's live env-steps -- every
-                # instance is live in generations W+1 .. W+K of an episode), its own duration by HIP events, its own clock
+                # The kernel costs the same number of SHADER CYCLES per generation in every clock regime the chip was seen in (round 5: 261-265 k at 2.03, 2.06, 2.19,
+                # 2.28 GHz; tools/exp/clock_windows.py): cycles = the probed window's clock x its generation time by HIP events.  frac prices the vector
+                # wave-instructions of a generation (count from the profiled child: same work; every instance is live in generations W+1 .. W+K) at 4 issue cycles
+                # against those cycles; the clock of the timed repeats follows from the same cycle count and THEIR generation time (the probe wave itself keeps the
+                # chip 5-8 % below the clock the undisturbed repeats reach).
+                cyc = wc['clock_ghz'] * 1e3 * wc['kernel_us_per_generation_by_events']
                 wi = valu_in_run['wave_instructions_per_env_step'] * B
-                valu_in_run['clock_ghz'] = wc['clock_ghz']
-                valu_in_run['frac'] = wi * 4. / (1024. * wc['clock_ghz'] * 1e3 * wc['kernel_us_per_generation_by_events'])
-                valu_in_run['frac_is'] = ('vector wave-instructions per generation (count from the profiled child: same work) x 4 issue cycles / (1024 SIMDs x the clock x the '
-                                          'generation time of the clock-marked window of THIS process, no profiler attached)')
+                valu_in_run['shader_cycles_per_generation'] = cyc
+                valu_in_run['frac'] = wi * 4. / (1024. * cyc)
+                valu_in_run['clock_ghz_probed_window'] = wc['clock_ghz']
+                valu_in_run['clock_ghz'] = cyc / (avg_gen_s * 1e9) * (B / max(live_per_gen, 1.))     # timed repeats (per-generation time scaled to a full batch)
+                valu_in_run['frac_is'] = ('vector wave-instructions per generation x 4 issue cycles / (1024 SIMDs x shader cycles per generation); cycles = clock x generation time of a '
+                                          'window of THIS process probed without a profiler (timed_window_clock); clock_ghz = those cycles / the timed repeats\' own generation time')
             else:
                 valu_in_run['frac'] = valu_in_run['frac_profiled_launch']
                 valu_in_run['clock_ghz'] = valu_in_run['clock_ghz_profiled_launch']
@@ -829,12 +849,8 @@ def main():
                          'valu': valu_in_run or valu_roofline(live_per_gen, avg_gen_s, resident),
                          'policy_mfma': policy_mfma_profile()},
         }
-        if world == 1 and not args.no_other_configs:
-            try:
-                out['plugin_view'] = plugin_view_cost()
-                out['other_configs'] = other_configs()
-            except Exception as exc:                       # the headline line must survive a failure of the side legs
-                out['other_configs'] = {'error': repr(exc)}
+        if side_legs is not None:
+            out.update(side_legs)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -435,7 +435,7 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
 }
 
 // timing experiments only (never a shipped build): bit 0 no gate chains, 1 no head chains, 2 cheap hash instead of Philox in the tile phase,
-// 4 no noise in the row phase, 5 no ranking pass
+// 4 no noise in the row phase, 5 no ranking pass, 6 parent gathers from the lane's own row (no bank conflicts in the mutation)
 #ifndef MBX_LDE_ABL
 #define MBX_LDE_ABL 0
 #endif
@@ -619,9 +619,10 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
             const int jr = (int)__umulhi(w.w, (uint32_t)D);
             const float sf32 = L.ACT[i];
             const double sf = (double)sf32, cr = (double)L.ACT[NP + i], om = (double)(1.f - sf32);
-            const double* rowP = L.P + L.ORDER[pidx] * D;
-            const double* row0 = L.P + L.ORDER[r0] * D;
-            const double* row1 = L.P + L.ORDER[r1] * D;
+            // (MBX_LDE_ABL bit 6: the three parent gathers read the lane's own row instead of random rows -- what the bank conflicts of this phase cost)
+            const double* rowP = L.P + ((MBX_LDE_ABL & 64) ? jr_c : L.ORDER[pidx]) * D;
+            const double* row0 = L.P + ((MBX_LDE_ABL & 64) ? jr_c : L.ORDER[r0]) * D;
+            const double* row1 = L.P + ((MBX_LDE_ABL & 64) ? jr_c : L.ORDER[r1]) * D;
             const double* rowI = L.P + jr_c * D;
             const uint32_t* urow = UW + (jr_c - 16 * wave) * ROWW + ((i * D) & 3);   // (the clamped lanes read the uniforms of the row they are clamped to)
             double* pk = park + jr_c * D;

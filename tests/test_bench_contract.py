@@ -61,7 +61,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     v = r['valu']
     assert r['binding'] == 'valu'
     if v is not None and v.get('measured_in_run'):      # collected during the run: a point value at the measured clock
-        assert v['bound'] == 'valu' and 0.2 < v['frac'] < 1.0 and 1.2 < v['clock_ghz'] < 2.6 and v['wave_instructions_per_generation'] > 1e6
+        assert v['bound'] == 'valu' and 0.2 < v['frac'] < 1.0 and 1.2 < v['clock_ghz'] < 2.7 and v['wave_instructions_per_generation'] > 1e6
         assert 5e3 < v['wave_instructions_per_env_step'] < 5e4 and 30 < v['active_lanes_per_instruction'] <= 64
     else:
         assert v is None or (v['bound'] == 'valu' and 0 < v['frac'][0] <= v['frac'][1] and v['wave_instructions_per_generation'] > 1e6)
