@@ -232,6 +232,48 @@ __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, dou
 #endif
 }
 
+// ---- exact resolution of near-ties in the FDR scan (MBX_FDR_TIEFLAG, see fdr_exact) -------------------------------------------------
+#ifndef MBX_FDR_TIEFLAG
+#define MBX_FDR_TIEFLAG 0
+#endif
+// if (dif < 0) { ab = a; bb = b; kb = k; }: fdr_take on the SIGN of dif = a_j b* - fl(a* b_j) (one fma instead of the second product: same instruction count)
+__device__ __forceinline__ void fdr_take_neg(double dif, double& ab, double& bb, int& kb, double a, double b, int k)
+{
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_f64_e32 0, %[d]\n\t"
+        "v_mov_b64 %[ab], %[a]\n\t"
+        "v_mov_b64 %[bb], %[b]\n\t"
+        "v_mov_b32 %[kb], %[k]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ab] "+v"(ab), [bb] "+v"(bb), [kb] "+v"(kb), [sv] "=&s"(saved)
+        : [d] "v"(dif), [a] "v"(a), [b] "v"(b), [k] "s"(k)
+        : "vcc");
+}
+// running minimum of |dif| over the pairs of a scan, kept on the HIGH dwords read as float32 (sign | exponent | 20 mantissa bits of a float64 are monotone in
+// the float32 order for finite values): ONE v_min3_f32 covers the two coordinates of a work item
+__device__ __forceinline__ float f64_hi_as_f32(double v) { return __int_as_float(__double2hiint(v)); }
+__device__ __forceinline__ float fdr_min3_abs(float m, float x, float y)
+{
+    float r;
+    asm("v_min3_f32 %[r], %[m], |%[x]|, |%[y]|" : [r] "=v"(r) : [m] "v"(m), [x] "v"(x), [y] "v"(y));
+    return r;
+}
+// The reference's own evaluation for ONE coordinate (rlepso_optimizer.py:100-102): rounded quotients, np.argmin = the first minimal one in PARTICLE order.
+// Only the strictly better particles (ranks < nless) can hold the minimum when there is one; ranks are (cost, index)-ordered, so the particle index is looked up.
+__device__ __noinline__ int fdr_by_division(const double* NC, const double* PB, const int* ORDER, int D, int rk, int d, int nless)
+{
+    const double fi = NC[rk], pp = PB[rk * D + d];
+    double qb = (NC[0] - fi) / (fabs(PB[d] - pp) + 1e-5);
+    int kb = 0, ib = ORDER[0];
+    for (int k = 1; k < nless; ++k) {
+        const double qk = (NC[k] - fi) / (fabs(PB[k * D + d] - pp) + 1e-5);
+        const int ik = ORDER[k];
+        if (qk < qb || (qk == qb && ik < ib)) { qb = qk; kb = k; ib = ik; }
+    }
+    return kb;
+}
+
 // ---- FDR exemplar (rlepso_optimizer.py:97-109): argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum.
 //  * j == i contributes the ratio 0, every particle with a larger pbest a positive one: the minimum is attained
 //    among the strictly better particles (negative ratios) if there are any, otherwise it is 0 and np.argmin
@@ -244,8 +286,9 @@ __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, dou
 // Exact float64 scan for W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk; returns the exemplar's rank per coordinate.
 // UN: candidates per unrolled group (MBX_FDR_UNROLL = 4 everywhere but config 5's resident kernel: 1024 threads, D = 40: 2 / 4 / 8 -> 1.619 / 1.641 / 1.703 ms per
 // generation; the headline kernel: 2 / 3 / 4 / 6 / 8 -> 119.9 / 117.1 / 116.5 / 117.5 / 121.6 us)
+// range: an upper bound of |p_jd - p_id| + 1e-5 (ub - lb + 1e-5), used by the near-tie flag only
 template <int W, int UN = MBX_FDR_UNROLL>
-__device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W])
+__device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W], double range = 0.)
 {
 #pragma unroll
     for (int q = 0; q < W; ++q) kb[q] = nless;                   // rank of the exemplar when nobody is strictly better
@@ -256,6 +299,56 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
 #pragma unroll
     for (int q = 0; q < W; ++q) { pp[q] = L.PB[rk * D + d0 + q]; kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
     const double* col = L.PB + d0;
+#if MBX_FDR_TIEFLAG
+    // Cross-multiplication orders the EXACT ratios; the reference rounds the quotients first (see tests/test_fdr_ties.py: 49 % / 9 % of crafted pairs 0 / 1 ulp
+    // apart resolve differently).  Every comparison also yields dif = a_j b* - fl(a* b_j); while |dif| > 8 ulp of the products, both forms decide alike (a
+    // quotient pair that rounds together or apart differs by <= 1 ulp, i.e. |a_j b* - a* b_j| <= 2^-52 |a* b_j|).  The scan keeps min |dif| (high dwords, one
+    // v_min3_f32 per two coordinates and candidate) and, at the end, compares it with 2^-49 x the largest product an item can form, |a_0| x range:
+    // an item that ever came that close is redone the reference's way (fdr_by_division) -- exact by construction, and rare (a near-tie needs two candidates
+    // with quotients 2^-49 apart; identical candidates -- collapsed swarms -- take this path too).
+    float tiem = __int_as_float(0x7f000000);
+    int k = 1;
+    for (; k + UN <= nless; k += UN) {
+        double a[UN], x[UN][W];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            a[u] = L.NC[k + u];
+#pragma unroll
+            for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const double au = a[u] - fi;
+            double difv[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const double b = fabs(x[u][q] - pp[q]) + 1e-5;
+                difv[q] = __builtin_fma(au, bb[q], -(ab[q] * b));
+                fdr_take_neg(difv[q], ab[q], bb[q], kb[q], au, b, k + u);
+            }
+            tiem = fdr_min3_abs(tiem, f64_hi_as_f32(difv[0]), f64_hi_as_f32(difv[W - 1]));
+        }
+    }
+    for (; k < nless; ++k) {
+        const double au = L.NC[k] - fi;
+        double difv[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
+            difv[q] = __builtin_fma(au, bb[q], -(ab[q] * b));
+            fdr_take_neg(difv[q], ab[q], bb[q], kb[q], au, b, k);
+        }
+        tiem = fdr_min3_abs(tiem, f64_hi_as_f32(difv[0]), f64_hi_as_f32(difv[W - 1]));
+    }
+    {
+        const double thr = fabs(a0) * range * 0x1p-49;               // |a* b_j| <= |a_0| x range for every pair of the item
+        if (!(tiem > f64_hi_as_f32(thr) * 1.0000005f)) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) kb[q] = fdr_by_division(L.NC, L.PB, L.IMPR, D, rk, d0 + q, nless);
+        }
+    }
+    return;
+#else
     // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
     // issued before its first comparison
     int k = 1;
@@ -285,6 +378,7 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
             fdr_take(a * bb[q], ab[q] * b, ab[q], bb[q], kb[q], a, b, k);
         }
     }
+#endif
 }
 
 // Velocity / position update of W adjacent coordinates of particle i (rlepso_optimizer.py:179-195); FDR exemplars from KB.
@@ -567,7 +661,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
             if (ps >= base && ps < lim) {
                 const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
                 int kb[2];
-                fdr_exact<2>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                fdr_exact<2>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
                 L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
             }
         }
@@ -578,7 +672,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
             if (es >= base && es < lim) {
                 const int rk = fd.div(es), d0 = es - rk * D;
                 int kb[1];
-                fdr_exact<1>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                fdr_exact<1>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
                 L.KB[es] = (uint8_t)kb[0];
             }
         }
@@ -901,7 +995,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
             if (ps >= base && ps < lim) {
                 const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
                 int kb[2];
-                fdr_exact<2, (DC == 40 ? 2 : MBX_FDR_UNROLL)>(L, D, rk, d0, NLESS[ORDER[rk]], kb);
+                fdr_exact<2, (DC == 40 ? 2 : MBX_FDR_UNROLL)>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
                 L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
             }
         }
