@@ -152,7 +152,11 @@ int mbx_reset(mbx_batch* b, double* d_state_out, void* stream);
  * (basic_environment.py:21-22, rlepso_optimizer.py:173-263).  d_actions is
  * [n_instances, action_dim] (float32; int32 for DEDDQN; NULL for RANDOM_SEARCH).  Outputs: next state (float64),
  * reward (float64), done (uint8).  Done instances are left untouched and report reward 0 (their state row keeps
- * its last value).  Workgroups are dispatched most-expensive-objective first. */
+ * its last value).  Workgroups are dispatched most-expensive-objective first.  *
+ * RLEPSO, FDR exemplar (src/optimizer/rlepso_optimizer.py:97-109): the reference takes np.argmin of ROUNDED quotients; the kernels order the exact ratios by
+ * cross-multiplication, which can resolve differently only when two non-identical candidates have quotients within one ulp of each other (measured:
+ * tests/test_fdr_ties.py; ~2e-16 per comparison on continuous data).  A batch created with MBX_FDR_EXACT=1 in the environment runs generation kernels that
+ * detect such near-ties and redo them with the reference's divisions: bit-exact exemplars on any input, one launch per generation, ~12 % slower. */
 int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out,
              uint8_t* d_done_out, void* stream);
 

@@ -81,6 +81,8 @@ struct mbx_batch {
     double* d_pci = nullptr;
     double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (RLEPSO batches; allocated by mbx_batch_create)
     float* d_lstm_pack = nullptr;          // k-blocked copy of the PolicyNet weights for k_lde_run (k_lde_repack at every mbx_lde_rollout call)
+    bool fdr_exact = false;                // RLEPSO, MBX_FDR_EXACT=1 when the batch was created: near-ties of the FDR scan resolved with the reference's rounded quotients
+                                           // (run-time-geometry kernels, one launch per generation; include/mbx.h, mbx_step)
     bool rl_run_kinds_ok = false;          // RLEPSO: every problem of the batch is one of the 24 BBOB kinds the per-kind k_rlepso_run geometries have a body for (rl_run_kind_ok)
     bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind k_lde_run builds (lde_run_kind_ok)
     bool rollout_per_generation = false;   // MBX_ROLLOUT_PER_GENERATION=1 at batch creation: mbx_rlepso_rollout takes the host-loop route (tests)
@@ -107,7 +109,8 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.tape_stride = MBX_RLEPSO_TAPE_STRIDE(c.np, c.dim);
         {   // compile-time geometries that read their maps from global memory need no LDS for them (unless the generic kernels are forced)
             const char* gg = getenv("MBX_GENERIC_GEOMETRY");
-            const bool generic = gg && gg[0] == '1';
+            const char* fe = getenv("MBX_FDR_EXACT");
+            const bool generic = (gg && gg[0] == '1') || (fe && fe[0] == '1');
             g.lds_doubles = rl_lds_doubles(c.np, c.dim, generic || c.n_group != 5 || rl_maps_in_lds(c.np, c.dim));
         }
         g.state_dim = 1; g.action_dim = 7 * c.n_group;
@@ -525,7 +528,9 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     // MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
     {
         const char* g = getenv("MBX_GENERIC_GEOMETRY");
-        if (cfg->algo == MBX_ALGO_RLEPSO && cfg->n_group == 5 && !(g && g[0] == '1')) {
+        const char* fe = getenv("MBX_FDR_EXACT");
+        b->fdr_exact = cfg->algo == MBX_ALGO_RLEPSO && fe && fe[0] == '1';
+        if (cfg->algo == MBX_ALGO_RLEPSO && cfg->n_group == 5 && !(g && g[0] == '1') && !b->fdr_exact) {
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 10) b->fixed_geometry = 1;
             if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
             if (b->threads == 512 && cfg->np == 100 && cfg->dim == 30) b->fixed_geometry = 7;
@@ -563,8 +568,11 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         // mbx_rlepso_rollout never allocates or reads the environment (it may run under stream capture): both happen here
         HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * sizeof(double)));
         const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");
-        b->rollout_per_generation = per_gen && per_gen[0] == '1';
+        b->rollout_per_generation = (per_gen && per_gen[0] == '1') || b->fdr_exact;
     }
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -683,7 +691,12 @@ static void launch_rlepso_step(mbx_batch* b, hipStream_t stream, const float* d_
 #define MBX_RLEPSO_LAUNCH(...)                                                                                                   \
     hipLaunchKernelGGL((k_rlepso_step<__VA_ARGS__>), dim3(b->B), dim3(b->threads), b->lds_bytes, stream, make_params(b), d_actions, \
                        d_state_out, d_reward_out, d_done_out, d_table, table_rows, d_actions_out)
-    if (b->fixed_geometry == 1) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
+    if (b->fdr_exact) {
+        if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024, 0, 0, 0, true);
+        else if (b->threads == 512) MBX_RLEPSO_LAUNCH(512, 0, 0, 0, true);
+        else MBX_RLEPSO_LAUNCH(kThreads, 0, 0, 0, true);
+    }
+    else if (b->fixed_geometry == 1) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
     else if (b->fixed_geometry == 2) MBX_RLEPSO_LAUNCH(1024, 128, 40, 5);
     else if (b->fixed_geometry == 7) MBX_RLEPSO_LAUNCH(512, 100, 30, 5);
     else if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024);

@@ -232,7 +232,8 @@ __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, dou
 #endif
 }
 
-// ---- exact resolution of near-ties in the FDR scan (MBX_FDR_TIEFLAG, see fdr_exact) -------------------------------------------------
+// ---- exact resolution of near-ties in the FDR scan (fdr_exact<.., TIE = true>: the kernels of a batch created with MBX_FDR_EXACT=1 in the environment;
+// -DMBX_FDR_TIEFLAG=1 turns it on in every kernel, for the A/B of its cost) ---------------------------------------------------------
 #ifndef MBX_FDR_TIEFLAG
 #define MBX_FDR_TIEFLAG 0
 #endif
@@ -287,7 +288,7 @@ __device__ __noinline__ int fdr_by_division(const double* NC, const double* PB, 
 // UN: candidates per unrolled group (MBX_FDR_UNROLL = 4 everywhere but config 5's resident kernel: 1024 threads, D = 40: 2 / 4 / 8 -> 1.619 / 1.641 / 1.703 ms per
 // generation; the headline kernel: 2 / 3 / 4 / 6 / 8 -> 119.9 / 117.1 / 116.5 / 117.5 / 121.6 us)
 // range: an upper bound of |p_jd - p_id| + 1e-5 (ub - lb + 1e-5), used by the near-tie flag only
-template <int W, int UN = MBX_FDR_UNROLL>
+template <int W, int UN = MBX_FDR_UNROLL, bool TIE = false>
 __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W], double range = 0.)
 {
 #pragma unroll
@@ -299,7 +300,7 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
 #pragma unroll
     for (int q = 0; q < W; ++q) { pp[q] = L.PB[rk * D + d0 + q]; kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
     const double* col = L.PB + d0;
-#if MBX_FDR_TIEFLAG
+    if constexpr (TIE || MBX_FDR_TIEFLAG) {
     // Cross-multiplication orders the EXACT ratios; the reference rounds the quotients first (see tests/test_fdr_ties.py: 49 % / 9 % of crafted pairs 0 / 1 ulp
     // apart resolve differently).  Every comparison also yields dif = a_j b* - fl(a* b_j); while |dif| > 8 ulp of the products, both forms decide alike (a
     // quotient pair that rounds together or apart differs by <= 1 ulp, i.e. |a_j b* - a* b_j| <= 2^-52 |a* b_j|).  The scan keeps min |dif| (high dwords, one
@@ -348,7 +349,7 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
         }
     }
     return;
-#else
+    } else {
     // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
     // issued before its first comparison
     int k = 1;
@@ -378,7 +379,7 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
             fdr_take(a * bb[q], ab[q] * b, ab[q], bb[q], kb[q], a, b, k);
         }
     }
-#endif
+    }
 }
 
 // Velocity / position update of W adjacent coordinates of particle i (rlepso_optimizer.py:179-195); FDR exemplars from KB.
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double
 // NPC / DC / GC: population, dimension and group count fixed at compile time (0 = taken from the batch).  The reference's own
 // geometry (NP = 100 hard-coded in rlepso_optimizer.py:9, n_group = 5, and the D = 10 of its bbob configs) gets an instantiation of
 // its own: index arithmetic, the divisions by D and the short D-loops of the evaluator fold into constants (-8 % per generation).
-template <int THREADS, int NPC = 0, int DC = 0, int GC = 0>
+// TIE: the FDR scan flags near-ties and resolves them with the reference's divisions (fdr_exact): the run-time-geometry instantiations exist in both forms
+template <int THREADS, int NPC = 0, int DC = 0, int GC = 0, bool TIE = false>
 __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
                                                           double* __restrict__ state_out, double* __restrict__ reward_out,
                                                           uint8_t* __restrict__ done_out, const float* __restrict__ policy_table,
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
             if (ps >= base && ps < lim) {
                 const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
                 int kb[2];
-                fdr_exact<2>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
+                fdr_exact<2, MBX_FDR_UNROLL, TIE>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
                 L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
             }
         }
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
             if (es >= base && es < lim) {
                 const int rk = fd.div(es), d0 = es - rk * D;
                 int kb[1];
-                fdr_exact<1>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
+                fdr_exact<1, MBX_FDR_UNROLL, TIE>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
                 L.KB[es] = (uint8_t)kb[0];
             }
         }

@@ -9,6 +9,7 @@ exemplar from the velocity the step produces, and counts:
   * CPU:  the oracle agrees with the literal numpy formula of the reference on every (particle, dimension)            -> asserted, 100 %
   * GPU:  the kernel agrees with it whenever the two quotients are >= 4 ulp apart                                      -> asserted, 100 %
           and the measured disagreement rate at 0 / 1 / 2-3 ulp                                                          -> printed
+  * GPU:  a batch created with MBX_FDR_EXACT=1 (near-ties flagged inside the scan and redone with the reference's divisions) agrees on EVERY pair -> asserted
   * GPU:  on natural swarms (Philox episodes of four functions) kernel and oracle pick the same exemplar everywhere    -> asserted
 """
 import numpy as np
@@ -148,14 +149,18 @@ def test_oracle_fdr_is_the_reference_formula_on_adversarial_swarms():
 
 
 @pytest.mark.gpu
-def test_hip_fdr_on_adversarial_swarms_measured_disagreement():
+@pytest.mark.parametrize('mode', ['default', 'exact'])
+def test_hip_fdr_on_adversarial_swarms_measured_disagreement(mode, monkeypatch):
     import torch
+    if mode == 'exact':
+        monkeypatch.setenv('MBX_FDR_EXACT', '1')               # read when the batch is created
     from metabox_amd.suite import Batch, Suite
     from metabox_amd._abi import ALGO_RLEPSO
     p = problems('bbob', D)[1]
     cases = crafted_cases(512)
     B = len(cases)
     batch = Batch(Suite([p]), ALGO_RLEPSO, np.zeros(B, int), np.arange(B), NP, MAXFES, LOGI, NLOG)
+    assert batch.launch_info()['fixed_geometry'] == (0 if mode == 'exact' else 1) and batch.rollout_is_resident() == (mode != 'exact')
     batch.reset()
     torch.cuda.synchronize()
     template = batch.read_state(0)
@@ -177,13 +182,18 @@ def test_hip_fdr_on_adversarial_swarms_measured_disagreement():
         others[0] += rest.size
         others[1] += int((~rest).sum())
     batch.close()
-    print('FDR exemplar, kernel (cross-multiplied compare) vs reference formula (rounded quotients, np.argmin) on crafted near-ties:')
+    print(f'FDR exemplar, kernel ({"MBX_FDR_EXACT=1: near-ties redone with divisions" if mode == "exact" else "cross-multiplied compare"}) vs reference formula '
+          f'(rounded quotients, np.argmin) on crafted near-ties:')
     for u in sorted(buckets):
         n, bad = buckets[u]
         print(f'  quotients {u}{"+" if u == 4 else ""} ulp apart: {bad} / {n} pairs resolved differently ({100. * bad / max(n, 1):.1f} %)')
     print(f'  all other (particle, dimension) items of the same swarms: {others[1]} / {others[0]}')
     assert buckets[4][1] == 0 and others[1] == 0, (buckets, others)
     assert buckets[0][0] >= 500 and buckets[1][0] >= 500
+    if mode == 'exact':
+        assert all(v[1] == 0 for v in buckets.values()), buckets
+    else:
+        assert buckets[2][1] == 0 and buckets[3][1] == 0, buckets          # measured: only quotients that round together or to neighbours resolve differently
 
 
 @pytest.mark.gpu

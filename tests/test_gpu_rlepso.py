@@ -120,6 +120,20 @@ def test_tape_replay_matches_reference_episodes(env):
     print_ledger(ledger)
 
 
+def test_tape_replay_in_exact_fdr_mode(env, monkeypatch):
+    """MBX_FDR_EXACT=1 (include/mbx.h, mbx_step): the generation kernels whose FDR scan flags near-ties and redoes them with the reference's divisions replay
+    reference episodes like the default kernels do (run-time-geometry instantiations, one launch per generation)."""
+    monkeypatch.setenv('MBX_FDR_EXACT', '1')
+    TR = load('rlepso_traces.npz')
+    TIES = load('rlepso_ties.npz')
+    s, ids = env['bbob']
+    mine = [c for c in (str(c) for c in TR['cases']) if c.split('/')[0] == 'bbob'][::3]
+    ledger = []
+    ne, w, info = _tape_replay_group(s, ids, TR, TIES, mine, NP, D, MAXFES, ledger)
+    assert info['fixed_geometry'] == 0 and ne + len(ledger) == len(mine)
+    print(f'exact-FDR mode: {ne}/{len(mine)} episodes identical in every generation, worst gbest rel err {w:.2e}')
+
+
 # (dim, NP) -> the compile-time-geometry instantiation mbx_step must take: 7 = k_rlepso_step<512, 100, 30, 5> (bbob --dim 30, the geometry config 3's
 # suite runs RLEPSO at), 2 = k_rlepso_step<1024, 128, 40, 5> (BASELINE config 5), 0 = the run-time-geometry kernel (NP 100 at D 40: the reference as shipped)
 HD_GEOMETRIES = {(30, 100): 7, (40, 100): 0, (40, 128): 2}
