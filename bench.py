@@ -757,6 +757,8 @@ def main():
         side_legs = None
         if world == 1 and not args.no_other_configs:
             try:
+                # (the first call of a process also pays the one-instance suite's set-up and a cold clock: 0.13 against 0.058 ms per env.step standalone; the second counts)
+                plugin_view_cost(episodes=1)
                 side_legs = {'plugin_view': plugin_view_cost(), 'other_configs': other_configs()}
             except Exception as exc:                       # the headline line must survive a failure of the side legs
                 side_legs = {'other_configs': {'error': repr(exc)}}

@@ -1,4 +1,4 @@
-"""Config 3 alone (LDE bbob-noisy d=30, 16 384 instances, LSTM policy included), for profiling:
+"""Config 3 alone (LDE bbob-noisy d=30, 16 384 instances, LSTM policy included; --suite / --dim for the reference's own bbob d=10 setting), for profiling:
    python tools/exp/lde_run.py [--pop 50,100] [--steps 20] [--route step|resident] [--gens-per-launch 10]
 Prints one JSON line per population with the wall time per generation."""
 import argparse, json, os, sys, time
@@ -17,10 +17,12 @@ ap.add_argument('--instances', type=int, default=16384)
 ap.add_argument('--route', default='step')
 ap.add_argument('--gens-per-launch', type=int, default=10)
 ap.add_argument('--functions', default='')
+ap.add_argument('--suite', default='bbob-noisy')
+ap.add_argument('--dim', type=int, default=30)
 args = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for np_lde in [int(x) for x in args.pop.split(',')]:
-    cfg = get_config(['--problem', 'bbob-noisy', '--dim', '30', '--device', 'cuda'])
+    cfg = get_config(['--problem', args.suite, '--dim', str(args.dim), '--device', 'cuda'])
     cfg.agent_save_dir = None
     if np_lde != 50:
         cfg.NP_override = np_lde
@@ -55,5 +57,5 @@ for np_lde in [int(x) for x in args.pop.split(',')]:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         run(args.steps)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({'pop': np_lde, 'route': args.route, 'ms_per_generation': dt * 1e3, 'launch_info': env.batch.launch_info()}), flush=True)
+    print(json.dumps({'suite': args.suite, 'dim': args.dim, 'resident': bool(env.batch.lde_rollout_is_resident()), 'pop': np_lde, 'route': args.route, 'ms_per_generation': dt * 1e3, 'launch_info': env.batch.launch_info()}), flush=True)
     env.close()
