@@ -221,6 +221,63 @@ def pmc_traffic_in_run(instances, timeout_s=150):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def qnet_child(launches=60):
+    """config 4's policy GEMM alone: mbx_ddqn_qnet (k_qnet_argmax, Q-network 99 -> 100 x 4 -> 4 + argmax on the float32 matrix cores) over one GPU's share of
+    config 4 (2240 instances); the parent runs this under one rocprofv3 --pmc pass."""
+    import torch
+    from metabox_amd.agent import DE_DDQN_Agent
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.optimizer import DE_DDQN_Optimizer
+    from metabox_amd.utils import construct_problem_set
+    torch.cuda.set_device(0)
+    cfg = get_config(['--problem', 'protein', '--device', 'cuda'])
+    cfg.agent_save_dir = None
+    torch.manual_seed(0)
+    agent = DE_DDQN_Agent(cfg).to('cuda')
+    tr, te = construct_problem_set(cfg)
+    ps = (tr + te).data[:35]
+    B = 35 * 64
+    env = BatchedPBO_Env(ps, DE_DDQN_Optimizer(cfg), np.repeat(np.arange(35), 64), np.arange(B, dtype=np.uint64) + 1)
+    env.reset()
+    packed = agent.packed_weights()
+    for _ in range(launches):
+        env.step(env.batch.ddqn_qnet(packed))
+    torch.cuda.synchronize()
+    env.close()
+
+
+def policy_mfma_in_run(timeout_s=120):
+    """Matrix-pipe utilisation of the policy GEMM that IS on a timed route -- config 4's k_qnet_argmax -- measured during this bench run: one rocprofv3 --pmc pass
+    (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_MFMA, GRBM_GUI_ACTIVE; no trace domains) over `bench.py --qnet-child`.  utilisation = busy cycles of the matrix pipes /
+    (1024 SIMDs x the dispatch's cycles), both from the same dispatch.  -> dict or None."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='mbx_mfma_')
+    try:
+        cmd = [exe, '--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU', '--output-format', 'csv', '-d', tmp, '-o', 'p', '--',
+               sys.executable, os.path.abspath(__file__), '--qnet-child']
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, MBX_BENCH_CHILD='1', TMPDIR='/tmp'), capture_output=True, text=True, timeout=timeout_s)
+        acc = {}
+        for path in glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if 'k_qnet_argmax' in row['Kernel_Name']:
+                        acc.setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
+        if r.returncode != 0 or 'SQ_VALU_MFMA_BUSY_CYCLES' not in acc or 'GRBM_GUI_ACTIVE' not in acc:
+            return None
+        m = {k: float(np.mean(v)) for k, v in acc.items()}
+        cyc = m['GRBM_GUI_ACTIVE'] / 8.
+        return {'kernel': 'k_qnet_argmax<99, 100, 4>', 'dispatches': len(acc['GRBM_GUI_ACTIVE']), 'mfma_instructions_per_launch': m.get('SQ_INSTS_MFMA'),
+                'vector_instructions_per_launch': m.get('SQ_INSTS_VALU'), 'shader_cycles_per_launch': cyc, 'utilisation': m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024. * cyc)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def policy_mfma_profile():
     """Matrix-pipe utilisation of the policy kernels that use the matrix cores (north_star: 'MFMA utilisation on the policy GEMM'), from the newest committed
     profile (tools/exp/mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)).  Not collected during the run."""
@@ -442,7 +499,10 @@ def main():
                     help='bracket every n-th generation kernel with HIP events (default: every kernel when steps <= 64, else every 8th)')
     ap.add_argument('--dist-backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only for single-GPU plumbing tests)')
     ap.add_argument('--same-device', action='store_true', help='plumbing test: every rank uses cuda:0')
+    ap.add_argument('--qnet-child', action='store_true', help='(internal) config 4\'s Q-network launch alone, for the MFMA counter pass of roofline.policy_mfma')
     args = ap.parse_args()
+    if args.qnet_child:
+        return qnet_child()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -769,6 +829,15 @@ def main():
             if per_step is not None:
                 traffic, traffic_in_run = per_step * live_per_launch, True
         first_gen = W % EPISODE_GENS + 1
+        policy_mfma = policy_mfma_profile()
+        if world == 1 and not args.no_pmc and not args.no_other_configs and not os.environ.get('MBX_BENCH_CHILD'):
+            live = policy_mfma_in_run()
+            if live is not None:
+                policy_mfma = {'measured_in_run': True, 'peak': 'float32 MFMA 157.3 TFLOP/s (one v_mfma_f32_16x16x4_f32 per 32 cycles per SIMD)', **live,
+                               'note': 'config 4\'s Q-network + argmax (mbx_ddqn_qnet), the one policy GEMM on a timed route: 2240 instances x 40 k MAC is ~1 us of matrix '
+                                       'work at peak; the launch is five dependent layers of 25-step MFMA chains, i.e. latency.  The headline policy is the memoised actor table '
+                                       '(no matrix work on the step path); LDE\'s PolicyNet runs inside k_lde_run as float32 fma chains.',
+                               'committed_profiles': (policy_mfma or {}).get('utilisation')}
         if valu_in_run is not None:
             # the PMC child is a process's FIRST short window: the chip's low-clock regime (window_clock), a longer launch: its ratio is that launch's.  The
             # wave-instruction COUNT is the same work in the timed windows; price it against the SIMD cycles of a window in the repeats' regime at the clock sampled there.
@@ -849,7 +918,7 @@ def main():
                          # instruction at the clock the chip really sustained (measured in this run when rocprofv3 is there; else priced from the committed profile)
                          'binding': 'valu',
                          'valu': valu_in_run or valu_roofline(live_per_gen, avg_gen_s, resident),
-                         'policy_mfma': policy_mfma_profile()},
+                         'policy_mfma': policy_mfma},
         }
         if side_legs is not None:
             out.update(side_legs)

@@ -855,3 +855,39 @@ def test_move_phase_draws_are_uniform():
     rs = np.random.RandomState(0)
     u = rs.rand(n)
     assert stats.kstest(u, 'uniform').pvalue > 1e-4 and stats.chisquare(np.bincount(rs.randint(0, NP, n), minlength=NP)).pvalue > 1e-4
+
+
+def test_snapshot_and_resume_of_instances_is_bit_exact(env):
+    """mbx_debug_read_state / mbx_debug_write_state = what `copy.deepcopy(env)` or a pickled optimizer is in the reference: a run that is snapshotted after 15
+    generations, continued for 20, rolled back to the snapshot and continued again repeats itself bit for bit (the Philox counters -- generation and episode --
+    travel in the state block), through the one-generation route and through the resident kernel."""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_RLEPSO
+    s, ids = env['bbob']
+    B = 24
+    seeds = np.arange(B, dtype=np.uint64) * 31 + 7
+    b = Batch(s, ALGO_RLEPSO, np.arange(B), seeds, NP, MAXFES, LOGI, NLOG)
+    table = torch.rand(MAXFES + 2 * NP + 1, 2, 35, generator=torch.Generator().manual_seed(1)).cuda()
+    table[:, 1] = 0.05 + 0.3 * table[:, 1]
+    table = table.contiguous()
+    b.reset()
+    b.rlepso_rollout(table, 15)
+    torch.cuda.synchronize()
+    snap = [b.read_state(k) for k in range(B)]
+    _, _, _, t1 = b.rlepso_rollout(table, 20, trajectory=True)
+    t1 = {k: v.clone() for k, v in t1.items()}
+    end1 = [b.read_state(k) for k in range(B)]
+    for k in range(B):
+        b.write_state(k, snap[k])
+    assert all(np.array_equal(b.read_state(k), snap[k], equal_nan=True) for k in range(B))
+    _, _, _, t2 = b.rlepso_rollout(table, 20, trajectory=True)
+    for key in t1:
+        assert torch.equal(t1[key], t2[key]), key
+    assert all(np.array_equal(b.read_state(k), end1[k], equal_nan=True) for k in range(B))
+    for k in range(B):                                       # ... and once more, one launch per generation
+        b.write_state(k, snap[k])
+    for g in range(20):
+        sb, rb, db, acts = b.act_step(table, want_actions=True)
+        assert torch.equal(t1['reward'][g], rb) and torch.equal(t1['done'][g], db), g
+    assert all(np.array_equal(b.read_state(k), end1[k], equal_nan=True) for k in range(B))
+    b.close()
