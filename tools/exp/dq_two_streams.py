@@ -12,9 +12,10 @@ from metabox_amd.utils import construct_problem_set
 cfg = get_config(['--problem', 'protein', '--device', 'cuda']); cfg.agent_save_dir = None
 torch.manual_seed(0)
 agent = DE_DDQN_Agent(cfg).to('cuda')
-tr, te = construct_problem_set(cfg); ps = (tr + te).data[:35]
-B = 35 * 64
-pidx = np.repeat(np.arange(35), 64); seeds = np.arange(B, dtype=np.uint64) + 1
+NPROB = int(os.environ.get('NPROB', '35'))
+tr, te = construct_problem_set(cfg); ps = (tr + te).data[:NPROB]
+B = NPROB * 64
+pidx = np.repeat(np.arange(NPROB), 64); seeds = np.arange(B, dtype=np.uint64) + 1
 packed = agent.packed_weights()
 STEPS = 300
 
@@ -42,8 +43,9 @@ def run(S, interleave):
     go(STEPS); t_issue = (time.perf_counter() - t1) / STEPS; torch.cuda.synchronize()
     cost = float(sum(e.results()['cost'][:, -1].sum().item() for e in envs))
     for e in envs: e.close()
-    return {'streams': S, 'interleaved': bool(interleave), 'ms_per_step': round(dt * 1e3, 4), 'host_issue_ms_per_step': round(t_issue * 1e3, 4), 'cost_sum': cost}
+    return {'instances': B, 'streams': S, 'interleaved': bool(interleave), 'ms_per_step': round(dt * 1e3, 4), 'host_issue_ms_per_step': round(t_issue * 1e3, 4), 'cost_sum': cost}
 
+MODES = ((1, False),) if NPROB != 35 else ((1, False), (2, False), (2, True), (3, True), (4, True), (1, False))
 for rep in range(2):
-    for S, il in ((1, False), (2, False), (2, True), (3, True), (4, True), (1, False)):
+    for S, il in MODES:
         print(json.dumps(run(S, il)), flush=True)
