@@ -19,7 +19,7 @@ pidx = np.repeat(np.arange(NPROB), 64); seeds = np.arange(B, dtype=np.uint64) + 
 packed = agent.packed_weights()
 STEPS = 300
 
-def run(S, interleave):
+def run(S, interleave, delay_us=0):
     order = np.arange(B)
     if interleave:                                      # every sub-batch gets every problem (cost balance)
         order = np.concatenate([np.arange(B)[s::S] for s in range(S)])
@@ -37,15 +37,19 @@ def run(S, interleave):
                 with torch.cuda.stream(streams[s]):
                     envs[s].step(envs[s].batch.ddqn_qnet(packed))
     go(20); torch.cuda.synchronize()
+    if delay_us:                                        # phase offset between the streams: stream s starts s x delay_us later
+        for s_ in range(1, S):
+            with torch.cuda.stream(streams[s_]):
+                torch.cuda._sleep(int(delay_us * s_ * 2100))
     t0 = time.perf_counter(); go(STEPS); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / STEPS
     t1 = time.perf_counter(); 
     # host-side issue cost alone: the same loop is asynchronous, so time the issue of another STEPS steps before synchronising
     go(STEPS); t_issue = (time.perf_counter() - t1) / STEPS; torch.cuda.synchronize()
     cost = float(sum(e.results()['cost'][:, -1].sum().item() for e in envs))
     for e in envs: e.close()
-    return {'instances': B, 'streams': S, 'interleaved': bool(interleave), 'ms_per_step': round(dt * 1e3, 4), 'host_issue_ms_per_step': round(t_issue * 1e3, 4), 'cost_sum': cost}
+    return {'instances': B, 'streams': S, 'delay_us': delay_us, 'interleaved': bool(interleave), 'ms_per_step': round(dt * 1e3, 4), 'host_issue_ms_per_step': round(t_issue * 1e3, 4), 'cost_sum': cost}
 
-MODES = ((1, False),) if NPROB != 35 else ((1, False), (2, False), (2, True), (3, True), (4, True), (1, False))
+MODES = ((1, False, 0),) if NPROB != 35 else ((1, False, 0), (2, False, 0), (2, True, 0), (2, True, 10), (2, True, 20), (2, True, 30), (2, True, 40), (3, True, 20), (1, False, 0))
 for rep in range(2):
-    for S, il in MODES:
-        print(json.dumps(run(S, il)), flush=True)
+    for S, il, dl in MODES:
+        print(json.dumps(run(S, il, dl)), flush=True)
