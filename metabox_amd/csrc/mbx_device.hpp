@@ -46,7 +46,8 @@ constexpr double kTwoPi = 6.283185307179586;
 // Device copy of a problem (pointers are device addresses inside the suite's constant pool).
 // ------------------------------------------------------------------------------------------------
 struct DevProblem {
-    int32_t func_id, kind, dim, n_peaks, noise_kind, pad;
+    int32_t func_id, kind, dim, n_peaks, noise_kind;
+    int32_t n_close;     // protein: the leading pairs of the list that can come within the 9 A cut-off while |x_k| <= ub (mbx_suite_create); 0 = not computed
     double bias, lb, ub, pen_coef, s[4], noise_a, noise_b, optimum;
     const double *dshift, *m1, *m2, *v0, *v1, *v2, *py, *pc, *pw;
     const double* pyr;   // Gallagher: R y_k, precomputed at upload (mbx_suite_create); protein: pair records [n_pairs][4] = sqrt(e) | q | r | 0
@@ -579,9 +580,16 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
     double* RED = P2 + ((n + 1) & ~1);
     const double2* __restrict__ rec = (const double2*)P.pyr;       // [n_pairs][2]: (sqrt(e), q), (r, 0) in pair order (mbx_suite_create)
     const int32_t* __restrict__ pij = (const int32_t*)P.plogw;
-    const int n_pairs = ((n + 1) >> 1) * (n - 1);
+    const int n_pairs_all = ((n + 1) >> 1) * (n - 1);
+    const int n_close = P.n_close;
     for (int r = 0; r < n_rows; ++r) {
         const double* x = L.X + r * D;
+        // The pair list is ordered by the SMALLEST distance a pair can reach while the candidate stays inside the box (|x_k| <= ub: every optimizer clamps / repairs
+        // to it): the pairs behind the first n_close can never come within the 9 A cut-off, their terms are exactly 0 and adding them changes nothing -- the loop
+        // stops there (bit-identical sums, ~half of the 4950 distance tests).  A row outside the box (mbx_eval takes any x) walks the whole list.
+        bool inside = n_close > 0;
+        for (int k = 0; k < D; ++k) inside = inside && fabs(x[k]) <= P.ub;
+        const int n_pairs = inside ? n_close : n_pairs_all;
         for (int m = tid; m < m3; m += MBX_NT) {
             double s = 0.;
             for (int k = 0; k < D; ++k) s += (x[k] * L.V0[k]) * P.py[(size_t)k * m3 + m];
