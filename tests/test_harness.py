@@ -377,3 +377,41 @@ def test_mgd_between_two_saved_agents(tmp_path):
     for p in res['cost']:
         assert res['cost'][p]['RLEPSO_Agent_from'] == res['cost'][p]['RLEPSO_Agent_to'] and len(res['cost'][p]['RLEPSO_Agent_to']) == 3
         assert res['fes'][p]['RLEPSO_Agent_from'] == res['fes'][p]['RLEPSO_Agent_to']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('agent_name,argv', [('RLEPSO_Agent', ['--problem', 'protein']), ('LDE_Agent', ['--problem', 'bbob', '--dim', '10'])])
+def test_default_settings_roll_out_resident_and_equal_the_per_generation_route(agent_name, argv, monkeypatch):
+    """VERDICT r04 item 6, through the plugin surface: `--problem protein` with RLEPSO and `--problem bbob --dim 10` with LDE -- the settings the reference ships
+    checkpoints and published T2 rows for -- take the resident kernels (mbx_*_rollout_resident = 1), and the agent's rollout_batch returns the same table as with
+    MBX_ROLLOUT_PER_GENERATION=1 (one launch pair per generation), bit for bit."""
+    import torch
+    from metabox_amd import agent as agents, optimizer as optimizers
+    from metabox_amd.config import get_config
+    from metabox_amd.environment import BatchedPBO_Env
+    from metabox_amd.utils import construct_problem_set
+    cfg = get_config(argv + ['--device', 'cuda'])
+    cfg.agent_save_dir = None
+    torch.manual_seed(0)
+    agent = getattr(agents, agent_name)(cfg)
+    name = 'rlepso_bbob_easy.npz' if agent_name == 'RLEPSO_Agent' else 'lde_bbob_easy.npz'
+    agent = agent.load_exported_weights(np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'metabox_amd', 'agent_model', name))).to('cuda')
+    opt = getattr(optimizers, agent_name.replace('_Agent', '_Optimizer'))(cfg)
+    train, test = construct_problem_set(cfg)
+    ps = (train + test).data[:12]
+    B = 36
+    pidx, seeds = np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 5
+    outs = []
+    for per_generation in (False, True):
+        if per_generation:
+            monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')          # read when the batch is created
+        env = BatchedPBO_Env(ps, opt, pidx, seeds)
+        resident = env.batch.rollout_is_resident() if agent_name == 'RLEPSO_Agent' else env.batch.lde_rollout_is_resident()
+        assert bool(resident) == (not per_generation), (agent_name, per_generation)
+        with torch.no_grad():
+            r = agent.rollout_batch(env)
+        outs.append({k: v.clone() for k, v in r.items()})
+        env.close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), (agent_name, k)
+    assert bool((outs[0]['steps'] > 0).all())
