@@ -216,6 +216,10 @@ __device__ unsigned long long g_phase_cycles[8192 * 16];         // [block][phas
 // v_cndmask_b32 the compiler's if-conversion produces: the FDR scan below is VALU-issue bound and this is its innermost statement.
 __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, double& bb, int& kb, double a, double b, int k)
 {
+#ifdef MBX_FDR_BRANCH
+    // experiment (tools/fdr_sim/take_stats.py: on real swarms no lane of a wave takes in 50.5 % of the wave-steps): a wave-uniform branch around the masked moves
+    if (__builtin_amdgcn_ballot_w64(lhs < rhs) == 0ull) return;
+#endif
 #ifdef MBX_FDR_SELECT
     if (lhs < rhs) { ab = a; bb = b; kb = k; }
 #else
