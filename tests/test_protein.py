@@ -93,6 +93,15 @@ def test_hip_energy_matches_reference_and_oracle():
         assert np.all(np.abs(s.eval(k, X) - g) <= 1e-9 * np.abs(g)), pid
     p = byid[keys[0]]
     assert np.ndim(p.eval(KAT['x'][0])) == 0 and p.eval(KAT['x']).shape == (12,)
+    # The kernel stops its pair walk behind the pairs that can reach the 9 A cut-off while the candidate is inside the box (DevProblem::n_close, ordered at upload by the
+    # smallest reachable distance); a candidate OUTSIDE the box (mbx_eval takes any x) must walk the whole list.  Rows far outside move atoms by several Angstrom, so pairs
+    # beyond n_close do come within the cut-off: the energies must still be the oracle's.  Rows on the box's faces (|x_k| = ub exactly) take the short walk.
+    rs = np.random.RandomState(2)
+    Xout = np.concatenate([rs.uniform(-4., 4., size=(40, 12)), np.where(rs.uniform(size=(24, 12)) < 0.5, -1.5, 1.5), rs.uniform(-1.5, 1.5, size=(24, 12))])
+    Xout[40:64:2, 3] = 1.5000000000000002                                         # one ulp outside on one coordinate
+    for k, pid in enumerate(keys):
+        g = oracle.evaluate(byid[pid].desc(), Xout)
+        assert np.all(np.abs(s.eval(k, Xout) - g) <= 1e-9 * np.abs(g) + 1e-12), pid
 
 
 @pytest.mark.gpu
