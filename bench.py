@@ -118,6 +118,15 @@ def cpu_baseline(seconds_budget=20.0):
                       f'{one["steps"]} env-steps in {one["seconds"]:.1f} s'}
 
 
+def _child_env():
+    """Environment of the rocprofv3 child processes: this process's, WITHOUT the rendezvous variables of torch.distributed.run (a child that inherited RANK /
+    WORLD_SIZE / MASTER_* would join -- or collide with -- the parent's process group) and with the child marker set."""
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith('TORCHELASTIC_') or k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'MASTER_ADDR', 'MASTER_PORT'))}
+    env.update(MBX_BENCH_CHILD='1', TMPDIR='/tmp')
+    return env
+
+
 def _latest_profile():
     """The newest committed PMC summary (tools/pmc_summary.py output), or None."""
     import glob
@@ -172,7 +181,7 @@ def pmc_traffic_in_run(instances, timeout_s=150):
     try:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE', sq_pass):
             out = os.path.join(tmp, counter.split()[0])
-            env = dict(os.environ, MBX_BENCH_CHILD='1', TMPDIR='/tmp')
+            env = _child_env()
             cmd = [exe, '--pmc', *counter.split(), '--output-format', 'csv', '-d', out, '-o', 'p', '--', sys.executable, os.path.abspath(__file__), '--steps', '20',
                    '--warmup', '2', '--repeats', '1', '--instances', str(instances), '--no-cpu-baseline', '--no-other-configs']
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
@@ -259,7 +268,7 @@ def policy_mfma_in_run(timeout_s=120):
     try:
         cmd = [exe, '--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU', '--output-format', 'csv', '-d', tmp, '-o', 'p', '--',
                sys.executable, os.path.abspath(__file__), '--qnet-child']
-        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, MBX_BENCH_CHILD='1', TMPDIR='/tmp'), capture_output=True, text=True, timeout=timeout_s)
+        r = subprocess.run(cmd, cwd='/tmp', env=_child_env(), capture_output=True, text=True, timeout=timeout_s)
         acc = {}
         for path in glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True):
             with open(path) as f:
@@ -466,6 +475,56 @@ def other_configs(budget_s=60.0):
             entry('config 5: RLEPSO mixed suite (24 bbob + 30 noisy) d=40 pop=128, 8192 instances (one GPU of eight), mbx_rlepso_rollout (20 generations per launch, median of 3 launches)', B, dt,
                   2 * S5 + 4 * 35 + (D5 * D5 + D5 + 2) * 8 + 13, {'launch_info': b.launch_info()})
             b.close()
+        # ---- the reference's OWN default settings, resident (built for route coverage in round 5, timed since round 6)
+        # LDE as shipped: NP = 50 (lde_optimizer.py:10) on bbob --dim 10 (config.py:74), k_lde_run<50, 10>, all 24 objective kinds
+        if time.perf_counter() - t_start <= budget_s + 15:
+            cfg = get_config(['--problem', 'bbob', '--dim', '10', '--device', 'cuda'])
+            cfg.agent_save_dir = None
+            agent = LDE_Agent(cfg)
+            agent.load_exported_weights(np.load(os.path.join(ROOT, 'metabox_amd', 'agent_model', 'lde_bbob_easy.npz')))
+            agent.to('cuda')
+            tr, te = construct_problem_set(cfg)
+            ps = sorted(tr.data + te.data, key=lambda p: p.func_id)
+            B = 16384
+            env = BatchedPBO_Env(ps, LDE_Optimizer(cfg), np.arange(B) % len(ps), np.arange(B, dtype=np.uint64) + 1, early_stop=False)
+            env.reset()
+            net, hh, cc = agent.net, torch.zeros(B, 50, device='cuda'), torch.zeros(B, 50, device='cuda')
+            res10 = env.batch.lde_rollout_is_resident()
+
+            def run10(n, env=env, net=net, hh=hh, cc=cc):
+                env.batch.lde_rollout(net.packed_weights(), net.lstm.hidden_size, hh, cc, n)
+            run10(3)
+            dt = sorted(_bracket(run10, 50) for _ in range(3))[1]
+            entry('reference default: LDE bbob d=10 pop=50 (lde_optimizer.py:10), 16384 instances, LSTM policy included, mbx_lde_rollout (50 generations per launch, median of 3 launches)', B, dt,
+                  (2 * 50 * 10 + 2 * 50) * 8 + 4 * 2 * 50 + 8 * (50 + 10) + (10 * 10 + 10 + 2) * 8,
+                  {'launch_info': {'kernel': 'k_lde_run<50, 10>', 'threads': 64 * ((50 + 15) // 16), 'resident': bool(res10), 'step_kernel': env.batch.launch_info()}})
+            env.close()
+        # RLEPSO on protein docking (config.py:86-90: dim 12, maxFEs 1000 -> 9 generations per episode), k_rlepso_run<256, 100, 12, 5>: reset + ONE launch per episode
+        if time.perf_counter() - t_start <= budget_s + 25:
+            cfg = get_config(['--problem', 'protein', '--device', 'cuda'])
+            cfg.agent_save_dir = None
+            agent = RLEPSO_Agent(cfg).load_exported_weights(np.load(os.path.join(ROOT, 'metabox_amd', 'agent_model', 'rlepso_bbob_easy.npz'))).to('cuda')
+            actor = agent.actor
+            h1, h2 = actor.hidden_sizes()
+            tr, te = construct_problem_set(cfg)
+            ps = (tr + te).data[:35]
+            B = 35 * 64
+            b = Batch(Suite(ps), ALGO_RLEPSO, np.repeat(np.arange(35), 64), np.arange(B, dtype=np.uint64) + 1, 100, 1000, 200, 5)
+            table = b.policy_table(actor.packed_weights(), h1, h2, actor.min_sigma, actor.max_sigma)
+            resp = b.rollout_is_resident()
+
+            def runp(n, b=b, table=table):
+                for _ in range(n // 9):
+                    b.reset()
+                    b.rlepso_rollout(table, 9)
+            runp(18)
+            dt = sorted(_bracket(runp, 90) for _ in range(3))[1]      # ten whole episodes, the initial evaluation (mbx_reset) included; per GENERATION
+            Sp = (3 * 100 * 12 + 3 * 100 + 12 + 1) * 8 + 16
+            entry('reference default: RLEPSO protein-docking d=12 pop=100 (config.py:86-90), 2240 instances = 35 problems x 64 runs, mbx_reset + mbx_rlepso_rollout (whole 9-generation '
+                  'episodes, one launch each; median of 3 x 10 episodes)', B, dt, 2 * Sp + 4 * 35 + 13,
+                  {'note': 'compute-bound: 100 protein energies per instance-generation (4950 atom pairs each) against 60 k FDR candidate pairs; the HBM fraction is nominal',
+                   'launch_info': {'kernel': 'k_rlepso_run<256, 100, 12, 5>', 'resident': bool(resp), **b.launch_info()}})
+            b.close()
     return out
 
 
@@ -601,11 +660,26 @@ def main():
         policy_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(policy_graph), torch.no_grad():
             static_actions = policy(state)
+    slot_pool = []
+
+    def clock_slots(detach=False):
+        """A fresh zeroed slot pair {sum of shader cycles, sum of 100 MHz ticks over the workgroups' lifetimes}, attached to the batch for its next resident launch."""
+        import ctypes as C
+        if detach:
+            env.batch.lib.mbx_debug_clock_slots(env.batch._h, None)
+            return None
+        if not slot_pool or slot_pool[-1][1] == slot_pool[-1][0].shape[0]:
+            slot_pool.append([torch.zeros(256, 2, dtype=torch.int64, device=dev), 0])
+        blk, used = slot_pool[-1]
+        slot_pool[-1][1] = used + 1
+        env.batch.lib.mbx_debug_clock_slots(env.batch._h, C.c_void_p(blk[used].data_ptr()))
+        return blk[used]
+
     def timed_window():
         """One measurement: mbx_reset, W untimed warm-up generations, barrier + synchronize, EXACTLY K timed generations, barrier +
         synchronize.  Returns (elapsed seconds on this rank, live env-steps of the K generations, resident launches, marks, mark_step, reset_steps)."""
         nonlocal state
-        marks, mark_step, reset_steps, launches = [], [], [], []     # launches: (event before, event after, generations) of every timed launch
+        marks, mark_step, reset_steps, launches = [], [], [], []     # launches: (event before, event after, generations, clock slots) of every timed launch
         gen_in_ep, live, base = 0, 0, 0
         t0 = None
         state = env.reset()
@@ -630,13 +704,15 @@ def main():
                     # one launch = up to --gens-per-launch generations; it ends where the warm-up, the timed window or the episode ends
                     n = min(max(1, args.gens_per_launch), EPISODE_GENS - gen_in_ep, (W if it < W else W + K) - it)
                     if it >= W:
+                        slots = clock_slots()                          # the launch stamps its own first start / last end per XCD (mbx_debug_clock_slots): host-side pointer set, no device work
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record()
                     state, _, _ = env.batch.rlepso_rollout(fused_table, n)
                     if it >= W:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record()
-                        launches.append((e0, e1, n))
+                        launches.append((e0, e1, n, slots))
+                        clock_slots(detach=True)
                     it += n
                     gen_in_ep += n
                     continue
@@ -664,62 +740,6 @@ def main():
             elapsed = time.perf_counter() - t0
             live += steps_sum() - base
         return elapsed, live, launches, marks, mark_step, reset_steps
-
-    def window_clock(prime=6):
-        """Shader clock during a timed window, no profiler attached: the window once more (reset, W warm-up generations, the same K generations in the same
-        launches) with a one-wave kernel on a side stream that samples s_memtime (shader cycles of ITS XCD; the counters of different XCDs are offset against
-        each other, so one wave takes all samples) and s_memrealtime (100 MHz) beside the launches (mbx_debug_clock_probe); two mbx_debug_clock_mark launches on
-        the launch stream bracket the K generations in the real-time base.
-        The chip has two regimes (tools/exp/clock_windows.py, round 5): after >= ~10 ms of back-to-back work the kernel runs at ~2.3 GHz (108 us per generation, what
-        the 30-200 back-to-back repeats of the headline measure); a short window after >= 50 ms without work runs at 2.0-2.1 GHz (122-131 us per generation: a
-        process's first window, e.g. the rocprofv3 children).  The probed window is therefore preceded by `prime` plain windows, back to back.  -> dict or None."""
-        if not resident:
-            return None
-        import ctypes as C
-        lib = env.batch.lib
-        Kc = max(1, min(K, 50, EPISODE_GENS - W % EPISODE_GENS))           # early generations of an episode: every instance is live, the work per generation is known
-        n_s = 2048
-        est_s = max(Kc * 0.12e-3, 1e-3)                                   # ~0.11 ms per generation
-        sleep_units = max(127, int(est_s * 1.6 / n_s * 2.1e9 / 64))
-        buf = torch.zeros(n_s, 2, dtype=torch.int64, device=dev)
-        marks = torch.zeros(2, 2, dtype=torch.int64, device=dev)
-        side = torch.cuda.Stream()
-        main_s = torch.cuda.current_stream()
-        with torch.no_grad():
-            for _ in range(prime + 1):                                      # `prime` plain windows, then the probed one: no host work in between
-                env.reset()
-                it = 0
-                while it < W:
-                    n = min(max(1, args.gens_per_launch), EPISODE_GENS, W - it)
-                    env.batch.rlepso_rollout(fused_table, n)
-                    it += n
-                if _ < prime:
-                    env.batch.rlepso_rollout(fused_table, Kc)
-            barrier()
-            if lib.mbx_debug_clock_probe(C.c_void_p(buf.data_ptr()), n_s, sleep_units, C.c_void_p(side.cuda_stream)) != 0:
-                return None
-            lib.mbx_debug_clock_mark(C.c_void_p(marks[0].data_ptr()), C.c_void_p(main_s.cuda_stream))
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            it, gen_in_ep = 0, W % EPISODE_GENS
-            while it < Kc:
-                n = min(max(1, args.gens_per_launch), EPISODE_GENS - gen_in_ep, Kc - it)
-                if n <= 0:
-                    break                                                  # (an episode restart inside the window: the clock of the first part is enough)
-                env.batch.rlepso_rollout(fused_table, n)
-                it += n; gen_in_ep += n
-            e1.record()
-            lib.mbx_debug_clock_mark(C.c_void_p(marks[1].data_ptr()), C.c_void_p(main_s.cuda_stream))
-            torch.cuda.synchronize()
-        m = marks.cpu().numpy().astype(np.float64)
-        bb = buf.cpu().numpy().astype(np.float64)
-        inside = (bb[:, 1] >= m[0, 1]) & (bb[:, 1] <= m[1, 1])
-        if inside.sum() < 8:
-            return None
-        per = np.diff(bb[inside, 0]) / np.diff(bb[inside, 1]) * 0.1
-        return {'clock_ghz': float((bb[inside, 0][-1] - bb[inside, 0][0]) / (bb[inside, 1][-1] - bb[inside, 1][0]) * 0.1),
-                'clock_ghz_min_max_over_samples': [float(per.min()), float(per.max())], 'samples_in_window': int(inside.sum()), 'generations': int(it),
-                'between_marks_us': float((m[1, 1] - m[0, 1]) * 0.01), 'kernel_us_per_generation_by_events': float(e0.elapsed_time(e1) * 1e3 / max(it, 1))}
 
     red_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')
 
@@ -768,8 +788,8 @@ def main():
             span_ms += max(marks[j].elapsed_time(marks[j + 1]) - pair_ms, 0.)
             span_kernels += b_ - a_
     if resident:                                        # every launch of the window is bracketed by its own event pair
-        span_ms = sum(max(a_.elapsed_time(b_) - pair_ms, 0.) for a_, b_, _ in launches)
-        span_kernels = sum(n for _, _, n in launches)
+        span_ms = sum(max(l[0].elapsed_time(l[1]) - pair_ms, 0.) for l in launches)
+        span_kernels = sum(l[2] for l in launches)
     if span_kernels == 0:                               # policies that launch their own kernels between generations: fall back to the step time
         span_ms, span_kernels = float(np.median([w[0] for w in windows])) * 1e3, K
     kern_ms = span_ms / span_kernels * K                # generation-kernel time of K timed generations, averaged over every bracketed kernel of every repeat
@@ -802,17 +822,49 @@ def main():
         live_per_launch = live_per_gen * gens_per_launch           # env-steps (live instance-generations) one launch processes
         bytes_per_launch = ALGO_BYTES_PER_STEP * live_per_launch
         achieved = bytes_per_launch / avg_kernel_s / 1e9
+        # shader cycles of the timed launches, stamped by the launches themselves (mbx_debug_clock_slots): no probe wave, no profiler, the timed repeats' own regime
         wc = None
-        if resident and world == 1 and not args.no_pmc and not os.environ.get('MBX_BENCH_CHILD'):
+        if resident:
+            st = np.array([l[3].cpu().numpy().astype(np.float64) for l in launches if l[3] is not None]).reshape(-1, 2)      # [launch, {cycles, 10 ns ticks}] summed over workgroups
+            ev_ns = np.array([max(l[0].elapsed_time(l[1]) - pair_ms, 0.) * 1e6 for l in launches if l[3] is not None])
+            gens = np.array([l[2] for l in launches if l[3] is not None], dtype=np.float64)
+            ok = (st[:, 1] > 0) if len(st) else np.zeros(0, bool)
+            if ok.any():
+                ghz = st[ok, 0] / (st[ok, 1] * 10.)
+                clock = float(st[ok, 0].sum() / (st[ok, 1].sum() * 10.))
+                wc = {'clock_ghz': clock, 'shader_cycles_per_generation': clock * float(ev_ns[ok].sum() / gens[ok].sum()), 'stamped_launches': int(ok.sum()),
+                      'clock_ghz_p10_p50_p90_over_launches': [float(np.percentile(ghz, q)) for q in (10, 50, 90)],
+                      'method': ('thread 0 of every workgroup of k_rlepso_run reads s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end and adds both '
+                                 'differences to the launch\'s sums (mbx_debug_clock_slots): clock = sum of cycles / sum of time over the workgroups of all timed launches; '
+                                 'shader cycles per generation = that clock x the launches\' generation time by HIP events.  No probe wave, no profiler, the timed repeats themselves.')}
+        # side field: the same window on a batch created with MBX_F_FDR_FAST (the cross-multiplied FDR scan without the near-tie flag / settle stage; the headline runs the
+        # exact default).  Same instances, same launches, wall time between synchronize pairs like the headline's repeats; right behind them (same clock regime).
+        fdr_fast = None
+        if resident and world == 1 and not os.environ.get('MBX_BENCH_CHILD'):
             try:
-                wcs = sorted([w for w in (window_clock() for _ in range(3)) if w], key=lambda w: w['kernel_us_per_generation_by_events'])
-                if wcs:
-                    wc = dict(wcs[len(wcs) // 2])
-                    wc['all_windows'] = [{k: w[k] for k in ('clock_ghz', 'kernel_us_per_generation_by_events')} for w in wcs]
-                    wc['method'] = ('a one-wave kernel on a side stream samples s_memtime (shader cycles) and s_memrealtime (100 MHz) beside the K timed generations, no profiler '
-                                    'attached, after six plain windows back to back like the timed repeats (mbx_debug_clock_probe / mbx_debug_clock_mark); median of three such windows')
+                from metabox_amd._abi import ALGO_RLEPSO, F_FDR_FAST
+                from metabox_amd.suite import Batch
+                fb = Batch(env.suite, ALGO_RLEPSO, pidx, seeds, NP_, MAXFES, MAXFES // 50, 50, early_stop=not args.fixed_horizon, flags=F_FDR_FAST)
+                assert fb.flags & F_FDR_FAST and fb.rollout_is_resident()
+                ts = []
+                for _ in range(min(repeats, 60)):
+                    fb.reset()
+                    it = 0
+                    while it < W + K:
+                        if it == W:
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                        n = min(max(1, args.gens_per_launch), EPISODE_GENS - it % EPISODE_GENS, (W if it < W else W + K) - it)
+                        if it % EPISODE_GENS == 0 and it > 0:
+                            fb.reset()
+                        fb.rlepso_rollout(fused_table, n)
+                        it += n
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                fb.close()
+                fdr_fast = float(np.median(ts) / K * 1e3)
             except Exception as exc:
-                wc = {'error': repr(exc)}
+                fdr_fast = {'error': repr(exc)}
         # the side legs are timed legs: they run right behind the headline's repeats, before the (slow, idle-heavy) profiler children
         side_legs = None
         if world == 1 and not args.no_other_configs:
@@ -844,24 +896,20 @@ def main():
             valu_in_run['frac_profiled_launch'] = valu_in_run.pop('frac')
             valu_in_run['clock_ghz_profiled_launch'] = valu_in_run.pop('clock_ghz')
             valu_in_run['timed_window_clock'] = wc
-            if wc and wc.get('clock_ghz') and 1.0 < wc['clock_ghz'] < 3.0:
-                # The kernel costs the same number of SHADER CYCLES per generation in every clock regime the chip was seen in (round 5: 261-265 k at 2.03, 2.06, 2.19,
-                # 2.28 GHz; tools/exp/clock_windows.py): cycles = the probed window's clock x its generation time by HIP events.  frac prices the vector
-                # wave-instructions of a generation (count from the profiled child: same work; every instance is live in generations W+1 .. W+K) at 4 issue cycles
-                # against those cycles; the clock of the timed repeats follows from the same cycle count and THEIR generation time (the probe wave itself keeps the
-                # chip 5-8 % below the clock the undisturbed repeats reach).
-                cyc = wc['clock_ghz'] * 1e3 * wc['kernel_us_per_generation_by_events']
-                wi = valu_in_run['wave_instructions_per_env_step'] * B
+            if wc and 1.0 < wc['clock_ghz'] < 3.0:
+                # frac prices the vector wave-instructions of a generation (count per env-step from the profiled child: same work) at 4 issue cycles against the shader
+                # cycles the TIMED launches themselves took (stamped in the kernel); clock_ghz = those cycles / the same launches' HIP-event time.
+                cyc = wc['shader_cycles_per_generation']
+                wi = valu_in_run['wave_instructions_per_env_step'] * live_per_gen
                 valu_in_run['shader_cycles_per_generation'] = cyc
                 valu_in_run['frac'] = wi * 4. / (1024. * cyc)
-                valu_in_run['clock_ghz_probed_window'] = wc['clock_ghz']
-                valu_in_run['clock_ghz'] = cyc / (avg_gen_s * 1e9) * (B / max(live_per_gen, 1.))     # timed repeats (per-generation time scaled to a full batch)
-                valu_in_run['frac_is'] = ('vector wave-instructions per generation x 4 issue cycles / (1024 SIMDs x shader cycles per generation); cycles = clock x generation time of a '
-                                          'window of THIS process probed without a profiler (timed_window_clock); clock_ghz = those cycles / the timed repeats\' own generation time')
+                valu_in_run['clock_ghz'] = wc['clock_ghz']
+                valu_in_run['frac_is'] = ('vector wave-instructions per generation (per-env-step count of the profiled child x live instances per generation of the timed windows) x 4 '
+                                          'issue cycles / (1024 SIMDs x shader cycles per generation stamped by the timed launches themselves); clock_ghz = stamped cycles / HIP-event time')
             else:
                 valu_in_run['frac'] = valu_in_run['frac_profiled_launch']
                 valu_in_run['clock_ghz'] = valu_in_run['clock_ghz_profiled_launch']
-                valu_in_run['frac_is'] = 'the profiled launch\'s own ratio (no usable clock sample of the timed window)'
+                valu_in_run['frac_is'] = 'the profiled launch\'s own ratio (no stamped cycles of the timed windows)'
             if valu_in_run.get('f64_share') and valu_in_run.get('active_lanes_per_instruction'):
                 # issue slots are not useful work: the share of float64 arithmetic among the vector instructions x the lanes that are switched on
                 valu_in_run['useful_f64_frac'] = valu_in_run['frac'] * valu_in_run['f64_share'] * valu_in_run['active_lanes_per_instruction'] / 64.
@@ -874,9 +922,13 @@ def main():
             'backend': (dist.get_backend() if dist is not None else None),
             'ranks_seen': [{'rank': int(r[0]), 'device': int(r[1])} for r in diag_rows],
             'per_rank': {'ms_per_step': [r[2] for r in diag_rows], 'live_env_steps': [r[3] for r in diag_rows], 'kernel_us_per_generation': [r[4] for r in diag_rows]},
-            'repeats': repeats, 'spread': float((times.max() - times.min()) / np.median(times)) if repeats > 1 else 0.0,
+            # spread: (max - min) / median of the repeats' wall times WITHOUT the first repeat (a process's first window runs in the chip's low-clock regime and pays
+            # first-touch costs; it is a timed repeat like the others -- the median does not care -- but it says nothing about the measurement's stability)
+            'repeats': repeats, 'spread': float((times[1:].max() - times[1:].min()) / np.median(times[1:])) if repeats > 2 else 0.0,
+            'spread_with_first_repeat': float((times.max() - times.min()) / np.median(times)) if repeats > 1 else 0.0,
             'timed_region_s': float(times.sum()),
             'repeat_ms_per_step': {'min': float(times.min() / K * 1e3), 'median': float(np.median(times) / K * 1e3), 'max': float(times.max() / K * 1e3),
+                                   'p10': float(np.percentile(times, 10) / K * 1e3), 'p50': float(np.percentile(times, 50) / K * 1e3), 'p90': float(np.percentile(times, 90) / K * 1e3),
                                    'slowest_repeat': int(times.argmax()), 'max_without_first': float(times[1:].max() / K * 1e3) if repeats > 1 else None},
             'config': {'workload': f'RLEPSO_Agent + RLEPSO_Optimizer, bbob dim=10 pop=100, {B} lock-step instances per GPU '
                                    f'({fn_desc} round-robin x seeds), maxFEs=20000 (199 generations/episode), '
@@ -910,6 +962,8 @@ def main():
                                            ((f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
                                              f"run's live instances (not collected during this run" + (f': {traffic_note}' if traffic_note else '') + ')') if traffic_src else None),
                          'kernel': 'k_rlepso_run<256, 100, 10, 5>' if resident else 'k_rlepso_step<256, 100, 10, 5>',
+                         # FDR exemplar: exact by default (index = the reference's np.argmin of rounded quotients on any input); the MBX_F_FDR_FAST kernels on the same window
+                         'fdr': 'exact (default flags)', 'fdr_fast_ms_per_step': fdr_fast,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'avg_kernel_us': avg_kernel_s * 1e6, 'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_STEP,
                          'env_steps_per_launch': live_per_launch, 'generations_per_launch': gens_per_launch,

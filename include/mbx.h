@@ -113,7 +113,23 @@ typedef struct mbx_algo_cfg {
     int32_t n_logpoint;    /* config.n_logpoint   (src/config.py:77,90)                           */
     int32_t early_stop;    /* 1 = reference rule `done = fes>=maxFEs or gbest<=1e-8`; 0 = fixed horizon */
     int32_t n_group;       /* RLEPSO: 5 (rlepso_optimizer.py:26)                                  */
+    uint32_t flags;        /* MBX_F_* below, OR-ed; 0 = the defaults.  Per batch: two batches of one process may differ. */
 } mbx_algo_cfg;
+
+/* Per-batch behaviour options (mbx_algo_cfg.flags).  They select among kernels that compute the SAME update(); none changes a result except
+ * MBX_F_FDR_FAST, and that one only where two FDR candidates have quotients within two ulp of each other.
+ *   MBX_F_FDR_FAST               RLEPSO: the FDR exemplar (rlepso_optimizer.py:97-109) by cross-multiplied comparison alone.  Default (flag clear): the scan also
+ *                                detects every comparison that comes near a tie and settles those items with the reference's ROUNDED quotients and np.argmin's
+ *                                first-index rule -- the exemplar index is the reference's on any input (tests/test_fdr_ties.py) at +3..5 % of a generation.
+ *   MBX_F_GENERIC_GEOMETRY       keep the run-time-geometry kernels where a compile-time-geometry instantiation exists (the tests compare the two bit for bit)
+ *   MBX_F_ROLLOUT_PER_GENERATION the mbx_*_rollout entry points step one launch per generation instead of the resident kernel (same outputs)
+ * Test override: the environment variables MBX_FDR_FAST=1, MBX_GENERIC_GEOMETRY=1, MBX_ROLLOUT_PER_GENERATION=1 are OR-ed into the flags of every batch
+ * created while they are set (read once, inside mbx_batch_create; never at call time). */
+#define MBX_F_FDR_FAST               1u
+#define MBX_F_GENERIC_GEOMETRY       2u
+#define MBX_F_ROLLOUT_PER_GENERATION 4u
+/* the flags a batch was created with, environment overrides included (negative = MBX_E_*) */
+int mbx_batch_flags(const mbx_batch* b);
 
 /* Dimensions of the per-step tensors for a configuration (so callers can size buffers):
  *   RLEPSO        : state [1]      (fes/maxFEs, rlepso_optimizer.py:170-171), action [35] float32
@@ -153,10 +169,11 @@ int mbx_reset(mbx_batch* b, double* d_state_out, void* stream);
  * [n_instances, action_dim] (float32; int32 for DEDDQN; NULL for RANDOM_SEARCH).  Outputs: next state (float64),
  * reward (float64), done (uint8).  Done instances are left untouched and report reward 0 (their state row keeps
  * its last value).  Workgroups are dispatched most-expensive-objective first.  *
- * RLEPSO, FDR exemplar (src/optimizer/rlepso_optimizer.py:97-109): the reference takes np.argmin of ROUNDED quotients; the kernels order the exact ratios by
- * cross-multiplication, which can resolve differently only when two non-identical candidates have quotients within one ulp of each other (measured:
- * tests/test_fdr_ties.py; ~2e-16 per comparison on continuous data).  A batch created with MBX_FDR_EXACT=1 in the environment runs generation kernels that
- * detect such near-ties and redo them with the reference's divisions: bit-exact exemplars on any input, one launch per generation, ~12 % slower. */
+ * RLEPSO, FDR exemplar (src/optimizer/rlepso_optimizer.py:97-109): the reference takes np.argmin of ROUNDED quotients.  Every RLEPSO kernel -- this one, the
+ * compile-time-geometry instantiations and the resident rollout kernels -- scans by cross-multiplication, flags each comparison that comes within 2^-49 of a
+ * tie and settles the flagged items with the reference's rounded quotients and first-index rule: the exemplar index equals the reference's on every input
+ * whose pbest positions lie inside [lb, ub] (which reset / step guarantee; a block injected with mbx_debug_write_state must keep it).  MBX_F_FDR_FAST in
+ * mbx_algo_cfg.flags drops the flag and the second pass (differs from the reference only where two quotients are <= 1 ulp apart: tests/test_fdr_ties.py). */
 int mbx_step(mbx_batch* b, const void* d_actions, double* d_state_out, double* d_reward_out,
              uint8_t* d_done_out, void* stream);
 
@@ -268,8 +285,8 @@ int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out
  * d_state_out / d_done_out [n_instances]: state / is_done after the last executed generation; d_reward_out [n_instances]: SUM of
  * the rewards of the executed generations (like mbx_rlpso_rollout).
  * The compile-time geometries (NP 100 / D 10, NP 100 / D 12 = protein docking, NP 100 / D 30 and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
- * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 in the environment when the
- * batch is CREATED forces that route).  mbx_rlepso_rollout_resident tells which route a batch takes: 1 = one resident launch per call,
+ * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_F_ROLLOUT_PER_GENERATION in the batch's flags
+ * forces that route).  mbx_rlepso_rollout_resident tells which route a batch takes: 1 = one resident launch per call,
  * 0 = one launch per generation (2 n_gens launches with d_reward_out).  Neither route allocates or reads the environment at call time. */
 int mbx_rlepso_rollout_resident(const mbx_batch* b);
 int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_traj_actions, double* d_traj_state,
@@ -292,7 +309,7 @@ int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_
  * before the call are not written); d_reward_out: SUM of the rewards of the executed generations.
  * The resident kernel is built for config 3's geometries (NP 50 / 100 at D 30, hidden 50) and the objective kinds whose row sums need one
  * array (all of bbob-noisy; bbob without F3, F4, F5, F15, F20, F24); any other batch is stepped with mbx_lde_policy + mbx_step per generation
- * behind the same interface (MBX_ROLLOUT_PER_GENERATION=1 when the batch is created forces that route).  mbx_lde_rollout_resident: 1 / 0. */
+ * behind the same interface (MBX_F_ROLLOUT_PER_GENERATION in the batch's flags forces that route).  mbx_lde_rollout_resident: 1 / 0. */
 int mbx_lde_rollout_resident(const mbx_batch* b);
 int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state_in, float* d_h, float* d_c, int n_gens,
                     float* d_traj_actions, double* d_traj_state, double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out,
@@ -351,6 +368,12 @@ int mbx_batch_launch_info(const mbx_batch* b, int32_t out[4]);
  * launch on its own stream bracket it in the same time base. */
 int mbx_debug_clock_probe(uint64_t* d_out, int n_samples, int sleep_units, void* stream);
 int mbx_debug_clock_mark(uint64_t* d_out2, void* stream);
+/* Measurement: the shader clock a resident RLEPSO launch runs at, measured by the launch ITSELF.  While a slot pair is attached, thread 0 of every workgroup of
+ * k_rlepso_run reads s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end and adds the two differences to d_slots2[0] / d_slots2[1] (the caller
+ * zeroes them): clock [GHz] = d_slots2[0] / d_slots2[1] / 10, averaged over the workgroups' lifetimes -- no cross-CU counter arithmetic (the s_memtime counters of
+ * different XCDs are offset against each other), no probe wave beside the launch, no profiler.  One scalar load per workgroup when nothing is attached.  NULL detaches.
+ * Host-only call, takes effect at the next mbx_rlepso_rollout.  (bench.py: roofline.valu.clock_ghz / shader_cycles_per_generation of the timed windows themselves.) */
+int mbx_debug_clock_slots(mbx_batch* b, uint64_t* d_slots2);
 
 const char* mbx_last_error(void);
 /* "metabox_amd libmbx <major.minor> (gfx950; Philox stream layout <n>: ...)".  The stream layout number changes whenever the assignment of Philox

@@ -30,7 +30,11 @@ class AlgoCfg(C.Structure):
     """mbx_algo_cfg"""
     _fields_ = [('algo', C.c_int32), ('np', C.c_int32), ('dim', C.c_int32), ('max_fes', C.c_int32),
                 ('log_interval', C.c_int32), ('n_logpoint', C.c_int32), ('early_stop', C.c_int32),
-                ('n_group', C.c_int32)]
+                ('n_group', C.c_int32), ('flags', C.c_uint32)]
+
+
+# mbx_algo_cfg.flags (include/mbx.h)
+F_FDR_FAST, F_GENERIC_GEOMETRY, F_ROLLOUT_PER_GENERATION = 1, 2, 4
 
 
 class GaussMlp(C.Structure):
@@ -124,6 +128,7 @@ def load_lib():
         'mbx_batch_create': (C.c_int, [vp, C.POINTER(AlgoCfg), C.POINTER(i32), C.POINTER(u64), C.c_int,
                                        C.POINTER(vp)]),
         'mbx_batch_destroy': (C.c_int, [vp]),
+        'mbx_batch_flags': (C.c_int, [vp]),
         'mbx_set_tape': (C.c_int, [vp, vp]),
         'mbx_reset': (C.c_int, [vp, vp, vp]),
         'mbx_step': (C.c_int, [vp, vp, vp, vp, vp, vp]),
@@ -149,6 +154,7 @@ def load_lib():
         'mbx_debug_write_state': (C.c_int, [vp, C.c_int, c_double_p]),
         'mbx_debug_clock_probe': (C.c_int, [vp, C.c_int, C.c_int, vp]),
         'mbx_debug_clock_mark': (C.c_int, [vp, vp]),
+        'mbx_debug_clock_slots': (C.c_int, [vp, vp]),
         'mbx_batch_rebind': (C.c_int, [vp, vp, vp]),
         'mbx_read_public': (C.c_int, [vp, C.c_int, c_double_p, vp]),
         'mbx_last_error': (C.c_char_p, []),
@@ -163,10 +169,10 @@ def load_lib():
 
 
 EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval',
-                    'mbx_state_dim', 'mbx_action_dim', 'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy',
+                    'mbx_state_dim', 'mbx_action_dim', 'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy', 'mbx_batch_flags',
                     'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results', 'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_ddqn_qnet', 'mbx_rlepso_policy_table_rows',
                     'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlepso_rollout_resident', 'mbx_rlepso_rollout', 'mbx_lde_rollout_resident', 'mbx_lde_rollout', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_debug_math', 'mbx_debug_rlepso_draws', 'mbx_batch_launch_info', 'mbx_instance_state_doubles',
-                    'mbx_debug_read_state', 'mbx_debug_write_state', 'mbx_debug_clock_probe', 'mbx_debug_clock_mark', 'mbx_batch_rebind', 'mbx_read_public', 'mbx_last_error', 'mbx_version')
+                    'mbx_debug_read_state', 'mbx_debug_write_state', 'mbx_debug_clock_probe', 'mbx_debug_clock_mark', 'mbx_debug_clock_slots', 'mbx_batch_rebind', 'mbx_read_public', 'mbx_last_error', 'mbx_version')
 
 
 def check(rc):

@@ -79,13 +79,14 @@ struct mbx_batch {
     double* d_state = nullptr;
     int32_t* d_order = nullptr;
     double* d_pci = nullptr;
+    unsigned long long* d_clk = nullptr;   // mbx_debug_clock_slots: the caller's slot block for the NEXT resident RLEPSO launches (not owned)
     double* d_scratch = nullptr; // [B] per-generation rewards of mbx_rlepso_rollout's host-loop route (RLEPSO batches; allocated by mbx_batch_create)
     float* d_lstm_pack = nullptr;          // k-blocked copy of the PolicyNet weights for k_lde_run (k_lde_repack at every mbx_lde_rollout call)
-    bool fdr_exact = false;                // RLEPSO, MBX_FDR_EXACT=1 when the batch was created: near-ties of the FDR scan resolved with the reference's rounded quotients
-                                           // (run-time-geometry kernels, one launch per generation; include/mbx.h, mbx_step)
+    bool fdr_fast = false;                 // RLEPSO, MBX_F_FDR_FAST honoured: the kernels without the near-tie flag / second pass of the FDR scan (include/mbx.h); cfg.flags holds
+                                           // the EFFECTIVE flags (environment overrides OR-ed in, MBX_F_FDR_FAST cleared where no fast instantiation exists)
     bool rl_run_kinds_ok = false;          // RLEPSO: every problem of the batch is one of the 24 BBOB kinds the per-kind k_rlepso_run geometries have a body for (rl_run_kind_ok)
     bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind k_lde_run builds (lde_run_kind_ok)
-    bool rollout_per_generation = false;   // MBX_ROLLOUT_PER_GENERATION=1 at batch creation: mbx_rlepso_rollout takes the host-loop route (tests)
+    bool rollout_per_generation = false;   // MBX_F_ROLLOUT_PER_GENERATION: the mbx_*_rollout entry points take the host-loop route
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
     size_t lds_bytes = 0;
@@ -107,18 +108,14 @@ static AlgoGeom geom_of(const mbx_algo_cfg& c)
         g.state_doubles = MBX_RLEPSO_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
         g.sc_off = MBX_RLEPSO_ST_SCALARS(c.np, c.dim);
         g.tape_stride = MBX_RLEPSO_TAPE_STRIDE(c.np, c.dim);
-        {   // compile-time geometries that read their maps from global memory need no LDS for them (unless the generic kernels are forced)
-            const char* gg = getenv("MBX_GENERIC_GEOMETRY");
-            const char* fe = getenv("MBX_FDR_EXACT");
-            const bool generic = (gg && gg[0] == '1') || (fe && fe[0] == '1');
-            g.lds_doubles = rl_lds_doubles(c.np, c.dim, generic || c.n_group != 5 || rl_maps_in_lds(c.np, c.dim));
-        }
+        // compile-time geometries that read their maps from global memory need no LDS for them (unless the generic kernels are asked for)
+        g.lds_doubles = rl_lds_doubles(c.np, c.dim, (c.flags & MBX_F_GENERIC_GEOMETRY) || c.n_group != 5 || rl_maps_in_lds(c.np, c.dim));
         g.state_dim = 1; g.action_dim = 7 * c.n_group;
     } else if (c.algo == MBX_ALGO_LDE) {
         g.state_doubles = MBX_LDE_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
         g.sc_off = MBX_LDE_ST_SCALARS(c.np, c.dim);
         g.tape_stride = MBX_LDE_TAPE_STRIDE(c.np, c.dim);
-        g.lds_doubles = lde_lds_doubles(c.np, c.dim, lde_maps_in_lds(c.np, c.dim) || (getenv("MBX_GENERIC_GEOMETRY") && getenv("MBX_GENERIC_GEOMETRY")[0] == '1'));
+        g.lds_doubles = lde_lds_doubles(c.np, c.dim, lde_maps_in_lds(c.np, c.dim) || (c.flags & MBX_F_GENERIC_GEOMETRY));
         g.state_dim = c.np + 2 * MBX_LDE_BINS; g.action_dim = 2 * c.np;
     } else if (c.algo == MBX_ALGO_DEDDQN) {
         g.state_doubles = MBX_DQ_STATE_DOUBLES(c.np, c.dim, c.n_logpoint);
@@ -448,6 +445,7 @@ static int check_cfg(const mbx_algo_cfg* c)
     if (c->algo == MBX_ALGO_RLEPSO && (c->n_group < 1 || c->n_group > 16 || c->np / c->n_group < 1))
         return fail(MBX_E_ARG, "bad n_group %d", c->n_group);
     if (c->max_fes <= 0 || c->log_interval <= 0 || c->n_logpoint <= 0) return fail(MBX_E_ARG, "bad budget/log settings");
+    if (c->flags & ~(MBX_F_FDR_FAST | MBX_F_GENERIC_GEOMETRY | MBX_F_ROLLOUT_PER_GENERATION)) return fail(MBX_E_ARG, "unknown bits in cfg.flags 0x%x", c->flags);
     return MBX_OK;
 }
 
@@ -521,11 +519,22 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     return MBX_OK;
 }
 
-extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int32_t* problem_idx, const uint64_t* seeds,
+// the environment's test overrides of mbx_algo_cfg.flags (include/mbx.h): read here, once per batch, and nowhere else
+static uint32_t env_flags()
+{
+    auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+    return (on("MBX_FDR_FAST") ? MBX_F_FDR_FAST : 0u) | (on("MBX_GENERIC_GEOMETRY") ? MBX_F_GENERIC_GEOMETRY : 0u) |
+           (on("MBX_ROLLOUT_PER_GENERATION") ? MBX_F_ROLLOUT_PER_GENERATION : 0u);
+}
+
+extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg_in, const int32_t* problem_idx, const uint64_t* seeds,
                                 int n_instances, mbx_batch** out)
 {
     if (!s || !problem_idx || !seeds || n_instances <= 0 || !out) return fail(MBX_E_ARG, "mbx_batch_create: bad arguments");
-    if (int rc = check_cfg(cfg)) return rc;
+    if (int rc = check_cfg(cfg_in)) return rc;
+    mbx_algo_cfg effective = *cfg_in;
+    effective.flags |= env_flags();
+    const mbx_algo_cfg* cfg = &effective;
     if (cfg->dim != s->dim) return fail(MBX_E_ARG, "cfg.dim %d != suite dim %d", cfg->dim, s->dim);
     for (int i = 0; i < n_instances; ++i)
         if (problem_idx[i] < 0 || problem_idx[i] >= s->n) return fail(MBX_E_ARG, "problem_idx[%d]=%d out of range", i, problem_idx[i]);
@@ -540,24 +549,27 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
     // evaluator's per-wave scratch inside its T region).
     if (cfg->algo == MBX_ALGO_LDE && (size_t)lde_lds_doubles(cfg->np, cfg->dim, true) * sizeof(double) > 40 * 1024 && cfg->dim >= 16) b->threads = 512;   // objective-bound at D = 30: 8 waves per workgroup, -21 %
     if (cfg->algo == MBX_ALGO_RLEPSO && (size_t)rl_lds_doubles(cfg->np, cfg->dim, true) * sizeof(double) > 80 * 1024 && cfg->dim >= 16) b->threads = cfg->dim >= 32 ? 1024 : 512;   // per-wave evaluator scratch needs D >= 2 x waves
-    // MBX_GENERIC_GEOMETRY=1 keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
+    // MBX_F_GENERIC_GEOMETRY keeps the run-time-geometry kernel (the tests compare the two instantiations bit for bit)
     {
-        const char* g = getenv("MBX_GENERIC_GEOMETRY");
-        const char* fe = getenv("MBX_FDR_EXACT");
-        b->fdr_exact = cfg->algo == MBX_ALGO_RLEPSO && fe && fe[0] == '1';
-        if (cfg->algo == MBX_ALGO_RLEPSO && cfg->n_group == 5 && !(g && g[0] == '1') && !b->fdr_exact) {
+        const bool generic = (cfg->flags & MBX_F_GENERIC_GEOMETRY) != 0;
+        if (cfg->algo == MBX_ALGO_RLEPSO && cfg->n_group == 5 && !generic) {
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 10) b->fixed_geometry = 1;
             if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
             if (b->threads == 512 && cfg->np == 100 && cfg->dim == 30) b->fixed_geometry = 7;
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 12) b->fixed_geometry = 8;     // protein docking: resident rollout only, the one-generation kernel stays the run-time-geometry one
         }
+        // the fast FDR scan exists for the run-time-geometry kernels and the geometries of BASELINE configs 2 / 5; the other compile-time geometries keep the exact scan on
+        // BOTH routes (so that the two stay bit-identical), and the batch's effective flags say so
+        if (cfg->algo != MBX_ALGO_RLEPSO || b->fixed_geometry == 7 || b->fixed_geometry == 8) b->cfg.flags &= ~MBX_F_FDR_FAST;
+        b->fdr_fast = (b->cfg.flags & MBX_F_FDR_FAST) != 0;
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
-        if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 3;
-        if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 100 && cfg->dim == 30 && !(g && g[0] == '1')) b->fixed_geometry = 6;
+        if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !generic) b->fixed_geometry = 3;
+        if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 100 && cfg->dim == 30 && !generic) b->fixed_geometry = 6;
         // the reference's own LDE setting (lde_optimizer.py:10 NP = 50, bbob --dim 10): resident rollout only, the one-generation kernel stays the run-time-geometry one
-        if (cfg->algo == MBX_ALGO_LDE && b->threads == kThreads && cfg->np == 50 && cfg->dim == 10 && !(g && g[0] == '1')) b->fixed_geometry = 9;
-        if (cfg->algo == MBX_ALGO_DEDDQN && cfg->np == 100 && cfg->dim == 12 && !(g && g[0] == '1')) b->fixed_geometry = 4;
-        if (cfg->algo == MBX_ALGO_GLEET && cfg->np == 100 && cfg->dim == 10 && !(g && g[0] == '1')) b->fixed_geometry = 5;
+        if (cfg->algo == MBX_ALGO_LDE && b->threads == kThreads && cfg->np == 50 && cfg->dim == 10 && !generic) b->fixed_geometry = 9;
+        if (cfg->algo == MBX_ALGO_DEDDQN && cfg->np == 100 && cfg->dim == 12 && !generic) b->fixed_geometry = 4;
+        if (cfg->algo == MBX_ALGO_GLEET && cfg->np == 100 && cfg->dim == 10 && !generic) b->fixed_geometry = 5;
+        b->rollout_per_generation = (cfg->flags & MBX_F_ROLLOUT_PER_GENERATION) != 0;
     }
 #ifdef MBX_LDS_PAD_EXPERIMENT
     if (const char* e = getenv("MBX_LDS_PAD")) b->lds_bytes += (size_t)atoi(e);      // occupancy experiments only
@@ -582,31 +594,22 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg, const int
         HIP_TRY(hipMemcpy(b->d_pci, pci.data(), cfg->np * sizeof(double), hipMemcpyHostToDevice));
         // mbx_rlepso_rollout never allocates or reads the environment (it may run under stream capture): both happen here
         HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * sizeof(double)));
-        const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");
-        b->rollout_per_generation = (per_gen && per_gen[0] == '1') || b->fdr_exact;
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<kThreads, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<1024, 128, 40, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<512, 100, 30, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_run<256, 100, 12, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512, 100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_reset<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rlepso_step<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define MBX_RL_LDS(...) HIP_TRY(hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+        MBX_RL_LDS(k_rlepso_reset<kThreads>); MBX_RL_LDS(k_rlepso_reset<512>); MBX_RL_LDS(k_rlepso_reset<1024>); MBX_RL_LDS(k_rlepso_reset<512, 100, 30>);
+        // generation kernels: run-time geometry and the geometries of BASELINE configs 2 / 5 in both FDR forms, bbob --dim 30 exact only
+        MBX_RL_LDS(k_rlepso_step<kThreads, 0, 0, 0, true>); MBX_RL_LDS(k_rlepso_step<512, 0, 0, 0, true>); MBX_RL_LDS(k_rlepso_step<1024, 0, 0, 0, true>);
+        MBX_RL_LDS(k_rlepso_step<kThreads, 0, 0, 0, false>); MBX_RL_LDS(k_rlepso_step<512, 0, 0, 0, false>); MBX_RL_LDS(k_rlepso_step<1024, 0, 0, 0, false>);
+        MBX_RL_LDS(k_rlepso_step<kThreads, 100, 10, 5, true>); MBX_RL_LDS(k_rlepso_step<kThreads, 100, 10, 5, false>);
+        MBX_RL_LDS(k_rlepso_step<1024, 128, 40, 5, true>); MBX_RL_LDS(k_rlepso_step<1024, 128, 40, 5, false>);
+        MBX_RL_LDS(k_rlepso_step<512, 100, 30, 5, true>);
+        MBX_RL_LDS(k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5, true>); MBX_RL_LDS(k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5, false>);
+        MBX_RL_LDS(k_rlepso_run<1024, 128, 40, 5, true>); MBX_RL_LDS(k_rlepso_run<1024, 128, 40, 5, false>);
+        MBX_RL_LDS(k_rlepso_run<512, 100, 30, 5, true>); MBX_RL_LDS(k_rlepso_run<256, 100, 12, 5, true>);
+#undef MBX_RL_LDS
     } else if (cfg->algo == MBX_ALGO_LDE) {
-        {   // mbx_lde_rollout: per-generation rewards / actions of the host-loop route, route flag (read here, never at call time)
+        {   // mbx_lde_rollout: per-generation rewards / actions of the host-loop route
             HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * (sizeof(double) + (size_t)g.action_dim * sizeof(float))));
-            const char* per_gen = getenv("MBX_ROLLOUT_PER_GENERATION");
-            b->rollout_per_generation = per_gen && per_gen[0] == '1';
             HIP_TRY(hipMalloc(&b->d_lstm_pack, (size_t)lde_run_pack_floats(g.state_dim, 64, g.action_dim) * sizeof(float)));      // hidden <= 64
             HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(100, 30, 50) * sizeof(double))));
             HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50) * sizeof(double))));
@@ -695,6 +698,7 @@ static BatchParams make_params(const mbx_batch* b)
     p.NP = b->cfg.np; p.D = b->cfg.dim; p.max_fes = b->cfg.max_fes; p.log_interval = b->cfg.log_interval;
     p.n_logpoint = b->cfg.n_logpoint; p.early_stop = b->cfg.early_stop; p.n_group = b->cfg.n_group; p.B = b->B;
     p.sc_off = b->sc_off;
+    p.clk = b->d_clk;
     return p;
 }
 
@@ -706,17 +710,13 @@ static void launch_rlepso_step(mbx_batch* b, hipStream_t stream, const float* d_
 #define MBX_RLEPSO_LAUNCH(...)                                                                                                   \
     hipLaunchKernelGGL((k_rlepso_step<__VA_ARGS__>), dim3(b->B), dim3(b->threads), b->lds_bytes, stream, make_params(b), d_actions, \
                        d_state_out, d_reward_out, d_done_out, d_table, table_rows, d_actions_out)
-    if (b->fdr_exact) {
-        if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024, 0, 0, 0, true);
-        else if (b->threads == 512) MBX_RLEPSO_LAUNCH(512, 0, 0, 0, true);
-        else MBX_RLEPSO_LAUNCH(kThreads, 0, 0, 0, true);
-    }
-    else if (b->fixed_geometry == 1) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5);
-    else if (b->fixed_geometry == 2) MBX_RLEPSO_LAUNCH(1024, 128, 40, 5);
-    else if (b->fixed_geometry == 7) MBX_RLEPSO_LAUNCH(512, 100, 30, 5);
-    else if (b->threads == 1024) MBX_RLEPSO_LAUNCH(1024);
-    else if (b->threads == 512) MBX_RLEPSO_LAUNCH(512);
-    else MBX_RLEPSO_LAUNCH(kThreads);
+    const bool fast = b->fdr_fast;
+    if (b->fixed_geometry == 1) { if (fast) MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5, false); else MBX_RLEPSO_LAUNCH(kThreads, 100, 10, 5, true); }
+    else if (b->fixed_geometry == 2) { if (fast) MBX_RLEPSO_LAUNCH(1024, 128, 40, 5, false); else MBX_RLEPSO_LAUNCH(1024, 128, 40, 5, true); }
+    else if (b->fixed_geometry == 7) MBX_RLEPSO_LAUNCH(512, 100, 30, 5, true);
+    else if (b->threads == 1024) { if (fast) MBX_RLEPSO_LAUNCH(1024, 0, 0, 0, false); else MBX_RLEPSO_LAUNCH(1024, 0, 0, 0, true); }
+    else if (b->threads == 512) { if (fast) MBX_RLEPSO_LAUNCH(512, 0, 0, 0, false); else MBX_RLEPSO_LAUNCH(512, 0, 0, 0, true); }
+    else { if (fast) MBX_RLEPSO_LAUNCH(kThreads, 0, 0, 0, false); else MBX_RLEPSO_LAUNCH(kThreads, 0, 0, 0, true); }
 #undef MBX_RLEPSO_LAUNCH
 }
 
@@ -932,11 +932,16 @@ extern "C" int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_
     return MBX_OK;
 }
 
+extern "C" int mbx_batch_flags(const mbx_batch* b)
+{
+    if (!b) return fail(MBX_E_ARG, "mbx_batch_flags: null batch");
+    return (int)b->cfg.flags;
+}
+
 extern "C" int mbx_rlepso_rollout_resident(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "mbx_rlepso_rollout_resident: null batch");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return 0;
-    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !b->rl_run_kinds_ok) return 0;
     return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7 || b->fixed_geometry == 8) && !b->rollout_per_generation ? 1 : 0;
 }
 
@@ -946,24 +951,17 @@ __global__ void k_sum_rewards(double* __restrict__ acc, const double* __restrict
     if (i < n) acc[i] = first ? r[i] : acc[i] + r[i];
 }
 
-// The ONE launch site of k_rlepso_run.  The D = 10 / D = 40 instantiations dispatch to one out-of-line body per function kind and trap on a kind without a
-// body (csrc/mbx_rlepso.hpp), which would take the whole GPU context down: the check that keeps such batches away lives here, next to the launch, not only in
-// the mbx_rlepso_rollout_resident query.
+// The ONE launch site of k_rlepso_run (the D = 10 / D = 40 instantiations dispatch to one out-of-line body per function kind and run the any-kind body for a
+// (kind, noise model) pair without one).
 static int launch_rlepso_run(mbx_batch* b, const float* d_table, int rows, int n_gens, const RunOut& out, hipStream_t stream)
 {
-    if ((b->fixed_geometry == 1 || b->fixed_geometry == 2) && !b->rl_run_kinds_ok)
-        return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: the batch holds a function kind the resident kernel has no body for");
-    if (b->fixed_geometry == 1)
-        hipLaunchKernelGGL((k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5>), dim3(b->B), dim3(MBX_RUN10_THREADS), b->lds_bytes, stream,
-                           make_params(b), d_table, rows, n_gens, out);
-    else if (b->fixed_geometry == 7)
-        hipLaunchKernelGGL((k_rlepso_run<512, 100, 30, 5>), dim3(b->B), dim3(512), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
-    else if (b->fixed_geometry == 2)
-        hipLaunchKernelGGL((k_rlepso_run<1024, 128, 40, 5>), dim3(b->B), dim3(1024), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
-    else if (b->fixed_geometry == 8)
-        hipLaunchKernelGGL((k_rlepso_run<256, 100, 12, 5>), dim3(b->B), dim3(256), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out);
-    else
-        return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: no instantiation for this geometry");
+#define MBX_RUN_LAUNCH(T, ...) hipLaunchKernelGGL((k_rlepso_run<T, __VA_ARGS__>), dim3(b->B), dim3(T), b->lds_bytes, stream, make_params(b), d_table, rows, n_gens, out)
+    if (b->fixed_geometry == 1) { if (b->fdr_fast) MBX_RUN_LAUNCH(MBX_RUN10_THREADS, 100, 10, 5, false); else MBX_RUN_LAUNCH(MBX_RUN10_THREADS, 100, 10, 5, true); }
+    else if (b->fixed_geometry == 2) { if (b->fdr_fast) MBX_RUN_LAUNCH(1024, 128, 40, 5, false); else MBX_RUN_LAUNCH(1024, 128, 40, 5, true); }
+    else if (b->fixed_geometry == 7) MBX_RUN_LAUNCH(512, 100, 30, 5, true);
+    else if (b->fixed_geometry == 8) MBX_RUN_LAUNCH(256, 100, 12, 5, true);
+    else return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: no instantiation for this geometry");
+#undef MBX_RUN_LAUNCH
     HIP_TRY(hipGetLastError());
     return MBX_OK;
 }
@@ -1198,6 +1196,13 @@ extern "C" int mbx_debug_clock_mark(uint64_t* d_out2, void* stream)
     if (!d_out2) return fail(MBX_E_ARG, "mbx_debug_clock_mark: bad arguments");
     hipLaunchKernelGGL(k_clock_mark, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out2);
     HIP_TRY(hipGetLastError());
+    return MBX_OK;
+}
+
+extern "C" int mbx_debug_clock_slots(mbx_batch* b, uint64_t* d_slots2)
+{
+    if (!b) return fail(MBX_E_ARG, "mbx_debug_clock_slots: null batch");
+    b->d_clk = (unsigned long long*)d_slots2;
     return MBX_OK;
 }
 

@@ -24,6 +24,8 @@ struct BatchParams {
     const double* pci;           // [NP] RLEPSO learning-probability curve pci_i (rlepso_optimizer.py:23-24), computed at batch creation
     int32_t NP, D, max_fes, log_interval, n_logpoint, early_stop, n_group, B;
     int64_t sc_off;              // offset of the scalar block inside an instance's state (per algorithm)
+    unsigned long long* clk;     // nullptr, or 2 words {sum of shader cycles (s_memtime), sum of 100 MHz ticks (s_memrealtime)} over the lifetimes of the resident RLEPSO kernel's
+                                 // workgroups (mbx_debug_clock_slots; bench.py prices the kernel's vector-issue bound at the clock its own waves saw)
 };
 
 // optimizer.cost bookkeeping shared by every update() of the reference (e.g. rlepso_optimizer.py:241-261): append gbest when fes
@@ -50,6 +52,9 @@ struct RlLds {
     // KB (NE bytes): rank of the FDR exemplar of every (rank, dimension), carved out of the part of Z that R1 / R2 / COEF leave free
     // (all dead before the evaluator first writes Z)
     uint8_t* KB;
+    // NCS [NP]: the cost column the FDR scan reads -- NC with the rows that are bitwise copies of the row one rank up (same cost, same position: particles sitting on
+    // the same corner of the box) replaced by a huge value, so that the scan never takes them and never mistakes them for near-ties (rl_mark_copies); same free part of Z
+    double* NCS;
     __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
 };
 
@@ -58,11 +63,11 @@ __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_
 // doubles of the move phase's byte table inside Z: KB (NE bytes)
 __host__ __device__ inline int64_t rl_aux_doubles(int NP, int D) { return ((int64_t)NP * D + 15) / 16 * 2; }
 
-// evaluator scratch Z: n*D doubles, at least 2 per thread for the block reductions, and room for the move phase's R1 | R2 | COEF | tables
+// evaluator scratch Z: n*D doubles, at least 2 per thread for the block reductions, and room for the move phase's R1 | R2 | COEF | NCS | tables
 __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
 {
     const int64_t NE = align2((int64_t)NP * D);
-    int64_t need = 2 * align2(NP) + 96 + rl_aux_doubles(NP, D);
+    int64_t need = 3 * align2(NP) + 96 + rl_aux_doubles(NP, D);
     if (need < 2 * kThreads) need = 2 * kThreads;
     return align2(NE > need ? NE : need);
 }
@@ -103,7 +108,8 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D, bool maps
     L.X = p; p += NE;
     L.Z = p;
     L.R1 = p; L.R2 = p + P; L.COEF = p + 2 * P;   // per-particle draws and group coefficients: last read in the move phase, Z first written by the evaluator
-    L.KB = (uint8_t*)(p + 2 * P + 96);
+    L.NCS = p + 2 * P + 96;
+    L.KB = (uint8_t*)(p + 3 * P + 96);
     p += SC;
     L.M1T = p; p += DD;
     L.M2T = p; p += DD;
@@ -236,11 +242,8 @@ __device__ __forceinline__ void fdr_take(double lhs, double rhs, double& ab, dou
 #endif
 }
 
-// ---- exact resolution of near-ties in the FDR scan (fdr_exact<.., TIE = true>: the kernels of a batch created with MBX_FDR_EXACT=1 in the environment;
-// -DMBX_FDR_TIEFLAG=1 turns it on in every kernel, for the A/B of its cost) ---------------------------------------------------------
-#ifndef MBX_FDR_TIEFLAG
-#define MBX_FDR_TIEFLAG 0
-#endif
+// ---- exact resolution of near-ties in the FDR scan (fdr_exact<.., TIE = true>: the DEFAULT of every RLEPSO kernel; TIE = false is the batch option
+// MBX_F_FDR_FAST of include/mbx.h) -------------------------------------------------------------------------------------------------
 // if (dif < 0) { ab = a; bb = b; kb = k; }: fdr_take on the SIGN of dif = a_j b* - fl(a* b_j) (one fma instead of the second product: same instruction count)
 __device__ __forceinline__ void fdr_take_neg(double dif, double& ab, double& bb, int& kb, double a, double b, int k)
 {
@@ -255,6 +258,27 @@ __device__ __forceinline__ void fdr_take_neg(double dif, double& ab, double& bb,
         : [d] "v"(dif), [a] "v"(a), [b] "v"(b), [k] "s"(k)
         : "vcc");
 }
+// the two coordinates of a work item in ONE block: both differences are complete before the first compare issues, so neither compare waits on the
+// instruction right in front of it
+__device__ __forceinline__ void fdr_take_neg2(double dif0, double dif1, double& ab0, double& bb0, int& kb0, double& ab1, double& bb1, int& kb1,
+                                              double a, double b0, double b1, int k)
+{
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_f64_e32 0, %[d0]\n\t"
+        "v_mov_b64 %[ab0], %[a]\n\t"
+        "v_mov_b64 %[bb0], %[b0]\n\t"
+        "v_mov_b32 %[kb0], %[k]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f64_e32 0, %[d1]\n\t"
+        "v_mov_b64 %[ab1], %[a]\n\t"
+        "v_mov_b64 %[bb1], %[b1]\n\t"
+        "v_mov_b32 %[kb1], %[k]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [ab0] "+v"(ab0), [bb0] "+v"(bb0), [kb0] "+v"(kb0), [ab1] "+v"(ab1), [bb1] "+v"(bb1), [kb1] "+v"(kb1), [sv] "=&s"(saved)
+        : [d0] "v"(dif0), [d1] "v"(dif1), [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1), [k] "s"(k)
+        : "vcc");
+}
 // running minimum of |dif| over the pairs of a scan, kept on the HIGH dwords read as float32 (sign | exponent | 20 mantissa bits of a float64 are monotone in
 // the float32 order for finite values): ONE v_min3_f32 covers the two coordinates of a work item
 __device__ __forceinline__ float f64_hi_as_f32(double v) { return __int_as_float(__double2hiint(v)); }
@@ -264,19 +288,65 @@ __device__ __forceinline__ float fdr_min3_abs(float m, float x, float y)
     asm("v_min3_f32 %[r], %[m], |%[x]|, |%[y]|" : [r] "=v"(r) : [m] "v"(m), [x] "v"(x), [y] "v"(y));
     return r;
 }
-// The reference's own evaluation for ONE coordinate (rlepso_optimizer.py:100-102): rounded quotients, np.argmin = the first minimal one in PARTICLE order.
-// Only the strictly better particles (ranks < nless) can hold the minimum when there is one; ranks are (cost, index)-ordered, so the particle index is looked up.
-__device__ __noinline__ int fdr_by_division(const double* NC, const double* PB, const int* ORDER, int D, int rk, int d, int nless)
+// A coordinate of an item whose scan met a near-tie (fdr_exact returned true) is settled by its WAVE, lane = candidate: the reference's own rule (rlepso_optimizer.py:
+// 100-102: rounded quotients, np.argmin = the first minimal one in PARTICLE order) applied to the scan's winner w and to every candidate that is not CLEARLY worse than w.
+//  * dif_k = fma(a_k, b_w, -fl(a_w b_k)) > 2^-49 |a_w b_k| means the exact ratios differ by > 2^-49.2 relative, i.e. the rounded quotient of k is strictly
+//    larger than w's: k cannot be the argmin (one pass over the candidates, 64 per step, no division);
+//  * candidates bitwise identical to w (same cost, same coordinate: collapsed swarms, coordinates clipped onto a bound) share w's quotient; ranks are (cost, index)-ordered,
+//    so the lowest RANK among w and its copies is np.argmin's lowest index -- no division either (the scan's fma may have taken a later copy: its rounding error has a sign);
+//  * only if a DIFFERENT candidate is within the band -- a true near-tie, or one clearly better than w, should an earlier near-tie have misled the scan -- the contenders
+//    compete with their rounded quotients, lowest particle index among equal ones (ORDER maps ranks to particle indices).
+// Exact by construction.  All arguments are wave-uniform, all 64 lanes are active; returns the exemplar's rank (uniform).  Measured on whole episodes of the 24 functions:
+// 0.02-0.15 % of the items are flagged, late in an episode up to 0.5 % (Gallagher); every lane redoing its own flagged item would stall the 64 lanes of each wave that holds
+// one (6.7 % of the wave-passes at 0.1 %) for a second scan, this form costs the wave ~200 instructions per flagged coordinate.
+__device__ __forceinline__ int fdr_settle(const RlLds& L, const int* __restrict__ ORDER, int D, int rk, int d, int nless, int kw, unsigned long long* cnt = nullptr)
 {
-    const double fi = NC[rk], pp = PB[rk * D + d];
-    double qb = (NC[0] - fi) / (fabs(PB[d] - pp) + 1e-5);
-    int kb = 0, ib = ORDER[0];
-    for (int k = 1; k < nless; ++k) {
-        const double qk = (NC[k] - fi) / (fabs(PB[k * D + d] - pp) + 1e-5);
-        const int ik = ORDER[k];
-        if (qk < qb || (qk == qb && ik < ib)) { qb = qk; kb = k; ib = ik; }
+    const int lane = threadIdx.x & 63;
+    const double fi = L.NC[rk];
+    const double pp = L.PB[rk * D + d];
+    const double aw = L.NC[kw] - fi, bw = fabs(L.PB[kw * D + d] - pp) + 1e-5;
+    int first_copy = 0x7fffffff;
+    bool others = false;
+    for (int k0 = 0; k0 < nless; k0 += 64) {
+        const int k = k0 + lane;
+        bool band = false, copy = false;
+        if (k < nless && k != kw) {
+            const double a = L.NC[k] - fi, b = fabs(L.PB[k * D + d] - pp) + 1e-5, pr = aw * b;
+            band = __builtin_fma(a, bw, -pr) <= pr * -0x1p-49;      // (pr < 0: the band is 2^-49 |a_w b_k|, the product at hand -- tighter than the scan's flag)
+            copy = band && a == aw && b == bw;
+        }
+        const unsigned long long mc = __builtin_amdgcn_ballot_w64(copy), mo = __builtin_amdgcn_ballot_w64(band && !copy);
+        if (mc != 0ull && first_copy == 0x7fffffff) first_copy = k0 + (int)__builtin_ctzll(mc);
+        others = others || mo != 0ull;
     }
-    return kb;
+    int kbest = kw < first_copy ? kw : first_copy;
+#ifdef MBX_FDR_COUNT
+    if (cnt && lane == 0) atomicAdd(cnt + (others ? 5 : first_copy != 0x7fffffff ? 4 : 6), 1ull);     // experiment: what the flagged coordinates turn out to be
+#endif
+    if (others) {                                             // wave-uniform, rare: a different candidate within (or below) the band
+        double qb = aw / bw;
+        int ib = ORDER[kbest];
+        for (int k0 = 0; k0 < nless; k0 += 64) {
+            const int k = k0 + lane;
+            bool cont = false;
+            double qk = 0.;
+            int ik = 0;
+            if (k < nless && k != kw) {
+                const double a = L.NC[k] - fi, b = fabs(L.PB[k * D + d] - pp) + 1e-5, pr = aw * b;
+                cont = __builtin_fma(a, bw, -pr) <= pr * -0x1p-49 && !(a == aw && b == bw);
+                if (cont) { qk = a / b; ik = ORDER[k]; }
+            }
+            unsigned long long m = __builtin_amdgcn_ballot_w64(cont);
+            while (m != 0ull) {
+                const int l = (int)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const double ql = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(qk), l), __builtin_amdgcn_readlane(__double2loint(qk), l));
+                const int il = __builtin_amdgcn_readlane(ik, l);
+                if (ql < qb || (ql == qb && il < ib)) { qb = ql; ib = il; kbest = k0 + l; }
+            }
+        }
+    }
+    return kbest;
 }
 
 // ---- FDR exemplar (rlepso_optimizer.py:97-109): argmin_j (pbest_j - pbest_i)/(|p_jd - p_id| + 1e-5), first minimum.
@@ -285,74 +355,69 @@ __device__ __noinline__ int fdr_by_division(const double* NC, const double* PB, 
 //    returns the lowest index with pbest_j == pbest_i.  Only the `nless` better particles are scanned, in
 //    ascending-cost order (ORDER / NC), halving the O(NP^2 D) work on average.
 //  * ratios are compared by cross-multiplication (denominators >= 1e-5 > 0): a_j/b_j < a*/b* <=> a_j b* < a* b_j.
-//    Identical candidates (same pbest cost and same coordinate) are adjacent in the (cost, index) order, so the
-//    strict `<` keeps the lower index like np.argmin.  Only ratios that agree to the last bit between
-//    NON-identical candidates (probability ~2^-52 per comparison) could resolve differently from the reference.
-// Exact float64 scan for W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk; returns the exemplar's rank per coordinate.
+//    The reference compares ROUNDED quotients; the two orders can differ only where two candidates' quotients are within an ulp or two of each other
+//    (tests/test_fdr_ties.py: 49 % / 9 % of crafted pairs 0 / 1 ulp apart resolve differently by cross-multiplication alone).
+//  * TIE = true (default): every comparison also yields dif = a_j b* - fl(a* b_j); while |dif| > 8 ulp of the products both forms decide alike (a quotient pair
+//    that rounds together or apart differs by <= 1 ulp, i.e. |a_j b* - a* b_j| <= 2^-52 |a* b_j|).  The scan keeps min |dif| (high dwords, one v_min3_f32 per
+//    two coordinates and candidate) and reports whether it came within 2^-49 x the largest product an item can form, |a_0| x range; the caller then runs
+//    fdr_settle on the item.  Bit-exact exemplars on any input whose pbest positions lie inside the box (|p_jd - p_id| <= ub - lb).
+//  * TIE = false (MBX_F_FDR_FAST): the cross-multiplied order alone, two products and a compare; identical candidates (same pbest cost and same coordinate)
+//    are adjacent in the (cost, index) order, so the strict `<` keeps the lower index like np.argmin.
+// Exact float64 scan for W adjacent coordinates d0 .. d0+W-1 of the particle of pbest-rank rk; the exemplar's rank per coordinate goes to kb; returns the near-tie flag.
+// The candidates' costs are read from NCS (= NC but for the rows rl_mark_copies took out of the scan).
 // UN: candidates per unrolled group (MBX_FDR_UNROLL = 4 everywhere but config 5's resident kernel: 1024 threads, D = 40: 2 / 4 / 8 -> 1.619 / 1.641 / 1.703 ms per
 // generation; the headline kernel: 2 / 3 / 4 / 6 / 8 -> 119.9 / 117.1 / 116.5 / 117.5 / 121.6 us)
 // range: an upper bound of |p_jd - p_id| + 1e-5 (ub - lb + 1e-5), used by the near-tie flag only
-template <int W, int UN = MBX_FDR_UNROLL, bool TIE = false>
-__device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W], double range = 0.)
+template <int W, int UN = MBX_FDR_UNROLL, bool TIE = true>
+__device__ __forceinline__ bool fdr_exact(const RlLds& L, int D, int rk, int d0, int nless, int kb[W], double range = 0.)
 {
 #pragma unroll
     for (int q = 0; q < W; ++q) kb[q] = nless;                   // rank of the exemplar when nobody is strictly better
-    if (nless <= 0) return;
+    if (nless <= 0) return false;
     const double fi = L.NC[rk];
     double pp[W], ab[W], bb[W];
     const double a0 = L.NC[0] - fi;
 #pragma unroll
     for (int q = 0; q < W; ++q) { pp[q] = L.PB[rk * D + d0 + q]; kb[q] = 0; ab[q] = a0; bb[q] = fabs(L.PB[d0 + q] - pp[q]) + 1e-5; }
     const double* col = L.PB + d0;
-    if constexpr (TIE || MBX_FDR_TIEFLAG) {
-    // Cross-multiplication orders the EXACT ratios; the reference rounds the quotients first (see tests/test_fdr_ties.py: 49 % / 9 % of crafted pairs 0 / 1 ulp
-    // apart resolve differently).  Every comparison also yields dif = a_j b* - fl(a* b_j); while |dif| > 8 ulp of the products, both forms decide alike (a
-    // quotient pair that rounds together or apart differs by <= 1 ulp, i.e. |a_j b* - a* b_j| <= 2^-52 |a* b_j|).  The scan keeps min |dif| (high dwords, one
-    // v_min3_f32 per two coordinates and candidate) and, at the end, compares it with 2^-49 x the largest product an item can form, |a_0| x range:
-    // an item that ever came that close is redone the reference's way (fdr_by_division) -- exact by construction, and rare (a near-tie needs two candidates
-    // with quotients 2^-49 apart; identical candidates -- collapsed swarms -- take this path too).
+    if constexpr (TIE) {
     float tiem = __int_as_float(0x7f000000);
+    // one candidate against the running best of the W coordinates: the W differences are complete before the first compare issues (fdr_take_neg2)
+    auto step = [&](double au, const double (&x)[W], int k) {
+        double b[W], difv[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) b[q] = fabs(x[q] - pp[q]) + 1e-5;
+#pragma unroll
+        for (int q = 0; q < W; ++q) difv[q] = ab[q] * b[q];
+#pragma unroll
+        for (int q = 0; q < W; ++q) difv[q] = __builtin_fma(au, bb[q], -difv[q]);
+        if constexpr (W == 2) fdr_take_neg2(difv[0], difv[1], ab[0], bb[0], kb[0], ab[1], bb[1], kb[1], au, b[0], b[1], k);
+        else {
+#pragma unroll
+            for (int q = 0; q < W; ++q) fdr_take_neg(difv[q], ab[q], bb[q], kb[q], au, b[q], k);
+        }
+        tiem = fdr_min3_abs(tiem, f64_hi_as_f32(difv[0]), f64_hi_as_f32(difv[W - 1]));
+    };
     int k = 1;
     for (; k + UN <= nless; k += UN) {
         double a[UN], x[UN][W];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            a[u] = L.NC[k + u];
+            a[u] = L.NCS[k + u];
 #pragma unroll
             for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const double au = a[u] - fi;
-            double difv[W];
-#pragma unroll
-            for (int q = 0; q < W; ++q) {
-                const double b = fabs(x[u][q] - pp[q]) + 1e-5;
-                difv[q] = __builtin_fma(au, bb[q], -(ab[q] * b));
-                fdr_take_neg(difv[q], ab[q], bb[q], kb[q], au, b, k + u);
-            }
-            tiem = fdr_min3_abs(tiem, f64_hi_as_f32(difv[0]), f64_hi_as_f32(difv[W - 1]));
-        }
+        for (int u = 0; u < UN; ++u) step(a[u] - fi, x[u], k + u);
     }
     for (; k < nless; ++k) {
-        const double au = L.NC[k] - fi;
-        double difv[W];
+        double x[W];
 #pragma unroll
-        for (int q = 0; q < W; ++q) {
-            const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
-            difv[q] = __builtin_fma(au, bb[q], -(ab[q] * b));
-            fdr_take_neg(difv[q], ab[q], bb[q], kb[q], au, b, k);
-        }
-        tiem = fdr_min3_abs(tiem, f64_hi_as_f32(difv[0]), f64_hi_as_f32(difv[W - 1]));
+        for (int q = 0; q < W; ++q) x[q] = col[k * D + q];
+        step(L.NCS[k] - fi, x, k);
     }
-    {
-        const double thr = fabs(a0) * range * 0x1p-49;               // |a* b_j| <= |a_0| x range for every pair of the item
-        if (!(tiem > f64_hi_as_f32(thr) * 1.0000005f)) {
-#pragma unroll
-            for (int q = 0; q < W; ++q) kb[q] = fdr_by_division(L.NC, L.PB, L.IMPR, D, rk, d0 + q, nless);
-        }
-    }
-    return;
+    const double thr = fabs(a0) * range * 0x1p-49;               // |a* b_j| <= |a_0| x range for every pair of the item
+    return !(tiem > f64_hi_as_f32(thr) * 1.0000005f);
     } else {
     // unrolled by hand (the compiler does not unroll around the inline assembly of fdr_take); the LDS reads of a group are
     // issued before its first comparison
@@ -361,7 +426,7 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
         double a[UN], x[UN][W];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            a[u] = L.NC[k + u];
+            a[u] = L.NCS[k + u];
 #pragma unroll
             for (int q = 0; q < W; ++q) x[u][q] = col[(k + u) * D + q];
         }
@@ -376,14 +441,132 @@ __device__ __forceinline__ void fdr_exact(const RlLds& L, int D, int rk, int d0,
         }
     }
     for (; k < nless; ++k) {
-        const double a = L.NC[k] - fi;
+        const double a = L.NCS[k] - fi;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             const double b = fabs(col[k * D + q] - pp[q]) + 1e-5;
             fdr_take(a * bb[q], ab[q] * b, ab[q], bb[q], kb[q], a, b, k);
         }
     }
+    return false;
     }
+}
+
+// The same settlement by the item's OWN lane (both coordinates): what a wave gets that holds more than eight flagged items -- a swarm collapsed onto the rounding floor of
+// its costs, where most items are flagged and settling them one after another would take longer than a second pass of every lane.
+template <int W>
+__device__ __noinline__ void fdr_settle_own(const double* __restrict__ NC, const double* __restrict__ PB, const int* __restrict__ ORDER, int D, int rk, int d0, int nless, int* kb)
+{
+    const double fi = NC[rk];
+    double pp[W], aw[W], bw[W];
+    int kw[W], first_copy[W];
+    bool others[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        kw[q] = kb[q];
+        pp[q] = PB[rk * D + d0 + q];
+        aw[q] = NC[kw[q]] - fi;
+        bw[q] = fabs(PB[kw[q] * D + d0 + q] - pp[q]) + 1e-5;
+        first_copy[q] = 0x7fffffff; others[q] = false;
+    }
+    for (int k = 0; k < nless; ++k) {                              // pass 1: who is inside the band of the winner?  copies of it, or somebody else?
+        const double a = NC[k] - fi;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const double b = fabs(PB[k * D + d0 + q] - pp[q]) + 1e-5, pr = aw[q] * b;
+            if (__builtin_fma(a, bw[q], -pr) <= pr * -0x1p-49 && k != kw[q]) {
+                if (a == aw[q] && b == bw[q]) { if (first_copy[q] == 0x7fffffff) first_copy[q] = k; }
+                else others[q] = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        kb[q] = kw[q] < first_copy[q] ? kw[q] : first_copy[q];
+        if (others[q]) {                                          // pass 2, rare: rounded quotients, lowest particle index among equal ones
+            double qb = aw[q] / bw[q];
+            int ib = ORDER[kb[q]];
+            for (int k = 0; k < nless; ++k) {
+                const double a = NC[k] - fi, b = fabs(PB[k * D + d0 + q] - pp[q]) + 1e-5, pr = aw[q] * b;
+                if (__builtin_fma(a, bw[q], -pr) <= pr * -0x1p-49 && k != kw[q] && !(a == aw[q] && b == bw[q])) {
+                    const double qk = a / b;
+                    const int ik = ORDER[k];
+                    if (qk < qb || (qk == qb && ik < ib)) { qb = qk; ib = ik; kb[q] = k; }
+                }
+            }
+        }
+    }
+}
+
+// Rows of the rank-ordered pbest table that are bitwise copies of the row one rank up -- same cost, same position: particles resting on the same corner of the box (linear
+// slope: most of the swarm, for dozens of generations) -- can never be np.argmin's choice (the copy with the lower index precedes them in rank order and ties with them in
+// every coordinate), but in the scan each of them is an exact tie with the running best: every item above them would be flagged.  The scan therefore reads their cost as 1e300
+// (NCS): a huge positive numerator, never taken, nowhere near a tie.  Called only when equal pbest costs exist in the swarm; thread r owns row r.  The caller synchronises.
+__device__ __forceinline__ void rl_mark_copies(const RlLds& L, int NP, int D, int r)
+{
+    if (r > 0 && r < NP && L.NC[r] == L.NC[r - 1]) {
+        bool same = true;
+        for (int d = 0; d < D && same; ++d) same = L.PB[r * D + d] == L.PB[(r - 1) * D + d];
+        if (same) L.NCS[r] = 1e300;
+    }
+}
+
+// The FDR pass of a generation: every (rank, coordinate pair) item of the population -> KB[rank * D + d] = rank of its exemplar.  Items are visited in
+// pbest-rank order so that the lanes of a wave own particles of similar rank, i.e. similar trip counts; the trip count grows with the rank and wave w of
+// every resident workgroup shares one SIMD, so odd passes run backwards (boustrophedon): each wave pairs a cheap slice of ranks with an expensive one.
+// Items whose scan met a near-tie are settled by their own wave right behind the scan of the pass, lane = candidate (fdr_settle; more than eight flagged lanes in a wave -- a
+// swarm collapsed onto the rounding floor of its costs -- every lane its own: fdr_settle_own).  Ends with the barrier that publishes KB.  Measured and dropped: the flagged items
+// collected in an LDS list and settled by one wave per coordinate behind a barrier (the other waves wait for a ~250-instruction serial chain that, with five workgroups per
+// CU, runs at a fifth of the issue rate: Gallagher F22 +11.6 % over whole episodes against +3.5 % of instructions).  (Measured and dropped: every lane redoing its own flagged item -- 0.1 % of the items stall 6.7 % of
+// the wave-passes for a second scan: +10.4 % per generation against +3.5 % of instructions.)
+template <int W, int UN, bool TIE, int THREADS>
+__device__ __forceinline__ void fdr_pass(const RlLds& L, const int* ORDER, const int* NLESS, int NP, int D, int tid, double range, unsigned long long* cnt = nullptr)
+{
+    const int DW = D / W, NI = NP * DW;
+    const FastDiv fw(DW);
+    for (int base = 0, pass = 0; base < NI; base += THREADS, ++pass) {
+        const int lim = base + THREADS < NI ? base + THREADS : NI;
+        const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
+        const bool valid = ps >= base && ps < lim;
+        int rk = 0, d0 = 0, nless = 0, kb[W];
+        bool tie = false;
+#pragma unroll
+        for (int q = 0; q < W; ++q) kb[q] = 0;
+        if (valid) {
+            rk = fw.div(ps); d0 = W * (ps - rk * DW);
+            nless = NLESS[ORDER[rk]];
+            tie = fdr_exact<W, UN, TIE>(L, D, rk, d0, nless, kb, range);
+#ifdef MBX_FDR_COUNT
+            if (cnt) { atomicAdd(cnt + 3, 1ull); if (tie) atomicAdd(cnt + 2, 1ull); }       // experiment: how many items does the scan flag? (tools/exp/fdr_flag_rate.py)
+#endif
+        }
+        if constexpr (TIE) {
+            // every lane of the wave is here (the loop bounds are workgroup-uniform): flagged items are settled by the whole wave, one coordinate after the other
+            unsigned long long m = __builtin_amdgcn_ballot_w64(tie);
+            if (m != 0ull) {
+                if (__builtin_popcountll(m) > 8) {
+                    if (tie) fdr_settle_own<W>(L.NC, L.PB, ORDER, D, rk, d0, nless, kb);
+                } else {
+                    const int lane = tid & 63;
+                    while (m != 0ull) {
+                        const int l = (int)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const int rk_l = __builtin_amdgcn_readlane(rk, l), d0_l = __builtin_amdgcn_readlane(d0, l), nless_l = __builtin_amdgcn_readlane(nless, l);
+#pragma unroll
+                        for (int q = 0; q < W; ++q) {
+                            const int kbest = fdr_settle(L, ORDER, D, rk_l, d0_l + q, nless_l, __builtin_amdgcn_readlane(kb[q], l), cnt);
+                            if (lane == l) kb[q] = kbest;
+                        }
+                    }
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) L.KB[rk * D + d0 + q] = (uint8_t)kb[q];
+        }
+    }
+    __syncthreads();
 }
 
 // Velocity / position update of W adjacent coordinates of particle i (rlepso_optimizer.py:179-195); FDR exemplars from KB.
@@ -525,8 +708,9 @@ __global__ __launch_bounds__(THREADS) void k_rlepso_reset(BatchParams bp, double
 // NPC / DC / GC: population, dimension and group count fixed at compile time (0 = taken from the batch).  The reference's own
 // geometry (NP = 100 hard-coded in rlepso_optimizer.py:9, n_group = 5, and the D = 10 of its bbob configs) gets an instantiation of
 // its own: index arithmetic, the divisions by D and the short D-loops of the evaluator fold into constants (-8 % per generation).
-// TIE: the FDR scan flags near-ties and resolves them with the reference's divisions (fdr_exact): the run-time-geometry instantiations exist in both forms
-template <int THREADS, int NPC = 0, int DC = 0, int GC = 0, bool TIE = false>
+// TIE: the FDR scan flags near-ties and resolves them with the reference's rounded quotients (fdr_exact / fdr_settle): the default; TIE = false is the
+// cross-multiplied order alone (MBX_F_FDR_FAST)
+template <int THREADS, int NPC = 0, int DC = 0, int GC = 0, bool TIE = true>
 __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParams bp, const float* __restrict__ actions,
                                                           double* __restrict__ state_out, double* __restrict__ reward_out,
                                                           uint8_t* __restrict__ done_out, const float* __restrict__ policy_table,
@@ -632,6 +816,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         }
     }
     __syncthreads();
+    int equal_costs = 0;
     for (int i = tid; i < NP; i += MBX_NT) {                    // per-particle quantities
         const int g = fg.div(i);
         L.CMUT[i] = g < G ? L.COEF[g * 6] * L.PNI[i] : 0.;        // uses per_no_improve BEFORE this step's update (:120)
@@ -639,55 +824,33 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         else { const U4 w = rng.draw((uint32_t)i, MBX_SITE_PART); L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w); }
         const double fi = L.PBC[i];
         int rank = NLESS[i];
-        if (RANK[i] - rank > 1)
+        if (RANK[i] - rank > 1) {
+            equal_costs = 1;
             for (int j = 0; j < i; ++j) rank += L.PBC[j] == fi;
+        }
         RANK[i] = rank;                                            // thread i is the only reader / writer of entry i here
-        ORDER[rank] = i; L.NC[rank] = fi;                          // NC: pbest costs in ascending order (free until eval)
+        ORDER[rank] = i; L.NC[rank] = fi; L.NCS[rank] = fi;        // NC: pbest costs in ascending order (free until eval); NCS: the column the FDR scan reads
     }
-    __syncthreads();
+    equal_costs = __syncthreads_or(equal_costs);
     MBX_PHASE(1);                                                 // ranking + per-particle draws
     // pbest positions are staged in RANK order (row r = particle ORDER[r]): the FDR scan below then walks LDS linearly
     for (int e = tid; e < NE; e += MBX_NT) { const int i = fd.div(e), d = e - i * D; L.PB[RANK[i] * D + d] = gPB[e]; }
     __syncthreads();
+    if (equal_costs) {                                            // workgroup-uniform: rows that are copies of the row one rank up leave the FDR scan (rl_mark_copies)
+        for (int r = tid; r < NP; r += MBX_NT) rl_mark_copies(L, NP, D, r);
+        __syncthreads();
+    }
     MBX_PHASE(2);                                                 // pbest rows -> LDS in rank order
 
     // ---- FDR exemplars -> KB[rank * D + d]  (a pass of its own: the scan's registers are dead before the velocity update starts, which
     // keeps the kernel at 80 VGPRs without scratch; fused into the update it needed 96 and spilled)
 #ifndef MBX_ABLATE_FDR
-    // Items are visited in pbest-rank
-    // order so that the lanes of a wave own particles of similar rank, i.e. similar trip counts; the trip count grows with the rank and
-    // wave w of every resident workgroup shares one SIMD, so odd passes run backwards (boustrophedon): each wave pairs a cheap slice of
-    // ranks with an expensive one.
-    if ((D & 1) == 0) {
-        const int HD = D >> 1, NI = NP * HD;
-        const FastDiv fh(HD);
-        for (int base = 0, pass = 0; base < NI; base += MBX_NT, ++pass) {
-            const int lim = base + MBX_NT < NI ? base + MBX_NT : NI;
-            const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
-            if (ps >= base && ps < lim) {
-                const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
-                int kb[2];
-                fdr_exact<2, MBX_FDR_UNROLL, TIE>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
-                L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
-            }
-        }
-    } else {
-        for (int base = 0, pass = 0; base < NE; base += MBX_NT, ++pass) {
-            const int lim = base + MBX_NT < NE ? base + MBX_NT : NE;
-            const int es = (pass & 1) ? lim - 1 - tid : base + tid;
-            if (es >= base && es < lim) {
-                const int rk = fd.div(es), d0 = es - rk * D;
-                int kb[1];
-                fdr_exact<1, MBX_FDR_UNROLL, TIE>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
-                L.KB[es] = (uint8_t)kb[0];
-            }
-        }
-    }
+    if ((D & 1) == 0) fdr_pass<2, MBX_FDR_UNROLL, TIE, THREADS>(L, ORDER, NLESS, NP, D, tid, ub - lb + 1e-5);
+    else fdr_pass<1, MBX_FDR_UNROLL, TIE, THREADS>(L, ORDER, NLESS, NP, D, tid, ub - lb + 1e-5);
 #else
     for (int e = tid; e < NE; e += MBX_NT) L.KB[e] = 0;
     __syncthreads();
 #endif
-    __syncthreads();
 
     // ---- velocity / position update (:179-195).  A work item is W adjacent dimensions of one particle (W = 2 when D is even).
     const MoveCtx mc{L, bp.pci, tape, rng, gPos, gVel, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
@@ -804,7 +967,7 @@ struct RunOut {
 // ARGS: a callable that returns (a reference to) the kernel's argument block -- the kernel's own parameters, or, out of line, the kernarg segment behind a pointer
 // that is re-materialised at every use (each field access a fresh scalar load next to its use: what the compiler does with a kernel's parameters by itself, and
 // what it cannot do with values a callee loaded once -- those stay in SGPRs across the whole body or are spilled).
-template <int THREADS, int NPC, int DC, int GC, int KIND, int NOISE, class ARGS>
+template <int THREADS, int NPC, int DC, int GC, int KIND, int NOISE, bool TIE, class ARGS>
 __device__ __forceinline__ void rl_run_body(ARGS ar)
 {
     const int n_gens = ar().n_gens;
@@ -830,6 +993,11 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
         }
         return;
     }
+    // launch clock (diagnostics, off unless a slot pair is attached): s_memtime counters of different XCDs / CUs are offset against each other, so every workgroup
+    // measures its OWN lifetime in both time bases and adds the two differences to the launch's sums
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    const bool clocked = ar().bp.clk != nullptr && tid0 == 0;
+    if (clocked) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     ConstProblem& P = *(ConstProblem*)(ar().bp.problems + ar().bp.problem_idx[b]);
     const RlLds L = rl_carve(smem, NP, D, rl_maps_in_lds(NPC, DC));
     int gen = (int)sc[MBX_SC_GEN];
@@ -873,7 +1041,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
     int* NLESS = L.MASK;
     int* RANK = L.RANK;
     float* ACT = (float*)L.R1;    // sampled action; R1 is not written before the ranking barrier
-    int* TIE = (int*)(L.RED + 14);  // equal-cost flag of the ranking (block_argmin uses RED[0..1] only)
+    int* EQC = (int*)(L.RED + 14);  // equal-cost flag of the ranking (block_argmin uses RED[0..1] only)
 
     // pbest / gbest bookkeeping of update() and __reinit() (rl_commit with c_cost and the pbest positions in registers)
     auto commit = [&](bool stagnation, int tid) {
@@ -919,7 +1087,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
             if (ar().out.traj_actions) ar().out.traj_actions[((int64_t)g * B + b) * A + tid] = a;
         }
         if (tid < NP) { NLESS[tid] = 0; ORDER[tid] = tid; }
-        if (tid == 0) *TIE = 0;
+        if (tid == 0) *EQC = 0;
         __syncthreads();
         if (tid < G) {                                            // __get_coe (:112-132), float32 like k_rlepso_step
             const float* a = ACT + tid * G;
@@ -937,7 +1105,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
         // ---- rank the particles by (pbest cost, index).  k_rlepso_step counts, per pair, both `<` and `<=` so that equal costs can be ordered
         // by index; here only the strictly better particles are counted (ONE compare per pair: half the ranking's instructions) and the rank is
         // that count.  Two particles with exactly the same pbest cost then claim the same slot of ORDER: the one that lost the slot sees it
-        // (ORDER[rank] != i), raises the workgroup's TIE flag, and the workgroup -- uniformly -- redoes the per-particle step with the index
+        // (ORDER[rank] != i), raises the workgroup's equal-cost flag, and the workgroup -- uniformly -- redoes the per-particle step with the index
         // tie-break and restages the rows.  Same ranks as k_rlepso_step in every case; the slow path only runs for instances that really hold
         // equal costs (collapsed swarms on F5 / F7 plateaus).
         {
@@ -964,10 +1132,10 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
             L.R1[i] = u53(w.x, w.y); L.R2[i] = u53(w.z, w.w);
             const int rank = NLESS[i];
             RANK[i] = rank;
-            ORDER[rank] = i; L.NC[rank] = L.PBC[i];
+            ORDER[rank] = i; L.NC[rank] = L.PBC[i]; L.NCS[rank] = L.PBC[i];
         }
         __syncthreads();
-        if (tid < NP && ORDER[RANK[tid]] != tid) *TIE = 1;
+        if (tid < NP && ORDER[RANK[tid]] != tid) *EQC = 1;
         // ---- pbest positions -> LDS in rank order, from the owners' registers
         auto stage_pbest = [&](int tid) {
 #pragma unroll
@@ -978,38 +1146,31 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
         };
         stage_pbest(tid);
         __syncthreads();
-        if (*TIE) {                                               // workgroup-uniform: equal pbest costs exist, order them by index
+        if (*EQC) {                                               // workgroup-uniform: equal pbest costs exist, order them by index
             int rank = 0;
             if (tid < NP) {
                 const double fi = L.PBC[tid];
                 rank = NLESS[tid];
                 for (int j = 0; j < tid; ++j) rank += L.PBC[j] == fi;
             }
-            __syncthreads();                                      // every thread has read TIE and the fast path's tables
-            if (tid < NP) { RANK[tid] = rank; ORDER[rank] = tid; L.NC[rank] = L.PBC[tid]; }
+            __syncthreads();                                      // every thread has read the flag and the fast path's tables
+            if (tid < NP) { RANK[tid] = rank; ORDER[rank] = tid; L.NC[rank] = L.PBC[tid]; L.NCS[rank] = L.PBC[tid]; }
             __syncthreads();
             stage_pbest(tid);
+            __syncthreads();
+            rl_mark_copies(L, NP, D, tid);                        // rows that are copies of the row one rank up leave the FDR scan
             __syncthreads();
         }
         // ---- FDR exemplars -> KB (see k_rlepso_step)
 #ifdef MBX_ABLATE_FDR
         for (int e = tid; e < NP * D; e += THREADS) L.KB[e] = 0;
+        __syncthreads();
 #else
-        for (int base = 0, pass = 0; base < NI; base += THREADS, ++pass) {
-            const int lim = base + THREADS < NI ? base + THREADS : NI;
-            const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
-            if (ps >= base && ps < lim) {
-                const int rk = fh.div(ps), d0 = 2 * (ps - rk * HD);
-                int kb[2];
-                fdr_exact<2, (DC == 40 ? 2 : MBX_FDR_UNROLL)>(L, D, rk, d0, NLESS[ORDER[rk]], kb, ub - lb + 1e-5);
-                L.KB[rk * D + d0] = (uint8_t)kb[0]; L.KB[rk * D + d0 + 1] = (uint8_t)kb[1];
-            }
-        }
+        fdr_pass<2, (DC == 40 ? 2 : MBX_FDR_UNROLL), TIE, THREADS>(L, ORDER, NLESS, NP, D, tid, ub - lb + 1e-5, ar().bp.clk);      // (ends with the barrier that publishes KB)
 #endif
         // (Measured and dropped, round 3: dealing config 5's half-empty last pass -- 512 items of the highest ranks on 1024 threads -- as single
         // coordinates, one per thread, so that every wave scans: 1.80 -> 1.94 ms per generation; the one-coordinate scan repeats the cost difference
         // and the LDS reads per candidate, which costs more than the idle waves did.)
-        __syncthreads();
         // ---- velocity / position update (:179-195): new position -> X, new velocity -> register
         {
             const MoveCtx mc{L, ar().bp.pci, nullptr, rng, nullptr, nullptr, ORDER, NLESS, RANK, NP, D, G, lb, ub, vmax, fg};
@@ -1103,6 +1264,10 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
         if (ar().out.state_out) ar().out.state_out[b] = st;
         if (ar().out.reward_out) ar().out.reward_out[b] = ret;
         if (ar().out.done_out) ar().out.done_out[b] = done ? 1 : 0;
+        if (clocked) {
+            atomicAdd(ar().bp.clk, (unsigned long long)__builtin_amdgcn_s_memtime() - clk_c0);
+            atomicAdd(ar().bp.clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
+        }
     }
 }
 
@@ -1118,7 +1283,7 @@ struct RlRunArgs {
 // rl_run_body out of line, one instantiation per function kind: register-allocated and scheduled without the other kinds' code (a build of the any-kind kernel with every
 // kind but one compiled out of the evaluator ran a one-function batch 8-12 % faster: docs/EXPERIMENTS.md).  In a callee s[8:9] is the IMPLICIT argument pointer, so the
 // address of the kernel's argument block is an argument; every field access goes through that address (see rl_run_body).
-template <int THREADS, int NPC, int DC, int GC, int KIND, int NOISE>
+template <int THREADS, int NPC, int DC, int GC, int KIND, int NOISE, bool TIE>
 __device__ __noinline__ void rl_run_body_of_kind(uint32_t karg_lo_, uint32_t karg_hi_)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_lo_), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)karg_hi_);
@@ -1128,7 +1293,7 @@ __device__ __noinline__ void rl_run_body_of_kind(uint32_t karg_lo_, uint32_t kar
         asm volatile("" : "+s"(p));
         return *(CArgs*)p;
     };
-    rl_run_body<THREADS, NPC, DC, GC, KIND, NOISE>(ar);
+    rl_run_body<THREADS, NPC, DC, GC, KIND, NOISE, TIE>(ar);
 }
 
 // per-kind bodies for the geometries of configs 1 / 2 (D = 10) and 5 (D = 40): the 24 noise-free BBOB kinds with the noise models compiled out (another
@@ -1141,7 +1306,8 @@ __host__ __device__ constexpr bool rl_run_kind_ok(int kind, int noise_kind)
                                         : (kind == 1 || kind == 7 || kind == 8 || kind == 10 || kind == 14 || kind == 17 || kind == 19 || kind == 21);
 }
 
-template <int THREADS, int NPC, int DC, int GC>
+// TIE: see k_rlepso_step
+template <int THREADS, int NPC, int DC, int GC, bool TIE = true>
 __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParams bp, const float* __restrict__ policy_table, int table_rows,
                                                                      int n_gens, RunOut out)
 {
@@ -1152,26 +1318,26 @@ __global__ __launch_bounds__(THREADS) MBX_RUN_WAVES void k_rlepso_run(BatchParam
         const DevProblem* pr = bp.problems + bp.problem_idx[bp.order[blockIdx.x]];
         const int kind = __builtin_amdgcn_readfirstlane(pr->kind);
         const bool noisy = __builtin_amdgcn_readfirstlane(pr->noise_kind) != MBX_NOISE_NONE;
-#define MBX_RL_KIND(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K, 0>(klo, khi); break;
-#define MBX_RL_NOISY(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K, 1>(klo, khi); break;
+#define MBX_RL_KIND(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K, 0, TIE>(klo, khi); break;
+#define MBX_RL_NOISY(K) case K: rl_run_body_of_kind<THREADS, NPC, DC, GC, K, 1, TIE>(klo, khi); break;
         if (noisy) {
             switch (kind) {
             MBX_RL_NOISY(1) MBX_RL_NOISY(7) MBX_RL_NOISY(8) MBX_RL_NOISY(10) MBX_RL_NOISY(14) MBX_RL_NOISY(17) MBX_RL_NOISY(19) MBX_RL_NOISY(21)
-            default: __builtin_trap();                              // (mbx_rlepso_rollout sends batches with any other function through the per-generation route)
+            default: rl_run_body_of_kind<THREADS, NPC, DC, GC, 0, -1, TIE>(klo, khi);      // any other (kind, noise model) pair: the any-kind body, out of line like the rest
             }
         } else {
             switch (kind) {
             MBX_RL_KIND(1) MBX_RL_KIND(2) MBX_RL_KIND(3) MBX_RL_KIND(4) MBX_RL_KIND(5) MBX_RL_KIND(6) MBX_RL_KIND(7) MBX_RL_KIND(8)
             MBX_RL_KIND(9) MBX_RL_KIND(10) MBX_RL_KIND(11) MBX_RL_KIND(12) MBX_RL_KIND(13) MBX_RL_KIND(14) MBX_RL_KIND(15) MBX_RL_KIND(16)
             MBX_RL_KIND(17) MBX_RL_KIND(18) MBX_RL_KIND(19) MBX_RL_KIND(20) MBX_RL_KIND(21) MBX_RL_KIND(22) MBX_RL_KIND(23) MBX_RL_KIND(24)
-            default: __builtin_trap();
+            default: rl_run_body_of_kind<THREADS, NPC, DC, GC, 0, -1, TIE>(klo, khi);
             }
         }
 #undef MBX_RL_NOISY
 #undef MBX_RL_KIND
     } else {
         typedef const RlRunArgs __attribute__((address_space(4))) CArgs;
-        rl_run_body<THREADS, NPC, DC, GC, 0, -1>([]() -> CArgs& {
+        rl_run_body<THREADS, NPC, DC, GC, 0, -1, TIE>([]() -> CArgs& {
             return *(CArgs*)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         });
     }

@@ -98,12 +98,14 @@ class Suite:
 class Batch:
     """B lock-step optimizer instances on one GPU (``mbx_batch``)."""
 
-    def __init__(self, suite, algo, problem_idx, seeds, np_, max_fes, log_interval, n_logpoint, early_stop=True, n_group=5):
+    def __init__(self, suite, algo, problem_idx, seeds, np_, max_fes, log_interval, n_logpoint, early_stop=True, n_group=5, flags=0):
+        """flags: ``mbx_algo_cfg.flags`` (``_abi.F_FDR_FAST | F_GENERIC_GEOMETRY | F_ROLLOUT_PER_GENERATION``), per batch; ``self.flags`` is what the
+        library made of them (environment overrides included)."""
         _require_gpu()
         self.lib = suite.lib
         self.suite = suite
         self.cfg = _abi.AlgoCfg(int(algo), int(np_), suite.dim, int(max_fes), int(log_interval), int(n_logpoint),
-                                int(bool(early_stop)), int(n_group))
+                                int(bool(early_stop)), int(n_group), int(flags))
         pidx = np.ascontiguousarray(problem_idx, dtype=np.int32)
         sd = np.ascontiguousarray(seeds, dtype=np.uint64)
         assert pidx.shape == sd.shape and pidx.ndim == 1
@@ -112,6 +114,8 @@ class Batch:
         _abi.check(self.lib.mbx_batch_create(suite._h, C.byref(self.cfg), pidx.ctypes.data_as(C.POINTER(C.c_int32)),
                                              sd.ctypes.data_as(C.POINTER(C.c_uint64)), self.B, C.byref(h)))
         self._h = h
+        self.flags = int(self.lib.mbx_batch_flags(h))
+        self.cfg.flags = self.flags            # the geometry queries below must see the flags the batch really has
         self.state_dim = self.lib.mbx_state_dim(C.byref(self.cfg))
         self.action_dim = self.lib.mbx_action_dim(C.byref(self.cfg))
         self.tape_stride = int(self.lib.mbx_tape_stride(C.byref(self.cfg)))

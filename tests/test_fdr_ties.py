@@ -1,16 +1,19 @@
-"""The FDR exemplar on adversarial swarms (VERDICT r04 item 3).
+"""The FDR exemplar on adversarial swarms (VERDICT r04 item 3, r05 item 1).
 
 Reference (src/optimizer/rlepso_optimizer.py:96-109): target_index = np.argmin((f_j - f_i) / (|p_jd - p_id| + 1e-5), axis=j) -- the quotients are ROUNDED and the
-first minimal one in particle-index order wins.  The oracle evaluates exactly that (oracle/mbx_oracle.c, division form).  The HIP kernels compare two candidates
-by cross-multiplication, a_j b* < a* b_j (csrc/mbx_rlepso.hpp fdr_exact), which orders the exact ratios the same way but can resolve differently when two
-NON-identical candidates have quotients within an ulp or two of each other.  This file builds swarms in which, for one query particle and every dimension,
-the two best candidates have quotients 0, 1, 2, ... ulp apart, hands the same state block + replay tape to the oracle and to the kernel, decodes the chosen
-exemplar from the velocity the step produces, and counts:
-  * CPU:  the oracle agrees with the literal numpy formula of the reference on every (particle, dimension)            -> asserted, 100 %
-  * GPU:  the kernel agrees with it whenever the two quotients are >= 4 ulp apart                                      -> asserted, 100 %
-          and the measured disagreement rate at 0 / 1 / 2-3 ulp                                                          -> printed
-  * GPU:  a batch created with MBX_FDR_EXACT=1 (near-ties flagged inside the scan and redone with the reference's divisions) agrees on EVERY pair -> asserted
-  * GPU:  on natural swarms (Philox episodes of four functions) kernel and oracle pick the same exemplar everywhere    -> asserted
+first minimal one in particle-index order wins.  The oracle evaluates exactly that (oracle/mbx_oracle.c, division form).  The HIP kernels scan by
+cross-multiplication, a_j b* < a* b_j (csrc/mbx_rlepso.hpp fdr_exact), which orders the exact ratios the same way but can resolve differently when two
+NON-identical candidates have quotients within an ulp or two of each other; by DEFAULT every kernel therefore flags each comparison that comes within 2^-49 of
+a tie and settles the flagged items with rounded quotients (fdr_verify).  This file builds swarms in which, for one query particle and every dimension, the two
+best candidates have quotients 0, 1, 2, ... ulp apart, hands the same state block to the reference formula and to the kernel, decodes the chosen exemplar from
+the velocity the step produces, and checks:
+  * CPU:  the oracle agrees with the literal numpy formula of the reference on every (particle, dimension)                              -> asserted, 100 %
+  * GPU:  the kernels agree with it on EVERY item, whatever the distance -- route in {one launch per generation (replay tape), resident rollout (Philox)} x
+          geometry in {NP 100 / D 10 (headline), NP 128 / D 40 (config 5)}                                                                -> asserted, 0 in every bucket
+  * GPU:  a batch created with MBX_F_FDR_FAST (the cross-multiplied order alone) disagrees only where the quotients are <= 1 ulp apart    -> asserted; rate printed
+  * GPU:  two batches with different flags coexist in one process (the option travels in mbx_algo_cfg.flags, not in the environment)
+  * GPU:  on natural swarms -- wide ones and ones converged to the rounding floor of their costs, where most comparisons ARE ties -- kernel and oracle pick the
+          same exemplar everywhere                                                                                                          -> asserted
 """
 import numpy as np
 import pytest
@@ -41,10 +44,12 @@ def quotient(f, P, i, m, d):
     return (f[m] - f[i]) / (np.abs(P[m, d] - P[i, d]) + 1e-5)
 
 
-def craft_swarm(rs, target_ulps):
+def craft_swarm(rs, target_ulps, NP=NP, D=D):
     """pbest costs f [NP], pbest positions P [NP, D], query particle q and the pair (j, k) whose quotients towards q are `target_ulps[d]` ulp apart in
     dimension d (as close as the +-24-ulp neighbourhood of the two coordinates allows); every other candidate's quotient is far weaker."""
     q, j, k = rs.choice(NP, 3, replace=False)
+    while q >= 5 * (NP // 5):                             # particles beyond the last full group move with zero coefficients (rlepso_optimizer.py:117-126): nothing to decode
+        q, j, k = rs.choice(NP, 3, replace=False)
     f = 1000. - rs.uniform(1., 40., NP)
     f[q] = 1000.
     f[j] = 1000. - 100. * (1 + rs.uniform())
@@ -79,14 +84,16 @@ def craft_swarm(rs, target_ulps):
 
 def reference_targets(f, P):
     """rlepso_optimizer.py:98-102, literally."""
+    NP = len(f)
     distance_per_dim = np.abs(P[None, :, :].repeat(NP, axis=0) - P[:, None, :].repeat(NP, axis=1))
     fitness_delta = f[None, :].repeat(NP, axis=0) - f[:, None].repeat(NP, axis=1)
     fdr = (fitness_delta[:, :, None]) / (distance_per_dim + 1e-5)
     return np.argmin(fdr, axis=1)
 
 
-def state_block(template, f, P):
+def state_block(template, f, P, NLOG=NLOG):
     """A reset state block with the crafted swarm as its pbest table, zero velocities and consistent gbest fields."""
+    NP, D = P.shape
     st = template.copy()
     sp = oracle.split_rlepso_state(st, NP, D, NLOG)          # views into st
     sp['vel'][:] = 0.
@@ -101,7 +108,7 @@ def state_block(template, f, P):
     return st
 
 
-def replay_tape():
+def replay_tape(NP=NP, D=D):
     """One update() worth of numpy draws (layout: oracle.NumpyTapeFeeder.step_tape): no CLPSO exemplar (u > pci), FDR weight 0.5, no re-initialisation."""
     t = np.zeros(9 * NP + 6 * NP * D)
     t[0:2 * NP] = 0.25                                       # rand1, rand2 (their terms carry zero coefficients)
@@ -114,18 +121,21 @@ def replay_tape():
     return t
 
 
-def decode_agreement(vel_after, f, P, targets):
-    """[NP, D] bool: the observed new velocity equals the one the reference's exemplar produces (bit for bit)."""
+def decode_agreement(vel_after, f, P, targets, u_fdr=U_FDR):
+    """[NP, D] bool: the observed new velocity equals the one the reference's exemplar produces (bit for bit).  u_fdr: the FDR weight, a scalar (replay
+    tape) or the [NP, D] Philox draws of the generation (mbx_debug_rlepso_draws)."""
+    NP, D = P.shape
     c2 = c2_of_action()
     ii, dd = np.indices((NP, D))
-    want = np.clip(c2 * (U_FDR * (P[targets, dd] - P)), -1., 1.)
+    want = np.clip(c2 * (u_fdr * (P[targets, dd] - P)), -1., 1.)
+    want[5 * (NP // 5):] = 0.                             # NP = 128: particles 125-127 get w = c = 0 under the reference's NP // n_group rule
     return vel_after.reshape(NP, D) == want
 
 
-def crafted_cases(n, seed=0):
+def crafted_cases(n, seed=0, NP=NP, D=D):
     rs = np.random.RandomState(seed)
-    menu = np.array([0, 0, 1, 1, 2, 2, 3, 4, 8, 64])
-    return [craft_swarm(rs, rs.permutation(menu)) for _ in range(n)]
+    menu = np.tile(np.array([0, 0, 1, 1, 2, 2, 3, 4, 8, 64]), D // 10)
+    return [craft_swarm(rs, rs.permutation(menu), NP, D) for _ in range(n)]
 
 
 def test_oracle_fdr_is_the_reference_formula_on_adversarial_swarms():
@@ -148,52 +158,140 @@ def test_oracle_fdr_is_the_reference_formula_on_adversarial_swarms():
     assert hist.get(0, 0) >= 60 and hist.get(1, 0) >= 60 and hist.get(2, 0) >= 30, hist      # the construction really produces 0 / 1 / 2-ulp pairs
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['default', 'exact'])
-def test_hip_fdr_on_adversarial_swarms_measured_disagreement(mode, monkeypatch):
+def _philox_fdr_weights(seed, NP_, D_):
+    """The FDR weights u_fdr [NP, D] the kernels draw for the instance with key `seed` in generation 1 of episode 0 (mbx_debug_rlepso_draws: rl_move's own code path)."""
+    import ctypes as C
     import torch
-    if mode == 'exact':
-        monkeypatch.setenv('MBX_FDR_EXACT', '1')               # read when the batch is created
+    from metabox_amd import _abi
+    out = torch.empty(NP_ * D_, 4, dtype=torch.float64, device='cuda')
+    _abi.check(_abi.load_lib().mbx_debug_rlepso_draws(C.c_uint64(int(seed)), 1, 0, NP_, D_, C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    return out[:, 1].cpu().numpy().reshape(NP_, D_)
+
+
+def _run_crafted(cases, NP_, D_, route, flags):
+    """Step every crafted swarm once on the GPU -- route 'per_generation': mbx_set_tape + mbx_step (u_fdr = 0.5 from the tape); route 'resident': ONE generation of
+    mbx_rlepso_rollout with an actor table whose mu is ACTION and whose sigma is 0 (Philox draws; u_fdr read back through mbx_debug_rlepso_draws) -- and return
+    (buckets {ulp distance: [pairs, disagreements]}, [other items, disagreements], batch flags, launch info, resident?)."""
+    import torch
     from metabox_amd.suite import Batch, Suite
     from metabox_amd._abi import ALGO_RLEPSO
-    p = problems('bbob', D)[1]
-    cases = crafted_cases(512)
+    maxfes = 2000 * D_
+    p = problems('bbob', D_)[1]
     B = len(cases)
-    batch = Batch(Suite([p]), ALGO_RLEPSO, np.zeros(B, int), np.arange(B), NP, MAXFES, LOGI, NLOG)
-    assert batch.launch_info()['fixed_geometry'] == (0 if mode == 'exact' else 1) and batch.rollout_is_resident() == (mode != 'exact')
+    seeds = np.arange(B, dtype=np.uint64) * 7 + 3
+    batch = Batch(Suite([p]), ALGO_RLEPSO, np.zeros(B, int), seeds, NP_, maxfes, maxfes // NLOG, NLOG, flags=flags)
+    info, resident, got_flags = batch.launch_info(), batch.rollout_is_resident(), batch.flags
     batch.reset()
     torch.cuda.synchronize()
     template = batch.read_state(0)
     for b, (f, P, _, _) in enumerate(cases):
         batch.write_state(b, state_block(template, f, P))
-    batch.set_tape(torch.from_numpy(np.tile(replay_tape(), (B, 1))).cuda())
-    batch.step(torch.from_numpy(np.tile(ACTION, (B, 1))).cuda())
+    if route == 'per_generation':
+        batch.set_tape(torch.from_numpy(np.tile(replay_tape(NP_, D_), (B, 1))).cuda())
+        batch.step(torch.from_numpy(np.tile(ACTION, (B, 1))).cuda())
+    else:
+        rows = maxfes + 2 * NP_ + 1
+        table = torch.zeros(rows, 2, 35, dtype=torch.float32)
+        table[:, 0] = torch.from_numpy(ACTION)                       # mu = ACTION, sigma = 0: the sampled action IS the action of the tape route
+        batch.rlepso_rollout(table.cuda().contiguous(), 1)
     torch.cuda.synchronize()
     buckets = {0: [0, 0], 1: [0, 0], 2: [0, 0], 3: [0, 0], 4: [0, 0]}           # ulp distance (4 = four or more) -> [pairs, disagreements]
     others = [0, 0]
     for b, (f, P, (q, j, k), ulps) in enumerate(cases):
-        vel = oracle.split_rlepso_state(batch.read_state(b), NP, D, NLOG)['vel']
-        agree = decode_agreement(vel, f, P, reference_targets(f, P))
-        for d in range(D):
-            u = min(int(ulps[d]), 4)
-            buckets[u][0] += 1
-            buckets[u][1] += int(not agree[q, d])
+        vel = oracle.split_rlepso_state(batch.read_state(b), NP_, D_, NLOG)['vel']
+        u = U_FDR if route == 'per_generation' else _philox_fdr_weights(seeds[b], NP_, D_)
+        agree = decode_agreement(vel, f, P, reference_targets(f, P), u)
+        for d in range(D_):
+            w = min(int(ulps[d]), 4)
+            buckets[w][0] += 1
+            buckets[w][1] += int(not agree[q, d])
         rest = np.delete(agree, q, axis=0)
         others[0] += rest.size
         others[1] += int((~rest).sum())
     batch.close()
-    print(f'FDR exemplar, kernel ({"MBX_FDR_EXACT=1: near-ties redone with divisions" if mode == "exact" else "cross-multiplied compare"}) vs reference formula '
-          f'(rounded quotients, np.argmin) on crafted near-ties:')
+    return buckets, others, got_flags, info, resident
+
+
+def _print_buckets(title, buckets, others):
+    print(title)
     for u in sorted(buckets):
         n, bad = buckets[u]
         print(f'  quotients {u}{"+" if u == 4 else ""} ulp apart: {bad} / {n} pairs resolved differently ({100. * bad / max(n, 1):.1f} %)')
     print(f'  all other (particle, dimension) items of the same swarms: {others[1]} / {others[0]}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['per_generation', 'resident'])
+@pytest.mark.parametrize('np_,dim,geometry', [(100, 10, 1), (128, 40, 2)])
+def test_hip_fdr_is_the_reference_index_on_adversarial_swarms(np_, dim, geometry, route):
+    """DEFAULT flags: the exemplar of every (particle, dimension) item equals np.argmin of the reference's rounded quotients -- 0 disagreements in every bucket, on the
+    one-generation kernels AND on the resident rollout kernels the product and the bench run, at the geometries of BASELINE configs 2 and 5.
+    src/optimizer/rlepso_optimizer.py:97-109."""
+    cases = crafted_cases(512 if dim == 10 else 96, seed=dim, NP=np_, D=dim)
+    buckets, others, flags, info, resident = _run_crafted(cases, np_, dim, route, 0)
+    assert flags == 0 and info['fixed_geometry'] == geometry and resident, (flags, info, resident)       # exact mode keeps the compile-time geometry and the resident route
+    _print_buckets(f'FDR exemplar, default (exact) kernels, {route}, NP {np_} / D {dim}, vs reference formula (rounded quotients, np.argmin) on crafted near-ties:', buckets, others)
+    assert buckets[0][0] >= 400 and buckets[1][0] >= 400, buckets
+    assert all(v[1] == 0 for v in buckets.values()) and others[1] == 0, (buckets, others)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['per_generation', 'resident'])
+def test_hip_fdr_fast_flag_measured_disagreement(route):
+    """MBX_F_FDR_FAST: the cross-multiplied order alone.  Differs from the reference only where the two quotients round together or to neighbours."""
+    from metabox_amd._abi import F_FDR_FAST
+    cases = crafted_cases(512)
+    buckets, others, flags, info, resident = _run_crafted(cases, NP, D, route, F_FDR_FAST)
+    assert flags == F_FDR_FAST and info['fixed_geometry'] == 1 and resident, (flags, info)
+    _print_buckets(f'FDR exemplar, MBX_F_FDR_FAST kernels, {route}, vs reference formula on crafted near-ties:', buckets, others)
     assert buckets[4][1] == 0 and others[1] == 0, (buckets, others)
-    assert buckets[0][0] >= 500 and buckets[1][0] >= 500
-    if mode == 'exact':
-        assert all(v[1] == 0 for v in buckets.values()), buckets
-    else:
-        assert buckets[2][1] == 0 and buckets[3][1] == 0, buckets          # measured: only quotients that round together or to neighbours resolve differently
+    assert buckets[2][1] == 0 and buckets[3][1] == 0, buckets          # measured: only quotients that round together or to neighbours resolve differently
+    assert buckets[0][1] > 0, buckets                                  # ... and there the fast form really is a different function (the flag reached the kernel)
+
+
+@pytest.mark.gpu
+def test_two_batches_with_different_flags_coexist_in_one_process():
+    """The behaviour options travel in mbx_algo_cfg.flags (include/mbx.h), per batch: an exact and a fast batch created side by side, stepped alternately on the
+    same crafted swarms, each keep their own FDR form; the generic-geometry and per-generation flags are per batch as well."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO, F_FDR_FAST, F_GENERIC_GEOMETRY, F_ROLLOUT_PER_GENERATION
+    p = problems('bbob', D)[1]
+    cases = crafted_cases(128, seed=5)
+    B = len(cases)
+    s = Suite([p])
+    mk = lambda fl: Batch(s, ALGO_RLEPSO, np.zeros(B, int), np.arange(B), NP, MAXFES, LOGI, NLOG, flags=fl)
+    exact, fast, generic, pergen = mk(0), mk(F_FDR_FAST), mk(F_GENERIC_GEOMETRY), mk(F_ROLLOUT_PER_GENERATION)
+    assert (exact.flags, fast.flags, generic.flags, pergen.flags) == (0, F_FDR_FAST, F_GENERIC_GEOMETRY, F_ROLLOUT_PER_GENERATION)
+    assert exact.launch_info()['fixed_geometry'] == 1 and generic.launch_info()['fixed_geometry'] == 0
+    assert exact.rollout_is_resident() and fast.rollout_is_resident() and generic.rollout_is_resident() is False and pergen.rollout_is_resident() is False
+    tape = torch.from_numpy(np.tile(replay_tape(), (B, 1))).cuda()
+    acts = torch.from_numpy(np.tile(ACTION, (B, 1))).cuda()
+    batches = (exact, fast, generic, pergen)
+    for bt in batches:
+        bt.reset()
+    torch.cuda.synchronize()
+    template = exact.read_state(0)
+    for b, (f, P, _, _) in enumerate(cases):
+        blk = state_block(template, f, P)
+        for bt in batches:
+            bt.write_state(b, blk)
+    for bt in batches:                                                # alternate launches of the four batches on one stream
+        bt.set_tape(tape)
+        bt.step(acts)
+    torch.cuda.synchronize()
+    bad = {id(bt): 0 for bt in batches}
+    for b, (f, P, (q, j, k), ulps) in enumerate(cases):
+        tg = reference_targets(f, P)
+        for bt in batches:
+            vel = oracle.split_rlepso_state(bt.read_state(b), NP, D, NLOG)['vel']
+            bad[id(bt)] += int((~decode_agreement(vel, f, P, tg)).sum())
+    for bt in batches:
+        bt.close()
+    assert bad[id(exact)] == 0 and bad[id(generic)] == 0 and bad[id(pergen)] == 0 and bad[id(fast)] > 0, bad
+    with pytest.raises(Exception):
+        mk(1 << 9)                                                    # unknown flag bits are an argument error, not ignored
 
 
 @pytest.mark.gpu
@@ -234,3 +332,76 @@ def test_hip_fdr_equals_the_oracle_on_natural_swarms():
     batch.close()
     print(f'natural swarms: {mismatched} of {items} (particle, dimension) items moved with a different exemplar')
     assert items > 500_000 and mismatched == 0
+
+
+def _near_tie_items(f, P):
+    """Number of (particle, dimension) items whose two smallest rounded quotients are <= 2 ulp apart (equal ones included) although they belong to different candidates."""
+    NP_ = len(f)
+    fdr = (f[None, :] - f[:, None])[:, :, None] / (np.abs(P[None, :, :] - P[:, None, :]) + 1e-5)          # [i, j, d]
+    two = np.partition(fdr, 1, axis=1)[:, :2, :]
+    lo, hi = two[:, 0, :], two[:, 1, :]
+    same_sign = np.signbit(lo) == np.signbit(hi)
+    ulp = np.abs(lo.view(np.int64) - hi.view(np.int64))
+    return int((same_sign & (ulp <= 2) & (lo < 0)).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['per_generation', 'resident'])
+def test_hip_fdr_is_the_reference_index_on_converged_swarms(route):
+    """Natural swarms at the rounding floor of their costs: RLEPSO runs whole episodes (no stop rule) on functions whose swarms collapse -- costs quantised at
+    ulp(bias), coordinates clipped onto a bound, exact duplicates -- and the pbest tables of generations 40 / 100 / 160 / 199 are handed, as in the crafted test,
+    to the reference formula and to the kernels.  There most items' best two quotients ARE ties; the exemplars must still be np.argmin's on every item."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    fids = (1, 2, 5, 7, 20, 24)
+    ps = [problems('bbob', D)[k] for k in fids]
+    B = 48
+    seeds = np.arange(B, dtype=np.uint64) * 6007 + 1
+    pidx = np.arange(B) % len(ps)
+    run = Batch(Suite(ps), ALGO_RLEPSO, pidx, seeds, NP, MAXFES, LOGI, NLOG, early_stop=False)
+    table = torch.rand(MAXFES + 2 * NP + 1, 2, 35, generator=torch.Generator().manual_seed(9))
+    table[:, 1] = 0.02 + 0.1 * table[:, 1]
+    table[:, 0, ::5] *= 0.05                                      # small c_mutation: few re-initialisations, the swarm is allowed to collapse
+    table = table.cuda().contiguous()
+    run.reset()
+    swarms, done_gens = [], 0
+    for upto in (40, 100, 160, 199):
+        run.rlepso_rollout(table, upto - done_gens)
+        done_gens = upto
+        torch.cuda.synchronize()
+        for b in range(B):
+            sp = oracle.split_rlepso_state(run.read_state(b), NP, D, NLOG)
+            swarms.append((sp['pbest'].copy(), sp['pbpos'].reshape(NP, D).copy(), None, None))
+    run.close()
+    ties = sum(_near_tie_items(f, P) for f, P, _, _ in swarms)
+    dup = sum(NP - len(np.unique(f)) for f, P, _, _ in swarms)
+    # the same machinery as the crafted test; the bucket bookkeeping is bypassed (no designated pair), every item counts
+    p = problems('bbob', D)[1]
+    n = len(swarms)
+    probe = Batch(Suite([p]), ALGO_RLEPSO, np.zeros(n, int), np.arange(n, dtype=np.uint64) * 7 + 3, NP, MAXFES, LOGI, NLOG)
+    assert probe.flags == 0 and probe.rollout_is_resident()
+    probe.reset()
+    torch.cuda.synchronize()
+    template = probe.read_state(0)
+    for b, (f, P, _, _) in enumerate(swarms):
+        probe.write_state(b, state_block(template, f, P))
+    if route == 'per_generation':
+        probe.set_tape(torch.from_numpy(np.tile(replay_tape(), (n, 1))).cuda())
+        probe.step(torch.from_numpy(np.tile(ACTION, (n, 1))).cuda())
+    else:
+        tb = torch.zeros(MAXFES + 2 * NP + 1, 2, 35, dtype=torch.float32)
+        tb[:, 0] = torch.from_numpy(ACTION)
+        probe.rlepso_rollout(tb.cuda().contiguous(), 1)
+    torch.cuda.synchronize()
+    items = bad = 0
+    for b, (f, P, _, _) in enumerate(swarms):
+        vel = oracle.split_rlepso_state(probe.read_state(b), NP, D, NLOG)['vel']
+        u = U_FDR if route == 'per_generation' else _philox_fdr_weights(b * 7 + 3, NP, D)
+        agree = decode_agreement(vel, f, P, reference_targets(f, P), u)
+        items += agree.size
+        bad += int((~agree).sum())
+    probe.close()
+    print(f'converged natural swarms ({route}): {bad} of {items} items moved with an exemplar other than np.argmin\'s; {ties} items whose two best quotients are <= 2 ulp '
+          f'apart, {dup} duplicate pbest costs in {n} swarms')
+    assert ties > 1000 and bad == 0

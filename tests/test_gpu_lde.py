@@ -165,6 +165,47 @@ def test_lde_large_batch_properties(NP):
     assert np.all(full['fes'] == NP * 7)
 
 
+@pytest.mark.parametrize('NP', [50, 100])
+def test_lde_resident_rollout_large_batch_properties(NP):
+    """The route config 3 is TIMED on, at its full size: 16384 instances on bbob-noisy d=30 through mbx_lde_rollout (k_lde_run<NP, 30>: PolicyNet inside the kernel, 12 generations
+    in two launches).  Deterministic, independent of the shard an instance runs in (every fourth instance alone gives the same rows, (h, c) and features), population kept
+    sorted, features normalised, histogram complete, FEs billed per generation.  (the property test stepped k_lde_step only.)"""
+    from metabox_amd.suite import Batch
+    from metabox_amd._abi import ALGO_LDE
+    s, ids = _suite('bbob-noisy', 30)
+    B = 16384
+    pidx = np.arange(B) % len(ids)
+    seeds = np.arange(B, dtype=np.uint64) * 31 + 5
+    net = _lde_net(NP)
+    w, H = net.packed_weights(), net.lstm.hidden_size
+
+    def run(sel):
+        b = Batch(s, ALGO_LDE, pidx[sel], seeds[sel], NP, 60000, 1200, 50)
+        assert b.lde_rollout_is_resident() and b.launch_info()['fixed_geometry'] == (3 if NP == 50 else 6)
+        b.reset()
+        h, c = torch.zeros(len(sel), H, device='cuda'), torch.zeros(len(sel), H, device='cuda')
+        b.lde_rollout(w, H, h, c, 5)
+        st, rw, dn = b.lde_rollout(w, H, h, c, 7)
+        out = {k: v.cpu().numpy() for k, v in b.results().items()}
+        out.update(state=st.cpu().numpy().copy(), h=h.cpu().numpy(), c=c.cpu().numpy(), reward=rw.cpu().numpy().copy())
+        fits = [oracle.split_lde_state(b.read_state(k), NP, 30, 50)['fit'] for k in (0, len(sel) // 2, len(sel) - 1)]
+        b.close()
+        return out, fits
+    full, fits = run(np.arange(B))
+    again, _ = run(np.arange(B))
+    for k in full:
+        assert np.array_equal(full[k], again[k], equal_nan=True), k
+    part, _ = run(np.arange(B)[::4])
+    for k in full:
+        assert np.array_equal(full[k][::4], part[k], equal_nan=True), k
+    assert all(np.all(np.diff(f) >= 0) for f in fits)                  # population kept sorted by fitness
+    st = full['state']
+    assert np.all(st[:, 0] == 0) and np.all((st[:, NP - 1] == 1) | (st[:, NP - 1] == 0))   # min-max normalised
+    assert np.all(st[:, NP:NP + 5].sum(1) == NP)                       # histogram counts every individual
+    assert np.all(full['fes'] == NP * 13) and np.all(full['steps'] == 12)
+    assert np.isfinite(full['h']).all() and np.abs(full['h']).max() <= 1 and np.ptp(full['h']) > 0
+
+
 def test_lde_end_to_end_statistics_match_the_reference():
     """Philox-driven batched LDE rollouts (batched LSTM policy, shipped weights) vs 30 reference runs on three bbob
     problems: final-cost, FEs and return distributions must be statistically indistinguishable."""

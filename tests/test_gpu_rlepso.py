@@ -120,18 +120,23 @@ def test_tape_replay_matches_reference_episodes(env):
     print_ledger(ledger)
 
 
-def test_tape_replay_in_exact_fdr_mode(env, monkeypatch):
-    """MBX_FDR_EXACT=1 (include/mbx.h, mbx_step): the generation kernels whose FDR scan flags near-ties and redoes them with the reference's divisions replay
-    reference episodes like the default kernels do (run-time-geometry instantiations, one launch per generation)."""
-    monkeypatch.setenv('MBX_FDR_EXACT', '1')
+def test_tape_replay_with_the_fast_fdr_scan(env, monkeypatch):
+    """MBX_F_FDR_FAST (include/mbx.h; here through its test override MBX_FDR_FAST=1 in the environment, read when the batch is created): the generation kernels
+    WITHOUT the near-tie flag replay the reference episodes like the default (exact) kernels do -- recorded episodes hold no two candidates within an ulp."""
+    from metabox_amd._abi import F_FDR_FAST
+    from metabox_amd.suite import Batch
+    monkeypatch.setenv('MBX_FDR_FAST', '1')
     TR = load('rlepso_traces.npz')
     TIES = load('rlepso_ties.npz')
     s, ids = env['bbob']
+    probe = Batch(s, 1, np.zeros(1, int), np.zeros(1, np.uint64), NP, MAXFES, MAXFES // 50, 50)
+    assert probe.flags == F_FDR_FAST                               # the override reached the batch's flags
+    probe.close()
     mine = [c for c in (str(c) for c in TR['cases']) if c.split('/')[0] == 'bbob'][::3]
     ledger = []
     ne, w, info = _tape_replay_group(s, ids, TR, TIES, mine, NP, D, MAXFES, ledger)
-    assert info['fixed_geometry'] == 0 and ne + len(ledger) == len(mine)
-    print(f'exact-FDR mode: {ne}/{len(mine)} episodes identical in every generation, worst gbest rel err {w:.2e}')
+    assert info['fixed_geometry'] == 1 and ne + len(ledger) == len(mine)
+    print(f'fast-FDR kernels: {ne}/{len(mine)} episodes identical in every generation, worst gbest rel err {w:.2e}')
 
 
 # (dim, NP) -> the compile-time-geometry instantiation mbx_step must take: 7 = k_rlepso_step<512, 100, 30, 5> (bbob --dim 30, the geometry config 3's

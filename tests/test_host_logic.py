@@ -75,7 +75,7 @@ def test_library_exports_every_symbol_declared_in_the_header():
     for name in declared:
         assert hasattr(lib, name), name
     assert b'gfx950' in lib.mbx_version()
-    assert ctypes.sizeof(_abi.AlgoCfg) == 32 and ctypes.sizeof(_abi.ProblemDesc) == 24 + 10 * 8 + 9 * 8
+    assert ctypes.sizeof(_abi.AlgoCfg) == 36 and _abi.AlgoCfg.flags.offset == 32 and ctypes.sizeof(_abi.ProblemDesc) == 24 + 10 * 8 + 9 * 8
 
 
 def test_product_does_not_import_the_oracle():
