@@ -52,6 +52,10 @@ struct RlLds {
     // KB (NE bytes): rank of the FDR exemplar of every (rank, dimension), carved out of the part of Z that R1 / R2 / COEF leave free
     // (all dead before the evaluator first writes Z)
     uint8_t* KB;
+    // FL (one uint16 per work item of the FDR pass) / FLN: the items whose scan met a near-tie, appended by their owners and settled wave-cooperatively (fdr_settle); same
+    // free part of Z, behind KB
+    uint16_t* FL;
+    int* FLN;
     // NCS [NP]: the cost column the FDR scan reads -- NC with the rows that are bitwise copies of the row one rank up (same cost, same position: particles sitting on
     // the same corner of the box) replaced by a huge value, so that the scan never takes them and never mistakes them for near-ties (rl_mark_copies); same free part of Z
     double* NCS;
@@ -60,8 +64,8 @@ struct RlLds {
 
 __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_t)1; }
 
-// doubles of the move phase's byte table inside Z: KB (NE bytes)
-__host__ __device__ inline int64_t rl_aux_doubles(int NP, int D) { return ((int64_t)NP * D + 15) / 16 * 2; }
+// doubles of the move phase's tables inside Z: KB (NE bytes, padded to 16) | FLN + pad (16 bytes) | FL (up to NE uint16)
+__host__ __device__ inline int64_t rl_aux_doubles(int NP, int D) { const int64_t NE = (int64_t)NP * D; return ((NE + 15) / 16 * 16 + 16 + 2 * NE + 7) / 8; }
 
 // evaluator scratch Z: n*D doubles, at least 2 per thread for the block reductions, and room for the move phase's R1 | R2 | COEF | NCS | tables
 __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
@@ -110,6 +114,8 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D, bool maps
     L.R1 = p; L.R2 = p + P; L.COEF = p + 2 * P;   // per-particle draws and group coefficients: last read in the move phase, Z first written by the evaluator
     L.NCS = p + 2 * P + 96;
     L.KB = (uint8_t*)(p + 3 * P + 96);
+    L.FLN = (int*)(L.KB + ((int64_t)NP * D + 15) / 16 * 16);
+    L.FL = (uint16_t*)(L.FLN + 4);
     p += SC;
     L.M1T = p; p += DD;
     L.M2T = p; p += DD;
@@ -288,6 +294,21 @@ __device__ __forceinline__ float fdr_min3_abs(float m, float x, float y)
     asm("v_min3_f32 %[r], %[m], |%[x]|, |%[y]|" : [r] "=v"(r) : [m] "v"(m), [x] "v"(x), [y] "v"(y));
     return r;
 }
+// Rows of the rank-ordered pbest table that are bitwise copies of the row one rank up -- same cost, same position: particles resting on the same corner of the box (linear
+// slope: most of the swarm, for dozens of generations) -- can never be np.argmin's choice (the copy with the lower index precedes them in rank order and ties with them in
+// every coordinate), but in the scan each of them is an exact tie with the running best: every item above them would be flagged.  The scan therefore reads their cost as 1e300
+// (NCS): a huge positive numerator, never taken, nowhere near a tie.  Called only when equal pbest costs exist in the swarm; thread r owns row r.  The caller synchronises.
+// (Measured and dropped: marking single COORDINATES that repeat the one a rank up -- NaN in the table, readers walk up to the value: the walk in the move phase costs every
+// batch 7 % and a collapsed linear-slope swarm 2.6x.)
+__device__ __forceinline__ void rl_mark_copies(const RlLds& L, int NP, int D, int r)
+{
+    if (r > 0 && r < NP && L.NC[r] == L.NC[r - 1]) {
+        bool same = true;
+        for (int d = 0; d < D && same; ++d) same = L.PB[r * D + d] == L.PB[(r - 1) * D + d];
+        if (same) L.NCS[r] = 1e300;
+    }
+}
+
 // A coordinate of an item whose scan met a near-tie (fdr_exact returned true) is settled by its WAVE, lane = candidate: the reference's own rule (rlepso_optimizer.py:
 // 100-102: rounded quotients, np.argmin = the first minimal one in PARTICLE order) applied to the scan's winner w and to every candidate that is not CLEARLY worse than w.
 //  * dif_k = fma(a_k, b_w, -fl(a_w b_k)) > 2^-49 |a_w b_k| means the exact ratios differ by > 2^-49.2 relative, i.e. the rounded quotient of k is strictly
@@ -452,8 +473,8 @@ __device__ __forceinline__ bool fdr_exact(const RlLds& L, int D, int rk, int d0,
     }
 }
 
-// The same settlement by the item's OWN lane (both coordinates): what a wave gets that holds more than eight flagged items -- a swarm collapsed onto the rounding floor of
-// its costs, where most items are flagged and settling them one after another would take longer than a second pass of every lane.
+// The same settlement by the item's OWN lane (both coordinates): what a swarm that has collapsed onto the rounding floor of its costs gets, where most items are flagged and
+// one wave per coordinate would take longer than a second pass of everybody (fdr_pass switches at 64 flagged items).
 template <int W>
 __device__ __noinline__ void fdr_settle_own(const double* __restrict__ NC, const double* __restrict__ PB, const int* __restrict__ ORDER, int D, int rk, int d0, int nless, int* kb)
 {
@@ -498,75 +519,62 @@ __device__ __noinline__ void fdr_settle_own(const double* __restrict__ NC, const
     }
 }
 
-// Rows of the rank-ordered pbest table that are bitwise copies of the row one rank up -- same cost, same position: particles resting on the same corner of the box (linear
-// slope: most of the swarm, for dozens of generations) -- can never be np.argmin's choice (the copy with the lower index precedes them in rank order and ties with them in
-// every coordinate), but in the scan each of them is an exact tie with the running best: every item above them would be flagged.  The scan therefore reads their cost as 1e300
-// (NCS): a huge positive numerator, never taken, nowhere near a tie.  Called only when equal pbest costs exist in the swarm; thread r owns row r.  The caller synchronises.
-__device__ __forceinline__ void rl_mark_copies(const RlLds& L, int NP, int D, int r)
-{
-    if (r > 0 && r < NP && L.NC[r] == L.NC[r - 1]) {
-        bool same = true;
-        for (int d = 0; d < D && same; ++d) same = L.PB[r * D + d] == L.PB[(r - 1) * D + d];
-        if (same) L.NCS[r] = 1e300;
-    }
-}
-
 // The FDR pass of a generation: every (rank, coordinate pair) item of the population -> KB[rank * D + d] = rank of its exemplar.  Items are visited in
 // pbest-rank order so that the lanes of a wave own particles of similar rank, i.e. similar trip counts; the trip count grows with the rank and wave w of
 // every resident workgroup shares one SIMD, so odd passes run backwards (boustrophedon): each wave pairs a cheap slice of ranks with an expensive one.
-// Items whose scan met a near-tie are settled by their own wave right behind the scan of the pass, lane = candidate (fdr_settle; more than eight flagged lanes in a wave -- a
-// swarm collapsed onto the rounding floor of its costs -- every lane its own: fdr_settle_own).  Ends with the barrier that publishes KB.  Measured and dropped: the flagged items
-// collected in an LDS list and settled by one wave per coordinate behind a barrier (the other waves wait for a ~250-instruction serial chain that, with five workgroups per
-// CU, runs at a fifth of the issue rate: Gallagher F22 +11.6 % over whole episodes against +3.5 % of instructions).  (Measured and dropped: every lane redoing its own flagged item -- 0.1 % of the items stall 6.7 % of
+// Items whose scan met a near-tie are appended to the workgroup's list FL (FLN was zeroed before the ranking barrier) and settled after a barrier: up to 64 of them one wave
+// per coordinate (fdr_settle), more than that -- a swarm collapsed onto the rounding floor of its costs -- every lane its own (fdr_settle_own: a second pass of everybody is
+// then the shorter one).  Ends with the barrier that publishes KB.  Measured and dropped: (a) every lane redoing its own flagged item right away -- 0.1 % of the items stall
+// 6.7 % of the wave-passes for a second scan, +10.4 % per generation against +3.5 % of instructions; (b) the flagged lanes' items settled by their own wave right behind
+// the pass (readlane + fdr_settle): the serial ~250-instruction chain then sits inside the scan of a wave the other three wait for, +4.8 % in the driver window against
+// +3.9 % for the list, +10.6 % against +8.8 % over whole episodes.  (Measured and dropped: every lane redoing its own flagged item -- 0.1 % of the items stall 6.7 % of
 // the wave-passes for a second scan: +10.4 % per generation against +3.5 % of instructions.)
 template <int W, int UN, bool TIE, int THREADS>
 __device__ __forceinline__ void fdr_pass(const RlLds& L, const int* ORDER, const int* NLESS, int NP, int D, int tid, double range, unsigned long long* cnt = nullptr)
 {
     const int DW = D / W, NI = NP * DW;
     const FastDiv fw(DW);
+    uint32_t mine = 0;                                            // bit p: this thread's item of pass p was flagged
     for (int base = 0, pass = 0; base < NI; base += THREADS, ++pass) {
         const int lim = base + THREADS < NI ? base + THREADS : NI;
         const int ps = (pass & 1) ? lim - 1 - tid : base + tid;
-        const bool valid = ps >= base && ps < lim;
-        int rk = 0, d0 = 0, nless = 0, kb[W];
-        bool tie = false;
+        if (ps >= base && ps < lim) {
+            const int rk = fw.div(ps), d0 = W * (ps - rk * DW);
+            int kb[W];
+            const bool tie = fdr_exact<W, UN, TIE>(L, D, rk, d0, NLESS[ORDER[rk]], kb, range);
 #pragma unroll
-        for (int q = 0; q < W; ++q) kb[q] = 0;
-        if (valid) {
-            rk = fw.div(ps); d0 = W * (ps - rk * DW);
-            nless = NLESS[ORDER[rk]];
-            tie = fdr_exact<W, UN, TIE>(L, D, rk, d0, nless, kb, range);
+            for (int q = 0; q < W; ++q) L.KB[rk * D + d0 + q] = (uint8_t)kb[q];
 #ifdef MBX_FDR_COUNT
             if (cnt) { atomicAdd(cnt + 3, 1ull); if (tie) atomicAdd(cnt + 2, 1ull); }       // experiment: how many items does the scan flag? (tools/exp/fdr_flag_rate.py)
 #endif
-        }
-        if constexpr (TIE) {
-            // every lane of the wave is here (the loop bounds are workgroup-uniform): flagged items are settled by the whole wave, one coordinate after the other
-            unsigned long long m = __builtin_amdgcn_ballot_w64(tie);
-            if (m != 0ull) {
-                if (__builtin_popcountll(m) > 8) {
-                    if (tie) fdr_settle_own<W>(L.NC, L.PB, ORDER, D, rk, d0, nless, kb);
-                } else {
-                    const int lane = tid & 63;
-                    while (m != 0ull) {
-                        const int l = (int)__builtin_ctzll(m);
-                        m &= m - 1ull;
-                        const int rk_l = __builtin_amdgcn_readlane(rk, l), d0_l = __builtin_amdgcn_readlane(d0, l), nless_l = __builtin_amdgcn_readlane(nless, l);
-#pragma unroll
-                        for (int q = 0; q < W; ++q) {
-                            const int kbest = fdr_settle(L, ORDER, D, rk_l, d0_l + q, nless_l, __builtin_amdgcn_readlane(kb[q], l), cnt);
-                            if (lane == l) kb[q] = kbest;
-                        }
-                    }
-                }
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int q = 0; q < W; ++q) L.KB[rk * D + d0 + q] = (uint8_t)kb[q];
+            if (TIE && tie) { L.FL[atomicAdd(L.FLN, 1)] = (uint16_t)ps; mine |= 1u << (pass & 31); }
         }
     }
     __syncthreads();
+    if constexpr (TIE) {
+        const int n = *L.FLN;                                     // workgroup-uniform
+        if (n > 0 && (n <= 64 || NI > 32 * THREADS)) {
+            for (int c = tid >> 6; c < W * n; c += THREADS / 64) {      // one wave per flagged COORDINATE
+                const int ps = L.FL[c / W], rk = fw.div(ps), d = W * (ps - rk * DW) + c % W;
+                const int kbest = fdr_settle(L, ORDER, D, rk, d, NLESS[ORDER[rk]], L.KB[rk * D + d], cnt);
+                if ((tid & 63) == 0) L.KB[rk * D + d] = (uint8_t)kbest;
+            }
+            __syncthreads();
+        } else if (n > 0) {                                       // a collapsed swarm: every lane settles its own items (passes <= 32: NP x D / W <= 32 x THREADS)
+            for (int base = 0, pass = 0; mine != 0u; base += THREADS, ++pass, mine >>= 1) {
+                if (!(mine & 1u)) continue;
+                const int lim = base + THREADS < NI ? base + THREADS : NI;
+                const int ps = (pass & 1) ? lim - 1 - tid : base + tid, rk = fw.div(ps), d0 = W * (ps - rk * DW);
+                int kb[W];
+#pragma unroll
+                for (int q = 0; q < W; ++q) kb[q] = L.KB[rk * D + d0 + q];
+                fdr_settle_own<W>(L.NC, L.PB, ORDER, D, rk, d0, NLESS[ORDER[rk]], kb);
+#pragma unroll
+                for (int q = 0; q < W; ++q) L.KB[rk * D + d0 + q] = (uint8_t)kb[q];
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // Velocity / position update of W adjacent coordinates of particle i (rlepso_optimizer.py:179-195); FDR exemplars from KB.
@@ -766,6 +774,7 @@ __global__ __launch_bounds__(THREADS) MBX_RL_WAVES void k_rlepso_step(BatchParam
         L.PNI[i] = S[MBX_RLEPSO_ST_PNI(NP, D) + i];
     }
     if (tid < D) L.GB[tid] = S[MBX_RLEPSO_ST_GBPOS(NP, D) + tid];
+    if (tid == 0) *L.FLN = 0;                                     // list of the FDR scan's near-tie items (fdr_pass): empty before the ranking barrier
     stage_problem<eval_dc(DC), eval_md(DC) == 0>(P, L.eval());
     // __get_coe (:112-132): float32 arithmetic (numpy >= 2 keeps float32 for scalar*python-float), group g
     // reads actions[g*n_group : g*n_group+7]
@@ -1087,7 +1096,7 @@ __device__ __forceinline__ void rl_run_body(ARGS ar)
             if (ar().out.traj_actions) ar().out.traj_actions[((int64_t)g * B + b) * A + tid] = a;
         }
         if (tid < NP) { NLESS[tid] = 0; ORDER[tid] = tid; }
-        if (tid == 0) *EQC = 0;
+        if (tid == 0) { *EQC = 0; *L.FLN = 0; }
         __syncthreads();
         if (tid < G) {                                            // __get_coe (:112-132), float32 like k_rlepso_step
             const float* a = ACT + tid * G;
