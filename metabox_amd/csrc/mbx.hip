@@ -495,7 +495,7 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
             }
         }
         switch (k) {
-        case MBX_KIND_PROTEIN: return 30000;
+        case MBX_KIND_PROTEIN: return 30000 + s->h_problems[pi].n_close;     // the energy walks the n_close atom pairs that can reach the 9 A cut-off (38-64 % of the 4950): most pairs first
         case 21: return 396; case 3: return 329; case 16: return 327; case 23: return 322; case 15: return 315; case 17: return 311;
         case 18: return 311; case 2: return 296; case 4: return 294; case 22: return 290; case 10: return 270; case 11: return 268;
         case 12: return 264; case 1: return 260; case 24: return 255; case 7: return 253; case 14: return 250; case 6: return 245;

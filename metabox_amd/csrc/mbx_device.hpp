@@ -575,9 +575,11 @@ template <int DC = 0, class PT = DevProblem, int PF = 1>
 __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
 {
     const int D = DC ? DC : P.dim, n = P.n_peaks, m3 = 3 * n, tid = threadIdx.x;
-    double* COOR = L.Z;
-    double* P2 = L.Z + ((m3 + 1) & ~1);
-    double* RED = P2 + ((n + 1) & ~1);
+    // one 32-byte record per atom: x | y | z | x^2 + y^2 + z^2.  A pair gathers its two atoms with TWO 16-byte-aligned ds_read_b128 pairs instead of eight scattered
+    // ds_read_b64 (coordinates at a 24-byte stride + the squared norms in an array of their own: 43 % of the LDS-active cycles of k_dq_step were bank conflicts,
+    // profiles/r05_dq_step_pmc.json).  Same LDS footprint (4 n doubles), same arithmetic.
+    double* ATOM = L.Z;
+    double* RED = ATOM + 4 * n;
     const double2* __restrict__ rec = (const double2*)P.pyr;       // [n_pairs][2]: (sqrt(e), q), (r, 0) in pair order (mbx_suite_create)
     const int32_t* __restrict__ pij = (const int32_t*)P.plogw;
     const int n_pairs_all = ((n + 1) >> 1) * (n - 1);
@@ -593,11 +595,12 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
         for (int m = tid; m < m3; m += MBX_NT) {
             double s = 0.;
             for (int k = 0; k < D; ++k) s += (x[k] * L.V0[k]) * P.py[(size_t)k * m3 + m];
-            COOR[m] = s + P.pc[m];
+            const int i = m / 3;
+            ATOM[4 * i + (m - 3 * i)] = s + P.pc[m];
         }
         __syncthreads();
         for (int i = tid; i < n; i += MBX_NT)
-            P2[i] = COOR[3 * i] * COOR[3 * i] + COOR[3 * i + 1] * COOR[3 * i + 1] + COOR[3 * i + 2] * COOR[3 * i + 2];
+            ATOM[4 * i + 3] = ATOM[4 * i] * ATOM[4 * i] + ATOM[4 * i + 1] * ATOM[4 * i + 1] + ATOM[4 * i + 2] * ATOM[4 * i + 2];
         __syncthreads();
         double acc = 0.;
         for (int t0 = tid; t0 < n_pairs; t0 += PF * MBX_NT) {
@@ -614,8 +617,10 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
                 tcl[u] = tc;
                 ok[u] = t < n_pairs && w >= 0;
                 const int i = w < 0 ? 0 : (w & 0xffff), j = w < 0 ? 1 : (w >> 16);
-                const double p3 = COOR[3 * i] * COOR[3 * j] + COOR[3 * i + 1] * COOR[3 * j + 1] + COOR[3 * i + 2] * COOR[3 * j + 2];
-                s[u] = P2[i] - 2 * p3 + P2[j] + 0.01;              // >= 0.01 up to rounding: always a positive normal number
+                const double2 ai0 = *(const double2*)(ATOM + 4 * i), ai1 = *(const double2*)(ATOM + 4 * i + 2);      // (x, y), (z, |.|^2) of atom i
+                const double2 aj0 = *(const double2*)(ATOM + 4 * j), aj1 = *(const double2*)(ATOM + 4 * j + 2);
+                const double p3 = ai0.x * aj0.x + ai0.y * aj0.y + ai1.x * aj1.x;
+                s[u] = ai1.y - 2 * p3 + aj1.y + 0.01;              // >= 0.01 up to rounding: always a positive normal number
                 close = close || (ok[u] && s[u] < 81.01);
             }
             // The pairs come in ascending order of their distance in coor_init (mbx_suite_create) and a move displaces a pair by a fraction of an
