@@ -539,6 +539,7 @@ def main():
                          '(~2 s of timed windows), the line reports the median repeat')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the configs 3 / 4 / 5 legs (other_configs)')
+    ap.add_argument('--no-fdr-fast', action='store_true', help='skip the side leg that times the MBX_F_FDR_FAST kernels on the same window (roofline.fdr_fast_ms_per_step); kernel traces of the headline alone')
     ap.add_argument('--no-pmc', action='store_true', help='do not collect roofline.traffic in this run (two rocprofv3 --pmc child passes, ~40 s); use the newest committed profile')
     ap.add_argument('--functions', default='all24',
                     help="all24 (default: every bbob function round-robin), train18 (the bbob-easy train split), or a comma list of "
@@ -840,7 +841,7 @@ def main():
         # side field: the same window on a batch created with MBX_F_FDR_FAST (the cross-multiplied FDR scan without the near-tie flag / settle stage; the headline runs the
         # exact default).  Same instances, same launches, wall time between synchronize pairs like the headline's repeats; right behind them (same clock regime).
         fdr_fast = None
-        if resident and world == 1 and not os.environ.get('MBX_BENCH_CHILD'):
+        if resident and world == 1 and not args.no_fdr_fast and not os.environ.get('MBX_BENCH_CHILD'):
             try:
                 from metabox_amd._abi import ALGO_RLEPSO, F_FDR_FAST
                 from metabox_amd.suite import Batch
@@ -961,7 +962,7 @@ def main():
                                             f'(every instance live): {traffic_note}; scaled to the env-steps of an average launch of this run') if traffic_in_run else
                                            ((f'profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to this '
                                              f"run's live instances (not collected during this run" + (f': {traffic_note}' if traffic_note else '') + ')') if traffic_src else None),
-                         'kernel': 'k_rlepso_run<256, 100, 10, 5>' if resident else 'k_rlepso_step<256, 100, 10, 5>',
+                         'kernel': 'k_rlepso_run<256, 100, 10, 5, true>' if resident else 'k_rlepso_step<256, 100, 10, 5, true>',
                          # FDR exemplar: exact by default (index = the reference's np.argmin of rounded quotients on any input); the MBX_F_FDR_FAST kernels on the same window
                          'fdr': 'exact (default flags)', 'fdr_fast_ms_per_step': fdr_fast,
                          'algorithmic_bytes_per_launch': bytes_per_launch,

@@ -284,7 +284,7 @@ int mbx_rlepso_act_step(mbx_batch* b, const float* d_table, float* d_actions_out
  *   d_traj_done    [n_gens, n_instances] uint8             is_done (1 after termination)
  * d_state_out / d_done_out [n_instances]: state / is_done after the last executed generation; d_reward_out [n_instances]: SUM of
  * the rewards of the executed generations (like mbx_rlpso_rollout).
- * The compile-time geometries (NP 100 / D 10, NP 100 / D 12 = protein docking, NP 100 / D 30 and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
+ * The compile-time geometries (NP 100 at D 10 / D 12 = protein docking / D 30 / D 40, and NP 128 / D 40, 5 groups) run the resident kernel; any other geometry is stepped
  * with one mbx_rlepso_act_step launch per generation behind the same interface (MBX_F_ROLLOUT_PER_GENERATION in the batch's flags
  * forces that route).  mbx_rlepso_rollout_resident tells which route a batch takes: 1 = one resident launch per call,
  * 0 = one launch per generation (2 n_gens launches with d_reward_out).  Neither route allocates or reads the environment at call time. */

@@ -43,10 +43,10 @@ class ReplayBuffer:
 
 def save_class(dir, file_name, saving_class):
     """Pickle `saving_class` to ``<dir><file_name>.pkl`` (dir is used as a string prefix, like the reference does).
-    With torch.distributed initialised: an agent whose training is data-parallel and gradient-synchronised (its ``train_batch`` sets
-    ``_mbx_replicated``: every rank holds the same parameters and reaches a checkpoint threshold at the same optimizer step) is written by rank 0
-    only; any other object (per-rank state: a tabular Q-function, a replay buffer, a train_episode loop that runs under a process group) is
-    written by EVERY rank, ranks > 0 under ``<file_name>.rank<r>.pkl``, so nothing is dropped silently.  Writes go to a temporary file that is
+    With torch.distributed initialised: an agent class that declares ``_mbx_replicated = True`` (RLEPSO / LDE / GLEET / DE-DDQN: under a process group
+    ``Trainer.train`` only ever drives their data-parallel, gradient-synchronised ``train_batch``, so every rank holds the same parameters and reaches a
+    checkpoint threshold at the same optimizer step) is written by rank 0 only; any other object (per-rank state: a tabular Q-function, a replay buffer) is
+    written by EVERY rank, ranks > 0 under ``<file_name>.rank<r>.pkl``.  Writes go to a temporary file that is
     renamed over the target: a reader never sees a half-written pickle."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:

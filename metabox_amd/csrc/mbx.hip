@@ -1,5 +1,5 @@
 // mbx.hip — libmbx.so: kernels' launch code and the C-ABI of include/mbx.h.
-// Build: make -C metabox_amd/csrc  (three translation units: this file, mbx_run_rlepso.hip, mbx_run_lde.hip); one file: hipcc ... -DMBX_SINGLE_TU -shared mbx.hip -o libmbx.so
+// Build: make -C metabox_amd/csrc  (six translation units: this file, mbx_run_rlepso*.hip, mbx_run_lde.hip); one file: hipcc ... -DMBX_SINGLE_TU -shared mbx.hip -o libmbx.so
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -95,7 +95,7 @@ struct mbx_batch {
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
     int fixed_geometry = 0;      // compile-time-geometry instantiation of the generation kernel for the BASELINE.json configs: 1 = RLEPSO NP 100 / D 10 /
-                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10, 6 = LDE NP 100 / D 30 (config 3 as written), 7 = RLEPSO NP 100 / D 30 / 5 groups (bbob --dim 30); 0 = geometry read from the batch
+                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10, 6 = LDE NP 100 / D 30 (config 3 as written), 7 = RLEPSO NP 100 / D 30 / 5 groups (bbob --dim 30), 8 / 10 = RLEPSO NP 100 at D 12 / D 40 (resident kernel only), 9 = LDE NP 50 / D 10 (resident kernel only); 0 = geometry read from the batch
 };
 
 // per-algorithm geometry
@@ -557,10 +557,11 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg_in, const 
             if (b->threads == 1024 && cfg->np == 128 && cfg->dim == 40) b->fixed_geometry = 2;
             if (b->threads == 512 && cfg->np == 100 && cfg->dim == 30) b->fixed_geometry = 7;
             if (b->threads == kThreads && cfg->np == 100 && cfg->dim == 12) b->fixed_geometry = 8;     // protein docking: resident rollout only, the one-generation kernel stays the run-time-geometry one
+            if (b->threads == 1024 && cfg->np == 100 && cfg->dim == 40) b->fixed_geometry = 10;        // the reference's own NP at bbob --dim 40 (config.py:74, rlepso_optimizer.py:11): resident rollout only, likewise
         }
         // the fast FDR scan exists for the run-time-geometry kernels and the geometries of BASELINE configs 2 / 5; the other compile-time geometries keep the exact scan on
         // BOTH routes (so that the two stay bit-identical), and the batch's effective flags say so
-        if (cfg->algo != MBX_ALGO_RLEPSO || b->fixed_geometry == 7 || b->fixed_geometry == 8) b->cfg.flags &= ~MBX_F_FDR_FAST;
+        if (cfg->algo != MBX_ALGO_RLEPSO || b->fixed_geometry == 7 || b->fixed_geometry == 8 || b->fixed_geometry == 10) b->cfg.flags &= ~MBX_F_FDR_FAST;
         b->fdr_fast = (b->cfg.flags & MBX_F_FDR_FAST) != 0;
         // config 3 (LDE, NP 50 / D 30, 512 threads) and config 4 (DE-DDQN, NP 100 / D 12)
         if (cfg->algo == MBX_ALGO_LDE && b->threads == 512 && cfg->np == 50 && cfg->dim == 30 && !generic) b->fixed_geometry = 3;
@@ -605,7 +606,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg_in, const 
         MBX_RL_LDS(k_rlepso_step<512, 100, 30, 5, true>);
         MBX_RL_LDS(k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5, true>); MBX_RL_LDS(k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5, false>);
         MBX_RL_LDS(k_rlepso_run<1024, 128, 40, 5, true>); MBX_RL_LDS(k_rlepso_run<1024, 128, 40, 5, false>);
-        MBX_RL_LDS(k_rlepso_run<512, 100, 30, 5, true>); MBX_RL_LDS(k_rlepso_run<256, 100, 12, 5, true>);
+        MBX_RL_LDS(k_rlepso_run<512, 100, 30, 5, true>); MBX_RL_LDS(k_rlepso_run<256, 100, 12, 5, true>); MBX_RL_LDS(k_rlepso_run<1024, 100, 40, 5, true>);
 #undef MBX_RL_LDS
     } else if (cfg->algo == MBX_ALGO_LDE) {
         {   // mbx_lde_rollout: per-generation rewards / actions of the host-loop route
@@ -942,7 +943,7 @@ extern "C" int mbx_rlepso_rollout_resident(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "mbx_rlepso_rollout_resident: null batch");
     if (b->cfg.algo != MBX_ALGO_RLEPSO) return 0;
-    return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7 || b->fixed_geometry == 8) && !b->rollout_per_generation ? 1 : 0;
+    return (b->fixed_geometry == 1 || b->fixed_geometry == 2 || b->fixed_geometry == 7 || b->fixed_geometry == 8 || b->fixed_geometry == 10) && !b->rollout_per_generation ? 1 : 0;
 }
 
 __global__ void k_sum_rewards(double* __restrict__ acc, const double* __restrict__ r, int n, int first)
@@ -960,6 +961,7 @@ static int launch_rlepso_run(mbx_batch* b, const float* d_table, int rows, int n
     else if (b->fixed_geometry == 2) { if (b->fdr_fast) MBX_RUN_LAUNCH(1024, 128, 40, 5, false); else MBX_RUN_LAUNCH(1024, 128, 40, 5, true); }
     else if (b->fixed_geometry == 7) MBX_RUN_LAUNCH(512, 100, 30, 5, true);
     else if (b->fixed_geometry == 8) MBX_RUN_LAUNCH(256, 100, 12, 5, true);
+    else if (b->fixed_geometry == 10) MBX_RUN_LAUNCH(1024, 100, 40, 5, true);
     else return fail(MBX_E_UNSUPPORTED, "k_rlepso_run: no instantiation for this geometry");
 #undef MBX_RUN_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -10,6 +10,7 @@
     X template __global__ void k_rlepso_run<512, 100, 30, 5, true>(BatchParams, const float*, int, int, RunOut);                \
     X template __global__ void k_rlepso_run<256, 100, 12, 5, true>(BatchParams, const float*, int, int, RunOut);      /* protein docking (src/config.py:86-90: dim 12), any-kind body */
 #define MBX_RUN_RLEPSO_C5(X) X template __global__ void k_rlepso_run<1024, 128, 40, 5, true>(BatchParams, const float*, int, int, RunOut);
+#define MBX_RUN_RLEPSO_D40(X) X template __global__ void k_rlepso_run<1024, 100, 40, 5, true>(BatchParams, const float*, int, int, RunOut);      /* the reference's NP at --dim 40 */
 #define MBX_RUN_RLEPSO_FAST(X)                                                                           \
     X template __global__ void k_rlepso_run<MBX_RUN10_THREADS, 100, 10, 5, false>(BatchParams, const float*, int, int, RunOut); \
     X template __global__ void k_rlepso_run<1024, 128, 40, 5, false>(BatchParams, const float*, int, int, RunOut);
@@ -17,6 +18,7 @@
 namespace mbx {
 MBX_RUN_RLEPSO_EXACT(extern)
 MBX_RUN_RLEPSO_C5(extern)
+MBX_RUN_RLEPSO_D40(extern)
 MBX_RUN_RLEPSO_FAST(extern)
 extern template __global__ void k_lde_run<100, 30>(LdeRunArgs);
 extern template __global__ void k_lde_run<50, 30>(LdeRunArgs);

@@ -82,6 +82,13 @@ class Trainer(object):
     def train(self, max_epochs=None):
         if getattr(self.config, 'train_batch_size', 1) > 1 and hasattr(self.agent, 'train_batch'):
             return self.train_batched(max_epochs)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # train_episode is the reference's one-instance loop (src/trainer.py:142-187): nothing synchronises the ranks' parameters there, while the agents'
+            # checkpoints are written by rank 0 only (agent/utils.py: save_class, `_mbx_replicated`).  Under a process group the data-parallel path is the only one.
+            if hasattr(self.agent, 'train_batch'):
+                return self.train_batched(max_epochs)
+            raise RuntimeError('Trainer.train: the one-instance train_episode loop is not synchronised across ranks; run it in a single process or use an agent with train_batch')
         exceed, epoch = False, 0
         cost_record = {str(p): [] for p in self.train_set.data}
         normalizer_record = {str(p): [] for p in self.train_set.data}

@@ -140,8 +140,8 @@ def test_tape_replay_with_the_fast_fdr_scan(env, monkeypatch):
 
 
 # (dim, NP) -> the compile-time-geometry instantiation mbx_step must take: 7 = k_rlepso_step<512, 100, 30, 5> (bbob --dim 30, the geometry config 3's
-# suite runs RLEPSO at), 2 = k_rlepso_step<1024, 128, 40, 5> (BASELINE config 5), 0 = the run-time-geometry kernel (NP 100 at D 40: the reference as shipped)
-HD_GEOMETRIES = {(30, 100): 7, (40, 100): 0, (40, 128): 2}
+# suite runs RLEPSO at), 2 = k_rlepso_step<1024, 128, 40, 5> (BASELINE config 5), 10 = NP 100 at D 40 (the reference as shipped: resident rollout kernel of its own, mbx_step on the run-time-geometry kernel)
+HD_GEOMETRIES = {(30, 100): 7, (40, 100): 10, (40, 128): 2}
 
 
 @pytest.mark.parametrize('dim,np_', sorted(HD_GEOMETRIES))
@@ -448,7 +448,7 @@ def test_resident_rollout_equals_one_launch_per_generation():
     assert (r['fes'] >= 20000).any()
 
 
-@pytest.mark.parametrize('dim,np_,chunks', [(40, 128, (1, 90, 233, 300)), (30, 100, (250, 350))])
+@pytest.mark.parametrize('dim,np_,chunks', [(40, 128, (1, 90, 233, 300)), (30, 100, (250, 350)), (40, 100, (3, 400, 400))])
 def test_resident_rollout_equals_one_launch_per_generation_whole_episodes_config_5_and_3_geometries(dim, np_, chunks):
     """The same bit-for-bit identity over WHOLE episodes at the geometries of BASELINE config 5 (k_rlepso_run<1024, 128, 40, 5>: one out-of-line body per
     function kind) and of bbob --dim 30 (k_rlepso_run<512, 100, 30, 5>), every function of both suites.  Together with the reference episodes replayed

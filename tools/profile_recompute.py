@@ -15,15 +15,15 @@ for l in open(os.path.join(d, 'trace.log'), errors='replace'):
 assert line is not None, 'no bench line in trace.log'
 row = None
 for r in csv.DictReader(open(os.path.join(d, 'kernel_stats.csv'))):
-    if 'k_rlepso_run<256, 100, 10, 5>' in r['Name']:
+    if 'k_rlepso_run<256, 100, 10, 5, true>' in r['Name']:              # the exact-FDR (default) resident kernel
         row = r
-assert row is not None, 'k_rlepso_run<256, 100, 10, 5> not in kernel_stats.csv'
+assert row is not None, 'k_rlepso_run<256, 100, 10, 5, true> not in kernel_stats.csv'
 calls, total_ns = int(row['Calls']), float(row['TotalDurationNs'])
 R, K = int(line['repeats']), int(line['steps'])
 env_steps = float(line['config']['live_env_steps']) * R                      # the reported repeat's live env-steps x repeats (episodes differ by < 1 %)
 per_gen_us = total_ns / (R * K) / 1e3
 frac = 54057.0 * env_steps / (total_ns * 1e-9) / 8e12
 rl = line['roofline']
-print(f"* recomputation from the trace (`{os.path.basename(d)}`): `k_rlepso_run<256, 100, 10, 5>` {calls} calls, {total_ns / 1e6:.3f} ms in total = {R} repeats x {K} generations "
+print(f"* recomputation from the trace (`{os.path.basename(d)}`): `k_rlepso_run<256, 100, 10, 5, true>` {calls} calls, {total_ns / 1e6:.3f} ms in total = {R} repeats x {K} generations "
       f"-> **{per_gen_us:.1f} us per generation** under the profiler (bench line of the same run: {rl['avg_generation_us']:.1f} us by HIP events); "
       f"54 057 B x {env_steps:.0f} env-steps / {total_ns / 1e6:.3f} ms / 8e12 B/s = **{frac:.4f}** (bench line of the same run: {rl['frac']:.4f}).")
