@@ -202,7 +202,8 @@ int64_t mbx_instance_state_doubles(const mbx_batch* b);
 int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out);
 /* The inverse: overwrite one instance's state block from the host (host_in: mbx_instance_state_doubles doubles, same layout).  What a caller of the
  * reference does with `copy.deepcopy(env)` / a pickled optimizer (src/tester.py, src/agent/utils.py:44-48 save_class): snapshot an instance and
- * resume it later -- and what the tests use to hand the generation kernels a crafted swarm (tests/test_fdr_ties.py).  Synchronises the device. */
+ * resume it later -- and what the tests use to hand the generation kernels a crafted swarm (tests/test_fdr_ties.py).  Synchronises the device.
+ * RLEPSO: a block whose pbest positions leave the problem's box [lb, ub] is refused (MBX_E_ARG): reset / step never produce one, and the FDR scan's near-tie flag relies on it. */
 int mbx_debug_write_state(mbx_batch* b, int instance, const double* host_in);
 
 /* The RLEPSO / RL-PSO actor as ONE kernel launch per step (src/agent/rlepso_agent.py:9-47 Actor.forward without

@@ -75,6 +75,7 @@ struct mbx_batch {
     mbx_algo_cfg cfg{};
     int B = 0;
     int32_t* d_problem_idx = nullptr;
+    std::vector<int32_t> h_problem_idx;    // host copy (mbx_debug_write_state validates an injected block against its problem's box)
     uint64_t* d_seeds = nullptr;
     double* d_state = nullptr;
     int32_t* d_order = nullptr;
@@ -581,6 +582,7 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg_in, const 
     HIP_TRY(hipMalloc(&b->d_seeds, n_instances * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&b->d_state, (size_t)n_instances * b->state_stride * sizeof(double)));
     HIP_TRY(hipMemcpy(b->d_problem_idx, problem_idx, n_instances * sizeof(int32_t), hipMemcpyHostToDevice));
+    b->h_problem_idx.assign(problem_idx, problem_idx + n_instances);
     HIP_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d_state, 0, (size_t)n_instances * b->state_stride * sizeof(double)));
     if (int rc = upload_launch_order(b, problem_idx)) return rc;
@@ -667,6 +669,7 @@ extern "C" int mbx_batch_rebind(mbx_batch* b, const int32_t* problem_idx, const 
         if (problem_idx[i] < 0 || problem_idx[i] >= b->suite->n) return fail(MBX_E_ARG, "problem_idx[%d]=%d out of range", i, problem_idx[i]);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(b->d_problem_idx, problem_idx, b->B * sizeof(int32_t), hipMemcpyHostToDevice));
+    b->h_problem_idx.assign(problem_idx, problem_idx + b->B);
     HIP_TRY(hipMemcpy(b->d_seeds, seeds, b->B * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (int rc = upload_launch_order(b, problem_idx)) return rc;
     hipLaunchKernelGGL(k_init_state, dim3((b->B + 255) / 256), dim3(256), 0, nullptr, b->d_state, b->state_stride, b->sc_off, b->B);   // episode counter back to -1
@@ -1249,6 +1252,15 @@ extern "C" int mbx_debug_read_state(mbx_batch* b, int instance, double* host_out
 extern "C" int mbx_debug_write_state(mbx_batch* b, int instance, const double* host_in)
 {
     if (!b || instance < 0 || instance >= b->B || !host_in) return fail(MBX_E_ARG, "mbx_debug_write_state: bad arguments");
+    if (b->cfg.algo == MBX_ALGO_RLEPSO) {
+        // the near-tie flag of the FDR scan bounds every denominator |p_jd - p_id| + 1e-5 by the box (csrc/mbx_rlepso.hpp: fdr_exact): pbest positions outside it -- which
+        // reset / step never produce -- would void the exactness of the exemplar index, so such a block is refused
+        const DevProblem& P = b->suite->h_problems[b->h_problem_idx[instance]];
+        const double* pb = host_in + MBX_RLEPSO_ST_PBPOS(b->cfg.np, b->cfg.dim);
+        for (int e = 0; e < b->cfg.np * b->cfg.dim; ++e)
+            if (!(pb[e] >= P.lb && pb[e] <= P.ub))
+                return fail(MBX_E_ARG, "mbx_debug_write_state: pbest position %d (%g) lies outside the problem's box [%g, %g]", e, pb[e], P.lb, P.ub);
+    }
     HIP_TRY(hipDeviceSynchronize());
     const int64_t n = mbx_instance_state_doubles(b);
     HIP_TRY(hipMemcpy(b->d_state + (int64_t)instance * b->state_stride, host_in, n * sizeof(double), hipMemcpyHostToDevice));

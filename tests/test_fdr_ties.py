@@ -292,6 +292,15 @@ def test_two_batches_with_different_flags_coexist_in_one_process():
     assert bad[id(exact)] == 0 and bad[id(generic)] == 0 and bad[id(pergen)] == 0 and bad[id(fast)] > 0, bad
     with pytest.raises(Exception):
         mk(1 << 9)                                                    # unknown flag bits are an argument error, not ignored
+    # the near-tie flag bounds the denominators by the box: a block whose pbest positions leave it is refused, not silently mis-flagged
+    probe = mk(0)
+    probe.reset()
+    torch.cuda.synchronize()
+    f, P = cases[0][0], cases[0][1].copy()
+    P[3, 2] = 5.5
+    with pytest.raises(Exception, match='outside'):
+        probe.write_state(0, state_block(probe.read_state(0), f, P))
+    probe.close()
 
 
 @pytest.mark.gpu

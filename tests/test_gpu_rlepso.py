@@ -896,3 +896,35 @@ def test_snapshot_and_resume_of_instances_is_bit_exact(env):
         assert torch.equal(t1['reward'][g], rb) and torch.equal(t1['done'][g], db), g
     assert all(np.array_equal(b.read_state(k), end1[k], equal_nan=True) for k in range(B))
     b.close()
+
+
+def test_launch_clock_slots_report_the_shader_clock(env):
+    """mbx_debug_clock_slots (include/mbx.h): while a slot pair is attached, every workgroup of the resident kernel adds its own lifetime in shader cycles (s_memtime) and in
+    100 MHz ticks (s_memrealtime) to the two words; their ratio is the clock the launch ran at.  Results are unaffected; detached, nothing is written."""
+    import ctypes as C
+    from metabox_amd.suite import Batch
+    s, ids = env['bbob']
+    B = 512
+    pidx, seeds = np.arange(B) % len(ids), np.arange(B, dtype=np.uint64) + 9
+    table = torch.rand(MAXFES + 2 * NP + 1, 2, 35, generator=torch.Generator().manual_seed(2)).cuda()
+    table[:, 1] = 0.05 + 0.2 * table[:, 1]
+    table = table.contiguous()
+    a = Batch(s, 1, pidx, seeds, NP, MAXFES, MAXFES // 50, 50)
+    b = Batch(s, 1, pidx, seeds, NP, MAXFES, MAXFES // 50, 50)
+    slots = torch.zeros(2, dtype=torch.int64, device='cuda')
+    a.reset(); b.reset()
+    a.lib.mbx_debug_clock_slots(a._h, C.c_void_p(slots.data_ptr()))
+    a.rlepso_rollout(table, 12)
+    a.lib.mbx_debug_clock_slots(a._h, None)
+    b.rlepso_rollout(table, 12)
+    torch.cuda.synchronize()
+    cyc, ticks = (int(x) for x in slots.cpu())
+    ghz = cyc / (ticks * 10.)
+    assert ticks > B and 1.2 < ghz <= 2.45, (cyc, ticks, ghz)                     # MI355X: <= 2.4 GHz
+    before = slots.clone()
+    a.rlepso_rollout(table, 3); b.rlepso_rollout(table, 3)                        # detached: the words stay as they are
+    torch.cuda.synchronize()
+    assert torch.equal(slots, before)
+    for k in range(0, B, 37):
+        assert np.array_equal(a.read_state(k), b.read_state(k), equal_nan=True), k
+    a.close(); b.close()
