@@ -44,20 +44,23 @@ def quotient(f, P, i, m, d):
     return (f[m] - f[i]) / (np.abs(P[m, d] - P[i, d]) + 1e-5)
 
 
-def craft_swarm(rs, target_ulps, NP=NP, D=D):
+def craft_swarm(rs, target_ulps, NP=NP, D=D, three=False):
     """pbest costs f [NP], pbest positions P [NP, D], query particle q and the pair (j, k) whose quotients towards q are `target_ulps[d]` ulp apart in
-    dimension d (as close as the +-24-ulp neighbourhood of the two coordinates allows); every other candidate's quotient is far weaker."""
-    q, j, k = rs.choice(NP, 3, replace=False)
+    dimension d (as close as the +-24-ulp neighbourhood of the two coordinates allows); every other candidate's quotient is far weaker.  three: a third candidate l is
+    tuned against j the same way (a three-way near-tie: the scan's running best changes hands inside the band)."""
+    q, j, k, l = rs.choice(NP, 4, replace=False)
     while q >= 5 * (NP // 5):                             # particles beyond the last full group move with zero coefficients (rlepso_optimizer.py:117-126): nothing to decode
-        q, j, k = rs.choice(NP, 3, replace=False)
+        q, j, k, l = rs.choice(NP, 4, replace=False)
     f = 1000. - rs.uniform(1., 40., NP)
     f[q] = 1000.
     f[j] = 1000. - 100. * (1 + rs.uniform())
     f[k] = 1000. - 50. * (1 + rs.uniform())
+    if three:
+        f[l] = 1000. - 75. * (1 + rs.uniform())
     P = rs.uniform(-5, 5, (NP, D))
     P[q] = rs.uniform(-3, 3, D)
     for m in range(NP):                                   # everybody else stays >= 1 away from the query particle in every dimension
-        if m in (q, j, k):
+        if m in (q, j, k) or (three and m == l):
             continue
         bad = np.abs(P[m] - P[q]) < 1.
         P[m, bad] = P[q, bad] + np.where(rs.uniform(size=bad.sum()) < 0.5, -1, 1) * rs.uniform(1., 1.9, bad.sum())
@@ -79,6 +82,13 @@ def craft_swarm(rs, target_ulps, NP=NP, D=D):
         a, b = np.unravel_index(np.argmin(np.abs(dist - target_ulps[d])), dist.shape)
         P[j, d], P[k, d] = xj[a], xk[b]
         got[d] = ulps_apart(quotient(f, P, q, j, d), quotient(f, P, q, k, d))
+        if three:                                         # l against the (now fixed) j: its coordinate alone is searched, +-2000 ulp
+            al = f[l] - f[q]
+            xl0 = P[q, d] + rs.choice([-1., 1.]) * (al * (np.abs(P[j, d] - P[q, d]) + 1e-5) / aj - 1e-5)
+            xl = xl0 + np.arange(-2000, 2001) * np.spacing(xl0)
+            ql = al / (np.abs(xl - P[q, d]) + 1e-5)
+            dl = np.abs(ql.view(np.int64) - np.float64(quotient(f, P, q, j, d)).view(np.int64))
+            P[l, d] = xl[np.argmin(np.abs(dl - target_ulps[(d + 1) % D]))]
     return f, P, (q, j, k), got
 
 
@@ -132,10 +142,10 @@ def decode_agreement(vel_after, f, P, targets, u_fdr=U_FDR):
     return vel_after.reshape(NP, D) == want
 
 
-def crafted_cases(n, seed=0, NP=NP, D=D):
+def crafted_cases(n, seed=0, NP=NP, D=D, three=False):
     rs = np.random.RandomState(seed)
     menu = np.tile(np.array([0, 0, 1, 1, 2, 2, 3, 4, 8, 64]), D // 10)
-    return [craft_swarm(rs, rs.permutation(menu), NP, D) for _ in range(n)]
+    return [craft_swarm(rs, rs.permutation(menu), NP, D, three) for _ in range(n)]
 
 
 def test_oracle_fdr_is_the_reference_formula_on_adversarial_swarms():
@@ -143,14 +153,14 @@ def test_oracle_fdr_is_the_reference_formula_on_adversarial_swarms():
     cfg = oracle.make_cfg(1, NP, D, MAXFES, LOGI, NLOG)
     tape = replay_tape()
     hist = {}
-    for f, P, (q, j, k), ulps in crafted_cases(60):
+    for f, P, (q, j, k), ulps in crafted_cases(60) + crafted_cases(30, seed=11, three=True):
         o = oracle.RlepsoOracle(p.desc(), p.bias, cfg, seed=1)
         o.reset()
         o.set_state(state_block(o.state(), f, P))
         o.step(ACTION, tape)
         vel = oracle.split_rlepso_state(o.state(), NP, D, NLOG)['vel']
         tg = reference_targets(f, P)
-        assert set(tg[q]) <= {j, k}, 'the crafted pair must decide the query particle'
+        assert len(set(tg[q]) - {j, k}) <= 1, 'the crafted pair (or triple) must decide the query particle'
         agree = decode_agreement(vel, f, P, tg)
         assert agree.all(), np.argwhere(~agree)[:4]
         for d in range(D):
@@ -228,11 +238,11 @@ def test_hip_fdr_is_the_reference_index_on_adversarial_swarms(np_, dim, geometry
     """DEFAULT flags: the exemplar of every (particle, dimension) item equals np.argmin of the reference's rounded quotients -- 0 disagreements in every bucket, on the
     one-generation kernels AND on the resident rollout kernels the product and the bench run, at the geometries of BASELINE configs 2 and 5.
     src/optimizer/rlepso_optimizer.py:97-109."""
-    cases = crafted_cases(512 if dim == 10 else 96, seed=dim, NP=np_, D=dim)
+    cases = crafted_cases(384 if dim == 10 else 72, seed=dim, NP=np_, D=dim) + crafted_cases(128 if dim == 10 else 24, seed=dim + 1, NP=np_, D=dim, three=True)
     buckets, others, flags, info, resident = _run_crafted(cases, np_, dim, route, 0)
     assert flags == 0 and info['fixed_geometry'] == geometry and resident, (flags, info, resident)       # exact mode keeps the compile-time geometry and the resident route
     _print_buckets(f'FDR exemplar, default (exact) kernels, {route}, NP {np_} / D {dim}, vs reference formula (rounded quotients, np.argmin) on crafted near-ties:', buckets, others)
-    assert buckets[0][0] >= 400 and buckets[1][0] >= 400, buckets
+    assert buckets[0][0] >= 300 and buckets[1][0] >= 300, buckets
     assert all(v[1] == 0 for v in buckets.values()) and others[1] == 0, (buckets, others)
 
 
