@@ -497,10 +497,11 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
         }
         switch (k) {
         case MBX_KIND_PROTEIN: return 30000 + s->h_problems[pi].n_close;     // the energy walks the n_close atom pairs that can reach the 9 A cut-off (38-64 % of the 4950): most pairs first
-        case 21: return 396; case 3: return 329; case 16: return 327; case 23: return 322; case 15: return 315; case 17: return 311;
-        case 18: return 311; case 2: return 296; case 4: return 294; case 22: return 290; case 10: return 270; case 11: return 268;
-        case 12: return 264; case 1: return 260; case 24: return 255; case 7: return 253; case 14: return 250; case 6: return 245;
-        case 19: return 244; case 20: return 243; case 8: return 231; case 9: return 228; case 13: return 223; case 5: return 200;
+        // (round 6: ns per instance-generation x 10 of the exact-FDR resident kernel over generations 3-152 of one-function batches, tools/kbench_costs.py --gens 150)
+        case 21: return 416; case 3: return 332; case 15: return 326; case 16: return 325; case 22: return 323; case 23: return 316;
+        case 18: return 310; case 17: return 310; case 4: return 309; case 2: return 282; case 12: return 282; case 11: return 275;
+        case 10: return 270; case 6: return 254; case 14: return 252; case 1: return 251; case 20: return 250; case 19: return 247;
+        case 24: return 246; case 8: return 244; case 13: return 239; case 7: return 237; case 9: return 233; case 5: return 153;
         default: return 276;
         }
     };
