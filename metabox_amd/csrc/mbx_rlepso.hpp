@@ -527,8 +527,7 @@ __device__ __noinline__ void fdr_settle_own(const double* __restrict__ NC, const
 // then the shorter one).  Ends with the barrier that publishes KB.  Measured and dropped: (a) every lane redoing its own flagged item right away -- 0.1 % of the items stall
 // 6.7 % of the wave-passes for a second scan, +10.4 % per generation against +3.5 % of instructions; (b) the flagged lanes' items settled by their own wave right behind
 // the pass (readlane + fdr_settle): the serial ~250-instruction chain then sits inside the scan of a wave the other three wait for, +4.8 % in the driver window against
-// +3.9 % for the list, +10.6 % against +8.8 % over whole episodes.  (Measured and dropped: every lane redoing its own flagged item -- 0.1 % of the items stall 6.7 % of
-// the wave-passes for a second scan: +10.4 % per generation against +3.5 % of instructions.)
+// +3.9 % for the list, +10.6 % against +8.8 % over whole episodes.
 template <int W, int UN, bool TIE, int THREADS>
 __device__ __forceinline__ void fdr_pass(const RlLds& L, const int* ORDER, const int* NLESS, int NP, int D, int tid, double range, unsigned long long* cnt = nullptr)
 {
