@@ -62,7 +62,10 @@ EPISODE_COST_US = {
 
 def relative_cost(problem):
     """Predicted cost of one instance of `problem` (whole episode where EPISODE_COST_US knows the function, else one generation from COST_NS; the table of the nearest
-    measured dimension: 10 / 30 / 40; problems without a BBOB kind -- protein docking -- all cost the same).  Relative within one suite / dimension only."""
+    measured dimension: 10 / 30 / 40; a problem that knows its own relative cost -- protein docking: `relative_step_cost` -- says so; anything else costs 1).  Relative within one suite / dimension only."""
+    own = getattr(problem, 'relative_step_cost', None)
+    if own is not None:                                   # protein docking: the energy walks the problem's own number of close atom pairs
+        return float(own())
     kind = getattr(problem, 'kind', None)
     if kind is None:
         return 1.0
