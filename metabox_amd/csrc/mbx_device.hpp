@@ -297,6 +297,7 @@ struct EvalLds {
     double *M1T, *M2T;     // [D*D]  linear maps, transposed: MT[k*D+d] = M[d][k]
     double *DSH, *V0, *V1, *V2;   // [D] per-problem vectors
     double* F;             // [n]    objective values (output)
+    int z_doubles = 0;     // capacity of Z when the caller says so (0: unknown -- only the guaranteed max(n*D, 512) is used); eval_rows_protein's wave-per-row mode needs it
 };
 
 // Stage the per-problem constants (two D x D maps, transposed so that lanes differing in d read consecutive
@@ -571,6 +572,84 @@ constexpr int protein_prefetch(int dc) { return dc == 12 ? MBX_PROTEIN_PF : 1; }
 // SIMD, and a pair term is a chain of ~40 dependent float64 operations (rsq, Goldschmidt steps, r^12) that a single wave issues at the
 // chain's latency -- 11-13 cycles per instruction (instrumented build: 1070 cycles per pair, the energy 93 k of the step's 152 k cycles).
 // Same pairs per lane in the same order: every PF gives the same sums.
+// The pair terms of one candidate whose atom records are in ATOM, for the caller's share of the pair list: pairs first, first + stride, ... (stride = the number of lanes that
+// share the candidate: the workgroup, or one wave), PF of them in flight; returns the caller's partial sum.
+template <int PF>
+__device__ __forceinline__ double protein_pair_sum(const double* __restrict__ ATOM, const double2* __restrict__ rec, const int32_t* __restrict__ pij, int n_pairs,
+                                                   int first, int stride)
+{
+    double acc = 0.;
+    for (int t0 = first; t0 < n_pairs; t0 += PF * stride) {
+        double se[PF], q[PF], rr[PF], s[PF], g[PF], h[PF], e[PF], inv[PF], tv[PF];
+        bool ok[PF];
+        // ---- squared distance: one 4-byte index word per pair (lane t reads word t), two 32-byte atom records
+        int tcl[PF];
+        bool close = false;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u * stride;
+            const int tc = t < n_pairs ? t : n_pairs - 1;      // clamped: the loads are unconditional
+            const int w = pij[tc];
+            tcl[u] = tc;
+            ok[u] = t < n_pairs && w >= 0;
+            const int i = w < 0 ? 0 : (w & 0xffff), j = w < 0 ? 1 : (w >> 16);
+            const double2 ai0 = *(const double2*)(ATOM + 4 * i), ai1 = *(const double2*)(ATOM + 4 * i + 2);      // (x, y), (z, |.|^2) of atom i
+            const double2 aj0 = *(const double2*)(ATOM + 4 * j), aj1 = *(const double2*)(ATOM + 4 * j + 2);
+            const double p3 = ai0.x * aj0.x + ai0.y * aj0.y + ai1.x * aj1.x;
+            s[u] = ai1.y - 2 * p3 + aj1.y + 0.01;              // >= 0.01 up to rounding: always a positive normal number
+            close = close || (ok[u] && s[u] < 81.01);
+        }
+        // The pairs come in ascending order of their distance in coor_init (mbx_suite_create) and a move displaces a pair by a fraction of an
+        // Angstrom, so the tail of the list -- ~60 % of the pairs -- is beyond the 9 A cut-off in every candidate.  sqrt(81.01) = 9.0006: at
+        // s >= 81.01 both distance windows are closed and the term is exactly 0, so a wave that sees no closer pair adds nothing and moves on.
+        if (!__any(close)) continue;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {                         // one 32-byte record per pair (lane t reads record t)
+            const double2 a = rec[2 * tcl[u]], b = rec[2 * tcl[u] + 1];
+            se[u] = a.x; q[u] = a.y; rr[u] = b.x;
+        }
+        // ---- pd = sqrt(s) and 1 / pd from one v_rsq_f64 estimate: two coupled Goldschmidt steps, one residual correction each
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const double y = __builtin_amdgcn_rsq(s[u]); g[u] = s[u] * y; h[u] = 0.5 * y; }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) e[u] = __builtin_fma(-h[u], g[u], 0.5);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { g[u] = __builtin_fma(g[u], e[u], g[u]); h[u] = __builtin_fma(h[u], e[u], h[u]); }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) e[u] = __builtin_fma(-h[u], g[u], 0.5);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { g[u] = __builtin_fma(g[u], e[u], g[u]); h[u] = __builtin_fma(h[u], e[u], h[u]); }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) g[u] = __builtin_fma(__builtin_fma(-g[u], g[u], s[u]), h[u], g[u]);    // pd: sqrt(s) + (s - g^2) / (2 sqrt(s))
+#pragma unroll
+        for (int u = 0; u < PF; ++u) inv[u] = h[u] + h[u];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) inv[u] = __builtin_fma(inv[u], __builtin_fma(-g[u], inv[u], 1.0), inv[u]);   // 1 / pd
+        // ---- Coulomb + Lennard-Jones with the distance windows (protein_docking.py:40-46)
+#pragma unroll
+        for (int u = 0; u < PF; ++u) rr[u] = rr[u] * inv[u];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const double r2 = rr[u] * rr[u]; rr[u] = r2 * r2 * r2; }                 // (r / pd)^6
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const double pd = g[u], r6 = rr[u];
+            const double coeff = q[u] * (0.25 * inv[u]) + se[u] * (r6 * r6 - r6);
+            const bool near = pd > 0.11 && pd < 7.0, far = pd > 7.0 && pd < 9.0;
+            const double sw = (9 - pd) * (9 - pd) * (-12 + 2 * pd) * 0.125;
+            const double c10 = 10 * coeff;
+            tv[u] = near ? c10 : (far ? c10 * sw : 0.);
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) if (ok[u]) acc += tv[u];
+    }
+    return acc;
+}
+
+// pairs in flight per lane in the wave-per-row mode of eval_rows_protein (the generation kernels run under a 96-register cap)
+#ifndef MBX_PROTEIN_PFW
+#define MBX_PROTEIN_PFW 2
+#endif
+
 template <int DC = 0, class PT = DevProblem, int PF = 1>
 __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
 {
@@ -578,12 +657,44 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
     // one 32-byte record per atom: x | y | z | x^2 + y^2 + z^2.  A pair gathers its two atoms with TWO 16-byte-aligned ds_read_b128 pairs instead of eight scattered
     // ds_read_b64 (coordinates at a 24-byte stride + the squared norms in an array of their own: 43 % of the LDS-active cycles of k_dq_step were bank conflicts,
     // profiles/r05_dq_step_pmc.json).  Same LDS footprint (4 n doubles), same arithmetic.
-    double* ATOM = L.Z;
-    double* RED = ATOM + 4 * n;
     const double2* __restrict__ rec = (const double2*)P.pyr;       // [n_pairs][2]: (sqrt(e), q), (r, 0) in pair order (mbx_suite_create)
     const int32_t* __restrict__ pij = (const int32_t*)P.plogw;
     const int n_pairs_all = ((n + 1) >> 1) * (n - 1);
     const int n_close = P.n_close;
+    const int NW = MBX_NT >> 6;
+    // ---- a POPULATION of candidates (every population-based optimizer on protein docking: RLEPSO, GLEET, the resets): ONE WAVE PER ROW.  Each wave keeps its own atom table
+    // and walks the pair list with its 64 lanes; no workgroup barrier between rows (the block form pays four per row -- 400 per generation at NP = 100 -- and runs the rows'
+    // ~40-deep float64 chains one row at a time: 2.57 ms per generation of 2240 RLEPSO instances, 2.7x its issue bound).  Needs NW atom tables in Z (the caller says how large
+    // Z is: EvalLds::z_doubles); a workgroup always takes the same form for the same (rows, threads), so the two routes of a kernel family stay bit-identical.
+    if (n_rows >= NW && L.z_doubles >= NW * 4 * n) {
+        const int lane = tid & 63, wave = tid >> 6;
+        double* ATOM = L.Z + wave * 4 * n;
+        for (int r = wave; r < n_rows; r += NW) {
+            const double* x = L.X + r * D;
+            bool inside = n_close > 0;
+            for (int k = 0; k < D; ++k) inside = inside && fabs(x[k]) <= P.ub;
+            const int n_pairs = inside ? n_close : n_pairs_all;
+            for (int m = lane; m < m3; m += 64) {
+                double s = 0.;
+                for (int k = 0; k < D; ++k) s += (x[k] * L.V0[k]) * P.py[(size_t)k * m3 + m];
+                const int i = m / 3;
+                ATOM[4 * i + (m - 3 * i)] = s + P.pc[m];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < n; i += 64)
+                ATOM[4 * i + 3] = ATOM[4 * i] * ATOM[4 * i] + ATOM[4 * i + 1] * ATOM[4 * i + 1] + ATOM[4 * i + 2] * ATOM[4 * i + 2];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double acc = protein_pair_sum<MBX_PROTEIN_PFW>(ATOM, rec, pij, n_pairs, lane, 64);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);      // fixed butterfly: every lane ends with the same sum
+            if (lane == 0) L.F[r] = (2 * acc) / n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the next row overwrites ATOM
+        }
+        __syncthreads();
+        return;
+    }
+    double* ATOM = L.Z;
+    double* RED = ATOM + 4 * n;
     for (int r = 0; r < n_rows; ++r) {
         const double* x = L.X + r * D;
         // The pair list is ordered by the SMALLEST distance a pair can reach while the candidate stays inside the box (|x_k| <= ub: every optimizer clamps / repairs
@@ -602,70 +713,7 @@ __device__ void eval_rows_protein(const PT& P, const EvalLds& L, int n_rows)
         for (int i = tid; i < n; i += MBX_NT)
             ATOM[4 * i + 3] = ATOM[4 * i] * ATOM[4 * i] + ATOM[4 * i + 1] * ATOM[4 * i + 1] + ATOM[4 * i + 2] * ATOM[4 * i + 2];
         __syncthreads();
-        double acc = 0.;
-        for (int t0 = tid; t0 < n_pairs; t0 += PF * MBX_NT) {
-            double se[PF], q[PF], rr[PF], s[PF], g[PF], h[PF], e[PF], inv[PF], tv[PF];
-            bool ok[PF];
-            // ---- squared distance: one 4-byte index word per pair (lane t reads word t), eight LDS words
-            int tcl[PF];
-            bool close = false;
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int t = t0 + u * MBX_NT;
-                const int tc = t < n_pairs ? t : n_pairs - 1;      // clamped: the loads are unconditional
-                const int w = pij[tc];
-                tcl[u] = tc;
-                ok[u] = t < n_pairs && w >= 0;
-                const int i = w < 0 ? 0 : (w & 0xffff), j = w < 0 ? 1 : (w >> 16);
-                const double2 ai0 = *(const double2*)(ATOM + 4 * i), ai1 = *(const double2*)(ATOM + 4 * i + 2);      // (x, y), (z, |.|^2) of atom i
-                const double2 aj0 = *(const double2*)(ATOM + 4 * j), aj1 = *(const double2*)(ATOM + 4 * j + 2);
-                const double p3 = ai0.x * aj0.x + ai0.y * aj0.y + ai1.x * aj1.x;
-                s[u] = ai1.y - 2 * p3 + aj1.y + 0.01;              // >= 0.01 up to rounding: always a positive normal number
-                close = close || (ok[u] && s[u] < 81.01);
-            }
-            // The pairs come in ascending order of their distance in coor_init (mbx_suite_create) and a move displaces a pair by a fraction of an
-            // Angstrom, so the tail of the list -- ~60 % of the pairs -- is beyond the 9 A cut-off in every candidate.  sqrt(81.01) = 9.0006: at
-            // s >= 81.01 both distance windows are closed and the term is exactly 0, so a wave that sees no closer pair adds nothing and moves on.
-            if (!__any(close)) continue;
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {                         // one 32-byte record per pair (lane t reads record t)
-                const double2 a = rec[2 * tcl[u]], b = rec[2 * tcl[u] + 1];
-                se[u] = a.x; q[u] = a.y; rr[u] = b.x;
-            }
-            // ---- pd = sqrt(s) and 1 / pd from one v_rsq_f64 estimate: two coupled Goldschmidt steps, one residual correction each
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { const double y = __builtin_amdgcn_rsq(s[u]); g[u] = s[u] * y; h[u] = 0.5 * y; }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) e[u] = __builtin_fma(-h[u], g[u], 0.5);
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { g[u] = __builtin_fma(g[u], e[u], g[u]); h[u] = __builtin_fma(h[u], e[u], h[u]); }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) e[u] = __builtin_fma(-h[u], g[u], 0.5);
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { g[u] = __builtin_fma(g[u], e[u], g[u]); h[u] = __builtin_fma(h[u], e[u], h[u]); }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) g[u] = __builtin_fma(__builtin_fma(-g[u], g[u], s[u]), h[u], g[u]);    // pd: sqrt(s) + (s - g^2) / (2 sqrt(s))
-#pragma unroll
-            for (int u = 0; u < PF; ++u) inv[u] = h[u] + h[u];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) inv[u] = __builtin_fma(inv[u], __builtin_fma(-g[u], inv[u], 1.0), inv[u]);   // 1 / pd
-            // ---- Coulomb + Lennard-Jones with the distance windows (protein_docking.py:40-46)
-#pragma unroll
-            for (int u = 0; u < PF; ++u) rr[u] = rr[u] * inv[u];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) { const double r2 = rr[u] * rr[u]; rr[u] = r2 * r2 * r2; }                 // (r / pd)^6
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const double pd = g[u], r6 = rr[u];
-                const double coeff = q[u] * (0.25 * inv[u]) + se[u] * (r6 * r6 - r6);
-                const bool near = pd > 0.11 && pd < 7.0, far = pd > 7.0 && pd < 9.0;
-                const double sw = (9 - pd) * (9 - pd) * (-12 + 2 * pd) * 0.125;
-                const double c10 = 10 * coeff;
-                tv[u] = near ? c10 : (far ? c10 * sw : 0.);
-            }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) if (ok[u]) acc += tv[u];
-        }
+        const double acc = protein_pair_sum<PF>(ATOM, rec, pij, n_pairs, tid, MBX_NT);
         const double total = block_sum(acc, RED);
         if (tid == 0) L.F[r] = (2 * total) / n;
     }

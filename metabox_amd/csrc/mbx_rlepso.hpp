@@ -59,7 +59,8 @@ struct RlLds {
     // NCS [NP]: the cost column the FDR scan reads -- NC with the rows that are bitwise copies of the row one rank up (same cost, same position: particles sitting on
     // the same corner of the box) replaced by a huge value, so that the scan never takes them and never mistakes them for near-ties (rl_mark_copies); same free part of Z
     double* NCS;
-    __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC}; }
+    int zd;                       // doubles of Z (rl_z_doubles)
+    __device__ __forceinline__ EvalLds eval() const { return EvalLds{X, Z, T, M1T, M2T, DSH, V0, V1, V2, NC, zd}; }
 };
 
 __host__ __device__ inline int64_t align2(int64_t n) { return (n + 1) & ~(int64_t)1; }
@@ -73,6 +74,7 @@ __host__ __device__ inline int64_t rl_z_doubles(int NP, int D)
     const int64_t NE = align2((int64_t)NP * D);
     int64_t need = 3 * align2(NP) + 96 + rl_aux_doubles(NP, D);
     if (need < 2 * kThreads) need = 2 * kThreads;
+    if (D == 12 && need < 4 * 4 * 100) need = 4 * 4 * 100;      // protein docking (D = 12, 100 atoms): one 32-byte-per-atom table per wave of a 256-thread workgroup (eval_rows_protein)
     return align2(NE > need ? NE : need);
 }
 
@@ -110,7 +112,7 @@ __device__ __forceinline__ RlLds rl_carve(double* base, int NP, int D, bool maps
     double* p = base;
     L.PB = p; L.T = p; p += TS;      // T reuses PB's storage (see rl_commit)
     L.X = p; p += NE;
-    L.Z = p;
+    L.Z = p; L.zd = (int)SC;
     L.R1 = p; L.R2 = p + P; L.COEF = p + 2 * P;   // per-particle draws and group coefficients: last read in the move phase, Z first written by the evaluator
     L.NCS = p + 2 * P + 96;
     L.KB = (uint8_t*)(p + 3 * P + 96);
