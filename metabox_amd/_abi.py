@@ -168,11 +168,13 @@ def load_lib():
     return lib
 
 
-EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval',
-                    'mbx_state_dim', 'mbx_action_dim', 'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy', 'mbx_batch_flags',
-                    'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results', 'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_ddqn_qnet', 'mbx_rlepso_policy_table_rows',
-                    'mbx_rlepso_policy_table', 'mbx_rlepso_act_step', 'mbx_rlepso_rollout_resident', 'mbx_rlepso_rollout', 'mbx_lde_rollout_resident', 'mbx_lde_rollout', 'mbx_rlpso_rollout', 'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_debug_math', 'mbx_debug_rlepso_draws', 'mbx_batch_launch_info', 'mbx_instance_state_doubles',
-                    'mbx_debug_read_state', 'mbx_debug_write_state', 'mbx_debug_clock_probe', 'mbx_debug_clock_mark', 'mbx_debug_clock_slots', 'mbx_batch_rebind', 'mbx_read_public', 'mbx_last_error', 'mbx_version')
+EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval', 'mbx_state_dim', 'mbx_action_dim',
+                    'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy', 'mbx_batch_flags', 'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results',
+                    'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_ddqn_qnet', 'mbx_rlepso_policy_table_rows', 'mbx_rlepso_policy_table', 'mbx_rlepso_act_step',
+                    'mbx_rlepso_rollout_resident', 'mbx_rlepso_rollout', 'mbx_lde_rollout_resident', 'mbx_lde_rollout', 'mbx_rlpso_rollout',
+                    'mbx_qlpso_rollout', 'mbx_gleet_policy', 'mbx_debug_math', 'mbx_debug_rlepso_draws', 'mbx_batch_launch_info', 'mbx_instance_state_doubles',
+                    'mbx_debug_read_state', 'mbx_debug_write_state', 'mbx_debug_clock_probe', 'mbx_debug_clock_mark', 'mbx_debug_clock_slots',
+                    'mbx_batch_rebind', 'mbx_read_public', 'mbx_last_error', 'mbx_version')
 
 
 def check(rc):

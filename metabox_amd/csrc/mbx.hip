@@ -95,8 +95,11 @@ struct mbx_batch {
     int64_t tape_stride = 0;
     int state_dim = 0, action_dim = 0;
     int threads = kThreads;      // workgroup size of the RLEPSO generation kernels (512 for LDS-bound geometries)
-    int fixed_geometry = 0;      // compile-time-geometry instantiation of the generation kernel for the BASELINE.json configs: 1 = RLEPSO NP 100 / D 10 /
-                                 // 5 groups, 2 = RLEPSO NP 128 / D 40 / 5 groups, 3 = LDE NP 50 / D 30, 4 = DE-DDQN NP 100 / D 12, 5 = GLEET NP 100 / D 10, 6 = LDE NP 100 / D 30 (config 3 as written), 7 = RLEPSO NP 100 / D 30 / 5 groups (bbob --dim 30), 8 / 10 = RLEPSO NP 100 at D 12 / D 40 (resident kernel only), 9 = LDE NP 50 / D 10 (resident kernel only); 0 = geometry read from the batch
+    // compile-time-geometry instantiation of the generation / rollout kernels (0 = geometry read from the batch):
+    //   1 = RLEPSO NP 100 / D 10 / 5 groups (BASELINE configs 1-2)      2 = RLEPSO NP 128 / D 40 / 5 groups (config 5)      7 = RLEPSO NP 100 / D 30 (bbob --dim 30)
+    //   8 / 10 = RLEPSO NP 100 at D 12 (protein docking) / D 40 (bbob --dim 40): resident kernel only, mbx_step stays on the run-time-geometry kernel
+    //   3 / 6 = LDE NP 50 / NP 100 at D 30 (config 3)      9 = LDE NP 50 / D 10 (resident kernel only)      4 = DE-DDQN NP 100 / D 12 (config 4)      5 = GLEET NP 100 / D 10
+    int fixed_geometry = 0;
 };
 
 // per-algorithm geometry

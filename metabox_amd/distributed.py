@@ -43,9 +43,12 @@ def instance_table(n_problems, runs, sort_by_problem=True):
 # D = 40 / NP = 128.  Only the RATIOS matter: they weight the inter-rank partition below and -- the same numbers, rounded -- the launch order inside a batch
 # (upload_launch_order in csrc/mbx.hip).  Noisy functions cost what their base kind costs (the noise is O(NP) per generation).
 COST_NS = {
-    10: {1: 26.01, 2: 29.65, 3: 32.93, 4: 29.37, 5: 20.05, 6: 24.52, 7: 25.34, 8: 23.1, 9: 22.82, 10: 26.95, 11: 26.83, 12: 26.39, 13: 22.29, 14: 25.01, 15: 31.54, 16: 32.72, 17: 31.07, 18: 31.06, 19: 24.38, 20: 24.31, 21: 39.61, 22: 28.99, 23: 32.19, 24: 25.47},
-    30: {1: 84.86, 2: 100.99, 3: 112.79, 4: 102.7, 5: 73.29, 6: 81.22, 7: 90.62, 8: 78.32, 9: 78.39, 10: 91.78, 11: 91.66, 12: 93.63, 13: 76.91, 14: 84.95, 15: 112.8, 16: 118.18, 17: 113.17, 18: 113.63, 19: 83.24, 20: 80.5, 21: 144.75, 22: 97.63, 23: 104.35, 24: 86.63},
-    40: {1: 158.85, 2: 178.7, 3: 207.74, 4: 198.05, 5: 133.42, 6: 156.57, 7: 188.54, 8: 153.28, 9: 152.78, 10: 178.33, 11: 178.44, 12: 183.99, 13: 149.94, 14: 165.65, 15: 228.47, 16: 234.17, 17: 225.47, 18: 228.29, 19: 160.72, 20: 152.6, 21: 301.57, 22: 237.76, 23: 204.9, 24: 168.18},
+    10: {1: 26.01, 2: 29.65, 3: 32.93, 4: 29.37, 5: 20.05, 6: 24.52, 7: 25.34, 8: 23.1, 9: 22.82, 10: 26.95, 11: 26.83, 12: 26.39, 13: 22.29, 14: 25.01, 15:
+         31.54, 16: 32.72, 17: 31.07, 18: 31.06, 19: 24.38, 20: 24.31, 21: 39.61, 22: 28.99, 23: 32.19, 24: 25.47},
+    30: {1: 84.86, 2: 100.99, 3: 112.79, 4: 102.7, 5: 73.29, 6: 81.22, 7: 90.62, 8: 78.32, 9: 78.39, 10: 91.78, 11: 91.66, 12: 93.63, 13: 76.91, 14: 84.95, 15:
+         112.8, 16: 118.18, 17: 113.17, 18: 113.63, 19: 83.24, 20: 80.5, 21: 144.75, 22: 97.63, 23: 104.35, 24: 86.63},
+    40: {1: 158.85, 2: 178.7, 3: 207.74, 4: 198.05, 5: 133.42, 6: 156.57, 7: 188.54, 8: 153.28, 9: 152.78, 10: 178.33, 11: 178.44, 12: 183.99, 13: 149.94, 14:
+         165.65, 15: 228.47, 16: 234.17, 17: 225.47, 18: 228.29, 19: 160.72, 20: 152.6, 21: 301.57, 22: 237.76, 23: 204.9, 24: 168.18},
 }
 
 # us per WHOLE EPISODE of one RLEPSO instance by function id (bbob 1-24, bbob-noisy 101-130), measured on one MI355X with tools/episode_costs.py at the round-6 head
@@ -54,9 +57,21 @@ COST_NS = {
 # kind) remains the fallback for functions outside the table.  Only the ratios matter.  (tools/shard_balance.py: with the per-generation weights the eight shards of
 # 8 x config 2 came out at max / mean = 1.096 -- the shards that hold Sphere / linear slope finish early -- and config 5 at 1.035.)
 EPISODE_COST_US = {
-    10: {1: 2.994, 2: 6.585, 3: 10.836, 4: 7.891, 5: 1.623, 6: 5.809, 7: 5.925, 8: 5.519, 9: 5.506, 10: 6.45, 11: 6.398, 12: 7.737, 13: 7.09, 14: 6.083, 15: 8.555, 16: 7.779, 17: 7.655, 18: 7.704, 19: 5.944, 20: 6.157, 21: 10.469, 22: 8.368, 23: 7.44, 24: 5.853, 101: 3.069, 102: 3.303, 103: 5.879, 104: 5.968, 105: 6.032, 106: 6.059, 107: 5.793, 108: 5.859, 109: 5.904, 110: 5.963, 111: 6.031, 112: 6.066, 113: 6.276, 114: 6.349, 115: 6.787, 116: 6.876, 117: 6.96, 118: 6.959, 119: 6.504, 120: 6.58, 121: 6.594, 122: 7.944, 123: 8.012, 124: 8.044, 125: 6.335, 126: 6.405, 127: 6.432, 128: 9.962, 129: 10.018, 130: 10.09},
-    30: {1: 49.839, 2: 57.49, 3: 65.793, 4: 61.253, 5: 18.096, 6: 50.424, 7: 87.195, 8: 48.966, 9: 48.867, 10: 57.466, 11: 57.787, 12: 59.006, 13: 48.687, 14: 53.691, 15: 71.181, 16: 72.724, 17: 73.554, 18: 70.707, 19: 52.503, 20: 51.597, 21: 94.011, 22: 68.812, 23: 64.733, 24: 54.919, 101: 50.834, 102: 50.966, 103: 51.019, 104: 51.478, 105: 51.826, 106: 52.148, 107: 50.466, 108: 50.751, 109: 50.965, 110: 51.432, 111: 51.655, 112: 51.918, 113: 57.088, 114: 57.126, 115: 69.928, 116: 60.076, 117: 60.395, 118: 60.718, 119: 56.352, 120: 56.582, 121: 56.877, 122: 71.95, 123: 72.264, 124: 72.417, 125: 55.371, 126: 55.529, 127: 55.637, 128: 92.662, 129: 92.97, 130: 92.919},
-    40: {1: 96.322, 2: 114.884, 3: 133.6, 4: 127.253, 5: 42.755, 6: 100.916, 7: 174.791, 8: 98.739, 9: 97.95, 10: 115.614, 11: 115.238, 12: 117.948, 13: 96.142, 14: 106.594, 15: 147.226, 16: 149.02, 17: 145.344, 18: 145.246, 19: 104.588, 20: 97.767, 21: 192.195, 22: 151.999, 23: 130.564, 24: 109.576, 101: 102.836, 102: 103.422, 103: 103.867, 104: 105.042, 105: 105.406, 106: 105.627, 107: 103.087, 108: 103.709, 109: 103.705, 110: 105.092, 111: 106.204, 112: 105.789, 113: 120.459, 114: 121.348, 115: 149.978, 116: 122.797, 117: 123.647, 118: 124.065, 119: 115.076, 120: 115.811, 121: 115.873, 122: 148.381, 123: 149.596, 124: 149.642, 125: 112.751, 126: 112.987, 127: 112.725, 128: 198.153, 129: 199.259, 130: 198.812},
+    10: {1: 2.994, 2: 6.585, 3: 10.836, 4: 7.891, 5: 1.623, 6: 5.809, 7: 5.925, 8: 5.519, 9: 5.506, 10: 6.45, 11: 6.398, 12: 7.737, 13: 7.09, 14: 6.083, 15:
+         8.555, 16: 7.779, 17: 7.655, 18: 7.704, 19: 5.944, 20: 6.157, 21: 10.469, 22: 8.368, 23: 7.44, 24: 5.853, 101: 3.069, 102: 3.303, 103: 5.879, 104:
+         5.968, 105: 6.032, 106: 6.059, 107: 5.793, 108: 5.859, 109: 5.904, 110: 5.963, 111: 6.031, 112: 6.066, 113: 6.276, 114: 6.349, 115: 6.787, 116: 6.876,
+         117: 6.96, 118: 6.959, 119: 6.504, 120: 6.58, 121: 6.594, 122: 7.944, 123: 8.012, 124: 8.044, 125: 6.335, 126: 6.405, 127: 6.432, 128: 9.962, 129:
+         10.018, 130: 10.09},
+    30: {1: 49.839, 2: 57.49, 3: 65.793, 4: 61.253, 5: 18.096, 6: 50.424, 7: 87.195, 8: 48.966, 9: 48.867, 10: 57.466, 11: 57.787, 12: 59.006, 13: 48.687, 14:
+         53.691, 15: 71.181, 16: 72.724, 17: 73.554, 18: 70.707, 19: 52.503, 20: 51.597, 21: 94.011, 22: 68.812, 23: 64.733, 24: 54.919, 101: 50.834, 102:
+         50.966, 103: 51.019, 104: 51.478, 105: 51.826, 106: 52.148, 107: 50.466, 108: 50.751, 109: 50.965, 110: 51.432, 111: 51.655, 112: 51.918, 113: 57.088,
+         114: 57.126, 115: 69.928, 116: 60.076, 117: 60.395, 118: 60.718, 119: 56.352, 120: 56.582, 121: 56.877, 122: 71.95, 123: 72.264, 124: 72.417, 125:
+         55.371, 126: 55.529, 127: 55.637, 128: 92.662, 129: 92.97, 130: 92.919},
+    40: {1: 96.322, 2: 114.884, 3: 133.6, 4: 127.253, 5: 42.755, 6: 100.916, 7: 174.791, 8: 98.739, 9: 97.95, 10: 115.614, 11: 115.238, 12: 117.948, 13:
+         96.142, 14: 106.594, 15: 147.226, 16: 149.02, 17: 145.344, 18: 145.246, 19: 104.588, 20: 97.767, 21: 192.195, 22: 151.999, 23: 130.564, 24: 109.576,
+         101: 102.836, 102: 103.422, 103: 103.867, 104: 105.042, 105: 105.406, 106: 105.627, 107: 103.087, 108: 103.709, 109: 103.705, 110: 105.092, 111:
+         106.204, 112: 105.789, 113: 120.459, 114: 121.348, 115: 149.978, 116: 122.797, 117: 123.647, 118: 124.065, 119: 115.076, 120: 115.811, 121: 115.873,
+         122: 148.381, 123: 149.596, 124: 149.642, 125: 112.751, 126: 112.987, 127: 112.725, 128: 198.153, 129: 199.259, 130: 198.812},
 }
 
 
