@@ -308,9 +308,10 @@ int mbx_rlepso_rollout(mbx_batch* b, const float* d_table, int n_gens, float* d_
  *   d_traj_reward  [n_gens, n_instances] float64   reward (0 after termination);   d_traj_done [n_gens, n_instances] uint8 (1 after termination)
  * d_state_out [n_instances, NP + 10] / d_done_out: features / is_done after the last executed generation (rows of instances that were done
  * before the call are not written); d_reward_out: SUM of the rewards of the executed generations.
- * The resident kernel is built for config 3's geometries (NP 50 / 100 at D 30, hidden 50) and the objective kinds whose row sums need one
- * array (all of bbob-noisy; bbob without F3, F4, F5, F15, F20, F24); any other batch is stepped with mbx_lde_policy + mbx_step per generation
- * behind the same interface (MBX_F_ROLLOUT_PER_GENERATION in the batch's flags forces that route).  mbx_lde_rollout_resident: 1 / 0. */
+ * The resident kernel is built for NP 50 at D 10 and D 30 (all 24 BBOB kinds and the noisy suite; at D 30 the batches that hold F3 / F4 / F5 / F15 / F20 / F24 run an
+ * instantiation with a second tile array, the others the lean one config 3 is timed on) and for NP 100 at D 30 (config 3 as written: all of bbob-noisy; bbob without those six
+ * kinds), hidden 50; any other batch is stepped with mbx_lde_policy + mbx_step per generation behind the same interface (MBX_F_ROLLOUT_PER_GENERATION in the batch's flags forces
+ * that route).  mbx_lde_rollout_resident: 1 / 0. */
 int mbx_lde_rollout_resident(const mbx_batch* b);
 int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state_in, float* d_h, float* d_c, int n_gens,
                     float* d_traj_actions, double* d_traj_state, double* d_traj_reward, uint8_t* d_traj_done, double* d_state_out,

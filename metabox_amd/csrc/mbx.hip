@@ -86,7 +86,8 @@ struct mbx_batch {
     bool fdr_fast = false;                 // RLEPSO, MBX_F_FDR_FAST honoured: the kernels without the near-tie flag / second pass of the FDR scan (include/mbx.h); cfg.flags holds
                                            // the EFFECTIVE flags (environment overrides OR-ed in, MBX_F_FDR_FAST cleared where no fast instantiation exists)
     bool rl_run_kinds_ok = false;          // RLEPSO: every problem of the batch is one of the 24 BBOB kinds the per-kind k_rlepso_run geometries have a body for (rl_run_kind_ok)
-    bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind k_lde_run builds (lde_run_kind_ok)
+    bool lde_run_kinds_ok = false;         // LDE: every problem of the batch has an objective kind the LEAN instantiations of k_lde_run build (one tile array: lde_run_kind_ok(.., two = false))
+    bool lde_run_kinds_two = false;        // ... a kind the instantiations with the second tile array build (F1-F24)
     bool rollout_per_generation = false;   // MBX_F_ROLLOUT_PER_GENERATION: the mbx_*_rollout entry points take the host-loop route
     int64_t state_stride = 0;
     const double* d_tape = nullptr;
@@ -511,7 +512,11 @@ static int upload_launch_order(mbx_batch* b, const int32_t* problem_idx)
     b->lde_run_kinds_ok = true;
     b->rl_run_kinds_ok = true;
     for (int i = 0; i < n_instances; ++i) b->rl_run_kinds_ok = b->rl_run_kinds_ok && rl_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->h_problems[problem_idx[i]].noise_kind);
-    for (int i = 0; i < n_instances; ++i) b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->dim);
+    b->lde_run_kinds_two = true;
+    for (int i = 0; i < n_instances; ++i) {
+        b->lde_run_kinds_ok = b->lde_run_kinds_ok && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->dim, false);
+        b->lde_run_kinds_two = b->lde_run_kinds_two && lde_run_kind_ok(s->h_problems[problem_idx[i]].kind, s->dim, true);
+    }
     std::vector<int32_t> order(n_instances);
     for (int i = 0; i < n_instances; ++i) order[i] = i;
     // equal weights: by kind, so that neighbours in the launch order -- the workgroups that share a CU -- run the same per-kind body (k_rlepso_run, k_lde_run)
@@ -618,9 +623,10 @@ extern "C" int mbx_batch_create(mbx_suite* s, const mbx_algo_cfg* cfg_in, const 
         {   // mbx_lde_rollout: per-generation rewards / actions of the host-loop route
             HIP_TRY(hipMalloc(&b->d_scratch, (size_t)n_instances * (sizeof(double) + (size_t)g.action_dim * sizeof(float))));
             HIP_TRY(hipMalloc(&b->d_lstm_pack, (size_t)lde_run_pack_floats(g.state_dim, 64, g.action_dim) * sizeof(float)));      // hidden <= 64
-            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(100, 30, 50) * sizeof(double))));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50) * sizeof(double))));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 10, 50) * sizeof(double))));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<100, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(100, 30, 50, false) * sizeof(double))));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50, false) * sizeof(double))));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 30, 50, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 30, 50, true) * sizeof(double))));
+            HIP_TRY(hipFuncSetAttribute((const void*)k_lde_run<50, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lde_run_lds_doubles(50, 10, 50, true) * sizeof(double))));
         }
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_reset<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)k_lde_step<kThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1009,7 +1015,10 @@ extern "C" int mbx_lde_rollout_resident(const mbx_batch* b)
 {
     if (!b) return fail(MBX_E_ARG, "mbx_lde_rollout_resident: null batch");
     if (b->cfg.algo != MBX_ALGO_LDE) return 0;
-    return (b->fixed_geometry == 3 || b->fixed_geometry == 6 || b->fixed_geometry == 9) && b->lde_run_kinds_ok && !b->rollout_per_generation ? 1 : 0;
+    if (b->rollout_per_generation) return 0;
+    // NP 50 at D 10 / D 30: an instantiation with the second tile array exists (all 24 kinds); NP 100 / D 30 (config 3 as written): the lean one only
+    if (b->fixed_geometry == 9 || b->fixed_geometry == 3) return (b->lde_run_kinds_ok || b->lde_run_kinds_two) ? 1 : 0;
+    return b->fixed_geometry == 6 && b->lde_run_kinds_ok ? 1 : 0;
 }
 
 extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const double* d_state_in, float* d_h, float* d_c, int n_gens,
@@ -1025,7 +1034,6 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
                     net->in_dim, net->hidden, net->out_dim, b->state_dim, b->action_dim);
     const int64_t B = b->B, A = b->action_dim, NF = b->state_dim;
     if (mbx_lde_rollout_resident(b) == 1 && net->hidden == 50) {
-        if (!b->lde_run_kinds_ok) return fail(MBX_E_UNSUPPORTED, "k_lde_run: the batch holds an objective kind the resident kernel does not build");   // (its row-sum default yields NaN)
         LdeRunArgs ka{};
         ka.bp = make_params(b);
         {   // the weights may have changed since the last call: rebuild the k-blocked copy the kernel reads (one small launch, ~3 us)
@@ -1036,13 +1044,16 @@ extern "C" int mbx_lde_rollout(mbx_batch* b, const mbx_lstm_policy* net, const d
         ka.state_in = d_state_in; ka.hbuf = d_h; ka.cbuf = d_c; ka.n_gens = n_gens;
         ka.out = LdeRunOut{d_traj_actions, d_traj_state, d_traj_reward, d_traj_done, d_state_out, d_reward_out, d_done_out};
         if (b->fixed_geometry == 6)
-            hipLaunchKernelGGL((k_lde_run<100, 30>), dim3(b->B), dim3(lde_run_threads(100)), (size_t)lde_run_lds_doubles(100, 30, 50) * sizeof(double),
+            hipLaunchKernelGGL((k_lde_run<100, 30>), dim3(b->B), dim3(lde_run_threads(100)), (size_t)lde_run_lds_doubles(100, 30, 50, false) * sizeof(double),
                                (hipStream_t)stream, ka);
         else if (b->fixed_geometry == 9)
-            hipLaunchKernelGGL((k_lde_run<50, 10>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 10, 50) * sizeof(double),
+            hipLaunchKernelGGL((k_lde_run<50, 10>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 10, 50, true) * sizeof(double),
                                (hipStream_t)stream, ka);
-        else
-            hipLaunchKernelGGL((k_lde_run<50, 30>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 30, 50) * sizeof(double),
+        else if (b->lde_run_kinds_ok)
+            hipLaunchKernelGGL((k_lde_run<50, 30>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 30, 50, false) * sizeof(double),
+                               (hipStream_t)stream, ka);
+        else        // plain bbob --dim 30 at the reference's NP = 50 with F3 / F4 / F5 / F15 / F20 / F24 in the batch: the instantiation that carries the second tile array
+            hipLaunchKernelGGL((k_lde_run<50, 30, 50, true>), dim3(b->B), dim3(lde_run_threads(50)), (size_t)lde_run_lds_doubles(50, 30, 50, true) * sizeof(double),
                                (hipStream_t)stream, ka);
         HIP_TRY(hipGetLastError());
         return MBX_OK;

@@ -99,9 +99,10 @@ __device__ __forceinline__ LdeRunCArgs& lde_run_args()
 
 // one column tile (D <= 16): a second tile array TB2 exists and with it the six kinds whose row sums read two arrays / the candidate
 __host__ __device__ constexpr bool lde_run_two_arrays(int D) { return D <= 16; }
-__host__ __device__ constexpr bool lde_run_kind_ok(int kind, int D)
+// two: the instantiation carries the second tile array (always at D <= 16; at NP 50 / D 30 as the instantiation of its own k_lde_run<50, 30, 50, true>)
+__host__ __device__ constexpr bool lde_run_kind_ok(int kind, int D, bool two)
 {
-    return lde_run_two_arrays(D) ? (kind >= 1 && kind <= 24)
+    return two ? (kind >= 1 && kind <= 24)
                                  : (kind == 1 || kind == 2 || (kind >= 6 && kind <= 14) || (kind >= 16 && kind <= 19) || (kind >= 21 && kind <= 23));
 }
 
@@ -116,20 +117,20 @@ struct LdeRunLds {
 };
 
 // LDS is allocated in 1280-byte granules: 3 workgroups per CU need <= 53 760 B each (pop 100: 52 768 B), 6 need <= 26 880 B (pop 50: 26 880 B)
-__host__ __device__ inline int64_t lde_run_lds_doubles(int NP, int D, int H)
+__host__ __device__ inline int64_t lde_run_lds_doubles(int NP, int D, int H, bool two)
 {
     const int64_t NE = align2((int64_t)NP * D), P = align2(NP);
-    return (lde_run_two_arrays(D) ? 3 : 2) * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + align2((P + 1) / 2) + 2 * align2((P + 7) / 8) + 4 + align2(D);
+    return (two ? 3 : 2) * NE + 2 * P + align2(NP + 2 * MBX_LDE_BINS) + 8 + 8 + 8 + P /* ACT: 2 NP floats */ + align2(H) /* h | c */ + align2((P + 1) / 2) + 2 * align2((P + 7) / 8) + 4 + align2(D);
 }
 
-__device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, int H)
+__device__ __forceinline__ LdeRunLds lde_run_carve(double* base, int NP, int D, int H, bool two)
 {
     const int64_t NE = align2((int64_t)NP * D), P = align2(NP), PI = align2((P + 1) / 2);
     LdeRunLds L;
     double* p = base;
     L.P = p; p += NE;  L.TB = p; p += NE;
     L.TB2 = nullptr;
-    if (lde_run_two_arrays(D)) { L.TB2 = p; p += NE; }           // second tile array (kinds 3, 4, 5, 15, 20, 24)
+    if (two) { L.TB2 = p; p += NE; }           // second tile array (kinds 3, 4, 5, 15, 20, 24)
     L.FIT = p; p += P;
     L.A1 = p; p += P;            // SORTED (from the ranking to the next row sums) | Gallagher: best key per row
     L.FEAT = p; L.A2 = p; p += align2(NP + 2 * MBX_LDE_BINS);   // features; dead between the policy's input staging and the next feature phase, where
@@ -274,7 +275,7 @@ __device__ __forceinline__ void lde_map_tile(const double* __restrict__ M, const
 // Everything element-wise between the first linear map and the row sums (phases E1, C, E2 of eval_rows), IN PLACE in the wave's slice, one element per lane at a
 // time.  Out of line like the Gallagher search: the generation body (policy, mutation, ranking) is register-allocated without it, and the kinds that have
 // nothing element-wise never call it.
-template <int NP, int D, int KIND = 0>
+template <int NP, int D, int KIND = 0, bool TA = lde_run_two_arrays(D)>
 __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, ConstProblem* Pp, int kind_, double* TW2_ = nullptr)
 {
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -282,7 +283,7 @@ __device__ MBX_LDE_GALL_ATTR void lde_tile_transforms(double* TW_, double* A2_, 
     lds_f64* A2 = (lds_f64*)A2_;
     lds_f64* TW2 = (lds_f64*)TW2_;                                  // the wave's slice of the second tile array (D <= 16 only)
     constexpr int KS = (D + 3) / 4;
-    constexpr bool TWO = lde_run_two_arrays(D) && KIND == 0;       // kinds 3, 4, 5, 15, 20, 24 live in the any-kind loop of the one-tile geometries
+    constexpr bool TWO = TA && KIND == 0;                          // kinds 3, 4, 5, 15, 20, 24 live in the any-kind loop of the instantiations that carry the second tile array
     constexpr int MM = D > 16 ? 8 : 4;                             // elements per lane: 4 rows x one or two column tiles
     const uint64_t pu_ = (uint64_t)(uintptr_t)Pp;
     const uint64_t pu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pu_) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pu_ >> 32)) << 32);
@@ -454,18 +455,18 @@ enum { LR_FES = 0, LR_HCOUNT, LR_BSF, LR_RSUM, LR_RTOT, LR_LOGI, LR_CLEN };
 // and scheduled without the other kinds' code (the any-kind kernel ran a Sphere batch 10 % slower than a build with everything but Sphere compiled out).  One launch for the
 // mixed batch all the same: one launch per kind on side streams lost more in the eight tails than the specialisation gained (docs/EXPERIMENTS.md).
 // Arguments arrive in VGPRs and are made wave-uniform again (the address of the kernel's argument block among them); the LDS carve-up is rebuilt from the dynamic LDS symbol.  Returns the number of generations executed.
-template <int NPC, int DC, int HC_, int KIND>
+template <int NPC, int DC, int HC_, int KIND, bool TA>
 __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_, int n_gens_, uint32_t seed_lo_, uint32_t seed_hi_, uint32_t karg_lo_, uint32_t karg_hi_)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, A = 2 * NP, G4 = 4 * H, K1 = IN + H;
     constexpr int TILES = (NP + 15) / 16, KS = (D + 3) / 4, NF = NP + 2 * MBX_LDE_BINS;
-    constexpr bool TWO = lde_run_two_arrays(D) && KIND == 0;       // the six two-array kinds: any-kind loop of the one-tile geometries
+    constexpr bool TWO = TA && KIND == 0;                          // the six two-array kinds: any-kind loop of the instantiations that carry the second tile array
     // crossover uniforms of a row: D consecutive elements of the sorted population starting at offset (i D) & 3 in {0, 2} (D even) -> GPR Philox groups
     constexpr int GPR = (D + 2 + 3) / 4, ROWW = 4 * GPR;
     static_assert(D % 2 == 0 && 16 * ROWW * 4 <= 16 * D * 8, "the uniforms of a tile fit the wave's slice");
     static_assert(4 * ((K1 + 3) / 4) - IN <= 64, "the hidden state is staged by one wave");
-    const LdeRunLds L = lde_run_carve(smem, NP, D, H);
+    const LdeRunLds L = lde_run_carve(smem, NP, D, H, TA);
     const int b = __builtin_amdgcn_readfirstlane(b_), gen0 = __builtin_amdgcn_readfirstlane(gen0_), episode = __builtin_amdgcn_readfirstlane(episode_);
     const int n_gens = __builtin_amdgcn_readfirstlane(n_gens_);
     const uint32_t seed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_lo_), seed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed_hi_);
@@ -679,7 +680,7 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
         // calls, and the fewer values are alive across a call the fewer are spilled around it).
         if (!(TWO && (kind == 5 || kind == 20))) lde_map_tile<NP, D>(P.m1, av, TW, wave, c, q);      // (linear slope, Schwefel: no map)
         MBX_PHASE(8);                                              // (first linear map of wave 0)
-        if (!(kind == 1 || kind == 13 || gall || (TWO && kind == 5))) lde_tile_transforms<NP, D, KIND>(TW, L.A2, &P, kind, TW2);      // (Sphere-like kinds and Gallagher: nothing element-wise)
+        if (!(kind == 1 || kind == 13 || gall || (TWO && kind == 5))) lde_tile_transforms<NP, D, KIND, TA>(TW, L.A2, &P, kind, TW2);      // (Sphere-like kinds and Gallagher: nothing element-wise)
         __syncthreads();
         MBX_PHASE(2);                                              // mutation, linear maps, transforms (wave-local)
 
@@ -869,7 +870,9 @@ __device__ __noinline__ int lde_run_generations(int b_, int gen0_, int episode_,
     return executed;
 }
 
-template <int NPC, int DC, int HC_ = 50>
+// TA: the instantiation carries the second tile array (and with it the six kinds whose row sums read two arrays or the candidate): always at D <= 16; at D = 30 an
+// instantiation of its own for the reference's NP = 50 on plain bbob (38.9 KB of LDS: four workgroups per CU instead of six -- config 3's bbob-noisy batches keep the lean one)
+template <int NPC, int DC, int HC_ = 50, bool TA = lde_run_two_arrays(DC)>
 __global__ __launch_bounds__(64 * ((NPC + 15) / 16)) __attribute__((amdgpu_waves_per_eu(MBX_LDE_RUN_WAVES(NPC))))
 void k_lde_run(LdeRunArgs args_)
 {
@@ -877,7 +880,7 @@ void k_lde_run(LdeRunArgs args_)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NP = NPC, D = DC, NE = NP * D, H = HC_, IN = NP + 2 * MBX_LDE_BINS, K1 = IN + H, NF = NP + 2 * MBX_LDE_BINS;
     static_assert(D <= 32 && D % 2 == 0, "one or two 16-column tiles, coordinate pairs");
-    const LdeRunLds L = lde_run_carve(smem, NP, D, H);
+    const LdeRunLds L = lde_run_carve(smem, NP, D, H, TA);
     int b, gen0, episode, n_gens, kind0;
     uint32_t seed_lo, seed_hi;
     {
@@ -931,7 +934,7 @@ void k_lde_run(LdeRunArgs args_)
     __syncthreads();
     int executed;
     const uint64_t karg = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-#define MBX_LDE_GENS(K) lde_run_generations<NPC, DC, HC_, K>(b, gen0, episode, n_gens, seed_lo, seed_hi, (uint32_t)karg, (uint32_t)(karg >> 32))
+#define MBX_LDE_GENS(K) lde_run_generations<NPC, DC, HC_, K, TA>(b, gen0, episode, n_gens, seed_lo, seed_hi, (uint32_t)karg, (uint32_t)(karg >> 32))
     switch (kind0) {                                               // the kinds of the noisy suite (problem/bbob.py: _NOISY); anything else takes the any-kind loop
     case 1: executed = MBX_LDE_GENS(1); break;
     case 7: executed = MBX_LDE_GENS(7); break;

@@ -23,5 +23,6 @@ MBX_RUN_RLEPSO_FAST(extern)
 extern template __global__ void k_lde_run<100, 30>(LdeRunArgs);
 extern template __global__ void k_lde_run<50, 30>(LdeRunArgs);
 extern template __global__ void k_lde_run<50, 10>(LdeRunArgs);
+extern template __global__ void k_lde_run<50, 30, 50, true>(LdeRunArgs);
 }  // namespace mbx
 #endif

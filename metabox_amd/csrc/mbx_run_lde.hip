@@ -11,5 +11,6 @@
 namespace mbx {
 template __global__ void k_lde_run<100, 30>(LdeRunArgs);
 template __global__ void k_lde_run<50, 30>(LdeRunArgs);
-template __global__ void k_lde_run<50, 10>(LdeRunArgs);        // the reference's own LDE setting (NP = 50, bbob --dim 10): all 24 kinds
+template __global__ void k_lde_run<50, 10>(LdeRunArgs);
+template __global__ void k_lde_run<50, 30, 50, true>(LdeRunArgs);        // the reference's NP on plain bbob --dim 30: second tile array, all 24 kinds        // the reference's own LDE setting (NP = 50, bbob --dim 10): all 24 kinds
 }  // namespace mbx

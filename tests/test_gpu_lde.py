@@ -379,19 +379,28 @@ def test_lde_resident_rollout_reference_setting_dim10_all_24_kinds():
     assert np.all(r['fes'] >= 50 * 12) and np.all(r['steps'] == 11)
 
 
+def test_lde_resident_rollout_plain_bbob_dim30_all_24_kinds():
+    """The reference's NP = 50 on plain bbob --dim 30 (round 6): a batch that holds F3 / F4 / F5 / F15 / F20 / F24 takes k_lde_run<50, 30, 50, true>, the instantiation with the
+    second tile array (38.9 KB of LDS); batches without them keep the lean one config 3 is timed on.  All 24 functions, bit for bit against k_lstm_policy + k_lde_step per
+    generation, in uneven chunks; then whole short episodes with terminations inside a launch.  src/problem/bbob.py:229-287, 585-602, 740-759, 869-890."""
+    _lde_rollout_case('bbob', tuple(range(1, 25)), 50, 48, (1, 6, 13, 2))
+    r = _lde_rollout_case('bbob', (1, 3, 4, 5, 15, 20, 24, 21), 50, 16, (4, 9, 30), maxfes=50 * 12)
+    assert np.all(r['fes'] >= 50 * 12) and np.all(r['steps'] == 11)
+
+
 def test_lde_rollout_host_loop_route(monkeypatch):
-    """Behind the same entry point: objective kinds the D = 30 resident kernels do not build (F3, F15, F24: two arrays in the row sums / the candidate
-    itself; the second tile array exists at D <= 16 only), and MBX_ROLLOUT_PER_GENERATION=1 take mbx_lde_policy + mbx_step per generation -- same records."""
-    _lde_rollout_case('bbob', (1, 3, 15, 24), 50, 8, (2, 5), resident=False)
+    """Behind the same entry point: objective kinds the resident kernel of a geometry does not build (NP = 100 at D = 30 has the lean instantiation only: F3, F15, F24 need the
+    second tile array), and MBX_ROLLOUT_PER_GENERATION=1 take mbx_lde_policy + mbx_step per generation -- same records."""
+    _lde_rollout_case('bbob', (1, 3, 15, 24), 100, 8, (2, 5), resident=False)
     # whole short episodes on this route: instances terminate inside the second call and the third call starts with every instance done -- their
     # (h, c) and action rows must stay untouched, as include/mbx.h promises for both routes (ADVICE r04)
-    r = _lde_rollout_case('bbob', (1, 3, 15, 24), 50, 8, (4, 9, 30), resident=False, maxfes=50 * 12)
+    r = _lde_rollout_case('bbob', (1, 3, 15, 24), 100, 8, (4, 9, 30), resident=False, maxfes=100 * 12)
     assert np.all(r['steps'] == 11)
     monkeypatch.setenv('MBX_ROLLOUT_PER_GENERATION', '1')
     _lde_rollout_case('bbob-noisy', (101, 128), 100, 8, (3, 4), resident=False)
 
 
-@pytest.mark.parametrize('NP,suite,dim', [(50, 'bbob-noisy', 30), (100, 'bbob-noisy', 30), (50, 'bbob', 10), (50, 'bbob-noisy', 10)])
+@pytest.mark.parametrize('NP,suite,dim', [(50, 'bbob-noisy', 30), (100, 'bbob-noisy', 30), (50, 'bbob', 10), (50, 'bbob-noisy', 10), (50, 'bbob', 30)])
 def test_lde_resident_rollout_matches_the_oracle(NP, suite, dim):
     """The resident kernel against the C oracle directly: 10 generations of all 30 noisy functions in ONE launch; the oracle, on the same Philox
     seeds, replays the actions the in-kernel PolicyNet drew and must see the same features / rewards after every generation and the same
