@@ -424,3 +424,59 @@ def test_hip_fdr_is_the_reference_index_on_converged_swarms(route):
     print(f'converged natural swarms ({route}): {bad} of {items} items moved with an exemplar other than np.argmin\'s; {ties} items whose two best quotients are <= 2 ulp '
           f'apart, {dup} duplicate pbest costs in {n} swarms')
     assert ties > 1000 and bad == 0
+
+
+def craft_copy_pairs(rs, NP=NP, D=D):
+    """A swarm in which particles 2m and 2m + 1 (in a random index order) share their pbest COST and the first half of their coordinates but not the rest: every candidate has an
+    exact copy in dimensions < D / 2 -- a tie np.argmin resolves by the lower particle index -- while the rows differ, so the row-level copy marking (rl_mark_copies) cannot take
+    them out of the scan.  Hundreds of flagged items per swarm: the kernels settle them lane by lane (fdr_settle_own), not wave by wave."""
+    perm = rs.permutation(NP)
+    f = np.empty(NP)
+    P = rs.uniform(-4, 4, (NP, D))
+    for m in range(NP // 2):
+        a, b = perm[2 * m], perm[2 * m + 1]
+        f[a] = f[b] = 1000. - 10. * m - rs.uniform(0., 5.)
+        P[b, :D // 2] = P[a, :D // 2]
+    if NP % 2:
+        f[perm[-1]] = 2000.
+    return f, P
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['per_generation', 'resident'])
+def test_hip_fdr_with_copies_in_half_of_the_coordinates(route):
+    """Exact ties everywhere (craft_copy_pairs): the exemplar must be the LOWER-INDEXED copy in every item, on the path that settles a swarm with more than 64 flagged items."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    rs = np.random.RandomState(21)
+    swarms = [craft_copy_pairs(rs) for _ in range(48)]
+    p = problems('bbob', D)[1]
+    n = len(swarms)
+    seeds = np.arange(n, dtype=np.uint64) * 7 + 3
+    probe = Batch(Suite([p]), ALGO_RLEPSO, np.zeros(n, int), seeds, NP, MAXFES, LOGI, NLOG)
+    probe.reset()
+    torch.cuda.synchronize()
+    template = probe.read_state(0)
+    for b, (f, P) in enumerate(swarms):
+        probe.write_state(b, state_block(template, f, P))
+    if route == 'per_generation':
+        probe.set_tape(torch.from_numpy(np.tile(replay_tape(), (n, 1))).cuda())
+        probe.step(torch.from_numpy(np.tile(ACTION, (n, 1))).cuda())
+    else:
+        tb = torch.zeros(MAXFES + 2 * NP + 1, 2, 35, dtype=torch.float32)
+        tb[:, 0] = torch.from_numpy(ACTION)
+        probe.rlepso_rollout(tb.cuda().contiguous(), 1)
+    torch.cuda.synchronize()
+    items = bad = tied = 0
+    for b, (f, P) in enumerate(swarms):
+        vel = oracle.split_rlepso_state(probe.read_state(b), NP, D, NLOG)['vel']
+        u = U_FDR if route == 'per_generation' else _philox_fdr_weights(seeds[b], NP, D)
+        tg = reference_targets(f, P)
+        agree = decode_agreement(vel, f, P, tg, u)
+        items += agree.size
+        bad += int((~agree).sum())
+        tied += _near_tie_items(f, P)
+    probe.close()
+    print(f'copy pairs ({route}): {bad} of {items} items moved with an exemplar other than np.argmin\'s; {tied} items whose two best quotients are equal or <= 2 ulp apart')
+    assert tied > 5000 and bad == 0
