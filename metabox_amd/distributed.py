@@ -52,16 +52,18 @@ COST_NS = {
 }
 
 # us per WHOLE EPISODE of one RLEPSO instance by function id (bbob 1-24, bbob-noisy 101-130), measured on one MI355X with tools/episode_costs.py at the round-6 head
+# (D = 10: one-function batches of 4096 instances, which fill the chip like a shard does -- with 1024-instance batches the expensive functions look 1.6x dearer than they are
+# in a full launch; D = 30 / 40: 1024 instances, one workgroup per CU either way)
 # (exact FDR kernels, shipped policy, the reference's stop rule: Sphere and linear slope stop early, the noisy functions carry their noise models, the step ellipsoid's
 # plateaus re-initialise).  An epoch of Tester / rollout runs whole episodes, so THESE weight the inter-rank partition (relative_cost); COST_NS above (per generation, by
 # kind) remains the fallback for functions outside the table.  Only the ratios matter.  (tools/shard_balance.py: with the per-generation weights the eight shards of
 # 8 x config 2 came out at max / mean = 1.096 -- the shards that hold Sphere / linear slope finish early -- and config 5 at 1.035.)
 EPISODE_COST_US = {
-    10: {1: 2.994, 2: 6.585, 3: 10.836, 4: 7.891, 5: 1.623, 6: 5.809, 7: 5.925, 8: 5.519, 9: 5.506, 10: 6.45, 11: 6.398, 12: 7.737, 13: 7.09, 14: 6.083, 15:
-         8.555, 16: 7.779, 17: 7.655, 18: 7.704, 19: 5.944, 20: 6.157, 21: 10.469, 22: 8.368, 23: 7.44, 24: 5.853, 101: 3.069, 102: 3.303, 103: 5.879, 104:
-         5.968, 105: 6.032, 106: 6.059, 107: 5.793, 108: 5.859, 109: 5.904, 110: 5.963, 111: 6.031, 112: 6.066, 113: 6.276, 114: 6.349, 115: 6.787, 116: 6.876,
-         117: 6.96, 118: 6.959, 119: 6.504, 120: 6.58, 121: 6.594, 122: 7.944, 123: 8.012, 124: 8.044, 125: 6.335, 126: 6.405, 127: 6.432, 128: 9.962, 129:
-         10.018, 130: 10.09},
+    10: {1: 2.06, 2: 5.49, 3: 6.599, 4: 6.06, 5: 0.882, 6: 4.785, 7: 4.8, 8: 4.582, 9: 4.534, 10: 5.31, 11: 5.267, 12: 5.705, 13: 5.18, 14: 5.018, 15: 6.403,
+         16: 6.37, 17: 6.179, 18: 6.174, 19: 4.902, 20: 5.029, 21: 6.566, 22: 6.418, 23: 6.187, 24: 4.828, 101: 2.084, 102: 2.589, 103: 4.86, 104: 4.928, 105:
+         4.98, 106: 5.01, 107: 4.783, 108: 4.85, 109: 4.864, 110: 4.926, 111: 4.977, 112: 4.997, 113: 5.225, 114: 5.277, 115: 5.539, 116: 5.649, 117: 5.709,
+         118: 5.72, 119: 5.368, 120: 5.409, 121: 5.437, 122: 6.474, 123: 6.524, 124: 6.546, 125: 5.222, 126: 5.289, 127: 5.298, 128: 8.12, 129: 8.19, 130:
+         8.244},
     30: {1: 49.839, 2: 57.49, 3: 65.793, 4: 61.253, 5: 18.096, 6: 50.424, 7: 87.195, 8: 48.966, 9: 48.867, 10: 57.466, 11: 57.787, 12: 59.006, 13: 48.687, 14:
          53.691, 15: 71.181, 16: 72.724, 17: 73.554, 18: 70.707, 19: 52.503, 20: 51.597, 21: 94.011, 22: 68.812, 23: 64.733, 24: 54.919, 101: 50.834, 102:
          50.966, 103: 51.019, 104: 51.478, 105: 51.826, 106: 52.148, 107: 50.466, 108: 50.751, 109: 50.965, 110: 51.432, 111: 51.655, 112: 51.918, 113: 57.088,
