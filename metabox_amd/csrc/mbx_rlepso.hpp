@@ -225,6 +225,9 @@ __device__ unsigned long long g_phase_cycles[8192 * 16];         // [block][phas
 #ifndef MBX_FDR_UNROLL
 #define MBX_FDR_UNROLL 4
 #endif
+#ifndef MBX_FDR_OWN_AT
+#define MBX_FDR_OWN_AT 64           // flagged items per swarm and generation above which every lane settles its own items instead of one wave per coordinate (fdr_pass)
+#endif
 
 // if (lhs < rhs) { ab = a; bb = b; kb = k; } as three EXEC-masked moves (v_cmpx + v_mov_b64 x2 + v_mov_b32) instead of the five
 // v_cndmask_b32 the compiler's if-conversion produces: the FDR scan below is VALU-issue bound and this is its innermost statement.
@@ -554,7 +557,7 @@ __device__ __forceinline__ void fdr_pass(const RlLds& L, const int* ORDER, const
     __syncthreads();
     if constexpr (TIE) {
         const int n = *L.FLN;                                     // workgroup-uniform
-        if (n > 0 && (n <= 64 || NI > 32 * THREADS)) {
+        if (n > 0 && (n <= MBX_FDR_OWN_AT || NI > 32 * THREADS)) {
             for (int c = tid >> 6; c < W * n; c += THREADS / 64) {      // one wave per flagged COORDINATE
                 const int ps = L.FL[c / W], rk = fw.div(ps), d = W * (ps - rk * DW) + c % W;
                 const int kbest = fdr_settle(L, ORDER, D, rk, d, NLESS[ORDER[rk]], L.KB[rk * D + d], cnt);
