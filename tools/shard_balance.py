@@ -63,11 +63,7 @@ def rlepso_case(dim, np_, total, suites):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        done = 0
-        while done < gens:
-            n = min(50, gens - done)
-            b.rlepso_rollout(table, n)                                          # instances that finish leave their launch: whole episodes under the reference's stop rule
-            done += n
+        b.rlepso_rollout(table, gens)                                           # the whole episode in ONE launch, like RLEPSO_Agent.rollout_batch; instances that finish leave it
         e1.record()
         torch.cuda.synchronize()
         rows = mdist.pack_rows(b.results()).clone()
