@@ -3,7 +3,7 @@
 run:   python tools/profile_recompute.py gpurun_out/<tag>   (tools/profile_round.sh calls it; the paragraph goes into profiles/README.md)
 
 The traced command is `bench.py --steps 199 --warmup 0 --repeats R`: every k_rlepso_run launch of it is a timed launch (no warm-up launches
-to subtract), R x 199 lock-step generations in R x 4 launches.
+to subtract), R x 199 lock-step generations in R whole-episode launches (round 6; R x 4 launches of <= 50 generations before).
   fraction = 54 057 B x env-steps of all repeats / total duration of k_rlepso_run in the trace / 8e12 B/s."""
 import csv, json, os, sys
 

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/bench_steps20_warmup5.json" 2>> "$OUT/bench.err"     # the driver's window
 # headline command alone (no plugin_view / other_configs legs: they launch the same kernels on other batch sizes and would pollute the averages)
-# (--warmup 0 --repeats 5: every k_rlepso_run launch in the trace is a timed one, 5 x 199 generations in 5 x 4 launches -- tools/profile_recompute.py divides)
+# (--warmup 0 --repeats 5: every k_rlepso_run launch in the trace is a timed one, 5 x 199 generations in 5 whole-episode launches -- tools/profile_recompute.py divides)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python "$ROOT/bench.py" --steps 199 --warmup 0 --repeats 5 --no-cpu-baseline --no-other-configs --no-pmc --no-fdr-fast > "$OUT/trace.log" 2>&1
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 # the side legs (B = 1 plugin view, configs 3 / 4 / 5) in a trace of their own
