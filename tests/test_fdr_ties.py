@@ -480,3 +480,55 @@ def test_hip_fdr_with_copies_in_half_of_the_coordinates(route):
     probe.close()
     print(f'copy pairs ({route}): {bad} of {items} items moved with an exemplar other than np.argmin\'s; {tied} items whose two best quotients are equal or <= 2 ulp apart')
     assert tied > 5000 and bad == 0
+
+
+def craft_grid_swarm(rs, NP=NP, D=D, cost_levels=12, step=0.25):
+    """Low-entropy swarm: pbest costs from a dozen levels, coordinates on a 0.25 grid inside the box -- equal costs, equal denominators, whole-row copies, candidates that
+    tie in one coordinate and differ in the next, query particles with nobody better: every tie-breaking rule of np.argmin is exercised in every swarm."""
+    f = 1000. - 3. * rs.randint(0, cost_levels, NP)
+    P = step * rs.randint(-16, 17, (NP, D)).astype(np.float64)
+    for _ in range(NP // 10):                             # some whole-row copies (same cost, same position), as on a collapsed linear slope
+        a, b = rs.choice(NP, 2, replace=False)
+        f[b], P[b] = f[a], P[a]
+    return f, P
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('route', ['per_generation', 'resident'])
+@pytest.mark.parametrize('np_,dim', [(100, 10), (128, 40)])
+def test_hip_fdr_on_grid_swarms(np_, dim, route):
+    """craft_grid_swarm through both routes and both BASELINE geometries: the velocity of every (particle, dimension) item must be the one np.argmin's exemplar gives."""
+    import torch
+    from metabox_amd.suite import Batch, Suite
+    from metabox_amd._abi import ALGO_RLEPSO
+    rs = np.random.RandomState(100 + dim)
+    swarms = [craft_grid_swarm(rs, np_, dim, cost_levels=(4, 12, 40)[k % 3]) for k in range(48 if dim == 10 else 12)]
+    maxfes = 2000 * dim
+    p = problems('bbob', dim)[1]
+    n = len(swarms)
+    seeds = np.arange(n, dtype=np.uint64) * 7 + 3
+    probe = Batch(Suite([p]), ALGO_RLEPSO, np.zeros(n, int), seeds, np_, maxfes, maxfes // NLOG, NLOG)
+    assert probe.flags == 0 and probe.rollout_is_resident()
+    probe.reset()
+    torch.cuda.synchronize()
+    template = probe.read_state(0)
+    for b, (f, P) in enumerate(swarms):
+        probe.write_state(b, state_block(template, f, P))
+    if route == 'per_generation':
+        probe.set_tape(torch.from_numpy(np.tile(replay_tape(np_, dim), (n, 1))).cuda())
+        probe.step(torch.from_numpy(np.tile(ACTION, (n, 1))).cuda())
+    else:
+        tb = torch.zeros(maxfes + 2 * np_ + 1, 2, 35, dtype=torch.float32)
+        tb[:, 0] = torch.from_numpy(ACTION)
+        probe.rlepso_rollout(tb.cuda().contiguous(), 1)
+    torch.cuda.synchronize()
+    items = bad = 0
+    for b, (f, P) in enumerate(swarms):
+        vel = oracle.split_rlepso_state(probe.read_state(b), np_, dim, NLOG)['vel']
+        u = U_FDR if route == 'per_generation' else _philox_fdr_weights(seeds[b], np_, dim)
+        agree = decode_agreement(vel, f, P, reference_targets(f, P), u)
+        items += agree.size
+        bad += int((~agree).sum())
+    probe.close()
+    print(f'grid swarms NP {np_} / D {dim} ({route}): {bad} of {items} items moved with an exemplar other than np.argmin\'s')
+    assert bad == 0
