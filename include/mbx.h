@@ -80,6 +80,10 @@ int mbx_suite_destroy(mbx_suite* s);
 int mbx_suite_size(const mbx_suite* s);
 /* host copy of optimum_i (problem.optimum; NaN = None) */
 int mbx_suite_optimum(const mbx_suite* s, double* optimum_out /* [n_problems] */);
+/* Protein docking: the number of atom pairs i < j the energy kernel walks for a candidate inside the box -- the pairs that can reach the 9 A cut-off (the rest of the 4950
+ * are provably beyond it: an atom moves by at most ub |sum_k v0_k |basis_k||_2).  What the inter-rank partition weights a protein problem with
+ * (metabox_amd/problem/protein_docking.py: close_pairs computes the same number on the host; tests/test_protein.py compares the two).  -1 for a BBOB problem. */
+int mbx_suite_close_pairs(const mbx_suite* s, int problem);
 
 /* Stand-alone objective evaluation: Basic_Problem.eval / F*.func (src/problem/basic_problem.py:12-34).
  * d_x is [n, dim] row-major, d_f is [n]; the bias is included, the optimum is NOT subtracted.

@@ -121,6 +121,7 @@ def load_lib():
         'mbx_suite_destroy': (C.c_int, [vp]),
         'mbx_suite_size': (C.c_int, [vp]),
         'mbx_suite_optimum': (C.c_int, [vp, c_double_p]),
+        'mbx_suite_close_pairs': (C.c_int, [vp, C.c_int]),
         'mbx_eval': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, u64, vp, vp]),
         'mbx_state_dim': (C.c_int, [C.POINTER(AlgoCfg)]),
         'mbx_action_dim': (C.c_int, [C.POINTER(AlgoCfg)]),
@@ -168,7 +169,7 @@ def load_lib():
     return lib
 
 
-EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_eval', 'mbx_state_dim', 'mbx_action_dim',
+EXPORTED_SYMBOLS = ('mbx_suite_create', 'mbx_suite_destroy', 'mbx_suite_size', 'mbx_suite_optimum', 'mbx_suite_close_pairs', 'mbx_eval', 'mbx_state_dim', 'mbx_action_dim',
                     'mbx_tape_stride', 'mbx_batch_create', 'mbx_batch_destroy', 'mbx_batch_flags', 'mbx_set_tape', 'mbx_reset', 'mbx_step', 'mbx_results',
                     'mbx_gauss_policy', 'mbx_lde_policy', 'mbx_ddqn_qnet', 'mbx_rlepso_policy_table_rows', 'mbx_rlepso_policy_table', 'mbx_rlepso_act_step',
                     'mbx_rlepso_rollout_resident', 'mbx_rlepso_rollout', 'mbx_lde_rollout_resident', 'mbx_lde_rollout', 'mbx_rlpso_rollout',

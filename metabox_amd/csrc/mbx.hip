@@ -431,6 +431,12 @@ extern "C" int mbx_suite_optimum(const mbx_suite* s, double* optimum_out)
     return MBX_OK;
 }
 
+extern "C" int mbx_suite_close_pairs(const mbx_suite* s, int problem)
+{
+    if (!s || problem < 0 || problem >= s->n) return fail(MBX_E_ARG, "mbx_suite_close_pairs: bad arguments");
+    return s->h_problems[problem].kind == MBX_KIND_PROTEIN ? s->h_problems[problem].n_close : -1;
+}
+
 extern "C" int mbx_eval(mbx_suite* s, int problem, const double* d_x, int n, double* d_f, int noisy, uint64_t seed,
                         const double* d_noise_draws, void* stream)
 {

@@ -237,3 +237,20 @@ def test_protein_rlepso_resident_rollout_equals_per_generation_and_matches_the_o
         assert close(got['scalars'][oracle.SC_GBEST], want['scalars'][oracle.SC_GBEST]) and got['scalars'][oracle.SC_FES] == want['scalars'][oracle.SC_FES], k
         assert close(got['pbest'], want['pbest']) and close(got['cost'], want['cost']), k
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_close_pair_counts_of_host_and_library_agree():
+    """The inter-rank partition weights a protein problem with its close-pair count computed on the host (Protein_Docking.close_pairs); the energy kernel walks the count
+    mbx_suite_create computed (mbx_suite_close_pairs).  Same bound, two implementations: they must give the same number for all 280 problems."""
+    from metabox_amd.config import get_config
+    from metabox_amd.suite import Suite
+    from metabox_amd.utils import construct_problem_set
+    cfg = get_config(['--problem', 'protein', '--device', 'cuda'])
+    tr, te = construct_problem_set(cfg)
+    ps = (tr + te).data
+    s = Suite(ps)
+    lib_counts = [int(s.lib.mbx_suite_close_pairs(s._h, i)) for i in range(len(ps))]
+    host_counts = [p.close_pairs() for p in ps]
+    assert lib_counts == host_counts and min(lib_counts) == 1771 and max(lib_counts) == 3826
+    s.close()
